@@ -1,0 +1,117 @@
+"""The CPU oracle against the fixtures captured from the reference's own Python
+(tests/golden/make_golden.py) and against the independent exhaustive enumerator."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_cdist_bit_exact(golden_dir):
+    g = _load(golden_dir, "cdist.npz")
+    M = O.cdist(g["X"])
+    assert np.array_equal(M, g["M"])  # scipy cdist == sequential non-FMA sum, then sqrt
+    assert M[3, 5] == 0.0
+
+
+def test_find_nearest_matches_reference_selection(golden_dir):
+    g = _load(golden_dir, "find_nearest.npz")
+    X, labels, m = g["X"], g["labels"], int(g["m"])
+    for i, c, want in zip(g["rows"], g["bins"], g["selected_sorted"]):
+        cur = labels.copy()
+        cur[i] = -1
+        got = O.find_nearest_from_cluster(int(c), cur, O.cdist_row(X, int(i)), m)
+        want = want[want >= 0]
+        assert np.array_equal(np.sort(got), want), (i, c)
+        # documented ordering: (distance, index) ascending
+        d = O.cdist_row(X, int(i))[got]
+        assert np.all(np.diff(d) >= 0)
+
+
+def test_qp_argument_construction(golden_dir):
+    """solve_qp.py:44-51: G' = nearestPD(2XX^T), a = 2Xx, C = [-1 | I], b = [-1, -0...], meq=1."""
+    g = _load(golden_dir, "qp_args.npz")
+    for k in range(len(g["m"])):
+        m = int(g["m"][k])
+        P, x = g["P"][k][:m], g["x"][k]
+        G_ref, a_ref = g["G"][k][:m, :m], g["a"][k][:m]
+        Pm = 2.0 * P @ P.T
+        G = O.nearest_positive_definite(Pm)
+        scale = np.abs(Pm).max()
+        assert np.allclose(G, G_ref, rtol=0, atol=1e-12 * scale)
+        assert np.allclose(2.0 * P @ x, a_ref, rtol=1e-14, atol=0)
+        C_ref, b_ref = g["C"][k][:m, : m + 1], g["b"][k][: m + 1]
+        assert np.array_equal(C_ref, np.hstack([-np.ones((m, 1)), np.eye(m)]))
+        assert np.array_equal(b_ref, np.concatenate([[-1.0], np.zeros(m)]))
+        assert int(g["meq"][k]) == 1
+        # the recorded tuple solved by the restated Goldfarb-Idnani agrees with the enumerator
+        alpha = O.gi_solve(G_ref, a_ref, C_ref, b_ref, 1)
+        d_gi = np.linalg.norm(alpha @ P - x)
+        assert abs(d_gi - O.enum_hull_distance(x, P)) < 1e-7
+        assert abs(O.convex_hull_distance(x, P) - g["dist_with_oracle_gi"][k]) < 1e-9
+
+
+def test_fit_cluster_control_flow(golden_dir):
+    """Labels from the reference's own fit_cluster loop == the oracle's restated loop."""
+    g = _load(golden_dir, "fit_cluster_flow.npz")
+    labels, its, changed = O.fit_cluster(g["X"], int(g["B"]), g["initial"], g["perms"],
+                                         int(g["m"]), int(g["max_iter"]))
+    assert np.array_equal(labels, g["labels"])
+    assert its >= 3 and changed[-1] == 0
+    # with the precomputed matrix (InMemDistMatrix=yes semantics) nothing changes
+    labels2, _, _ = O.fit_cluster(g["X"], int(g["B"]), g["initial"], g["perms"], int(g["m"]),
+                                  int(g["max_iter"]), dm=O.cdist(g["X"]))
+    assert np.array_equal(labels2, labels)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_gi_vs_enumerator_random(seed):
+    rng = np.random.default_rng(seed)
+    for trial in range(400):
+        m = int(rng.integers(1, 9))
+        D = int(rng.integers(2, 60))
+        P = rng.random((m, D))
+        kind = trial % 5
+        if kind == 0:
+            x = rng.random(D)
+        elif kind == 1:
+            x = rng.dirichlet(np.ones(m)) @ P
+        elif kind == 2:
+            x = rng.random(D) * 3 - 1
+        elif kind == 3:
+            x = P[rng.integers(m)] + 1e-3 * rng.standard_normal(D)
+        else:
+            if m > 1:
+                P[m - 1] = P[0]
+            x = rng.random(D)
+        d_gi = O.convex_hull_distance(x, P)
+        d_en = O.enum_hull_distance(x, P)
+        assert abs(d_gi - d_en) < 1e-8 * max(1.0, d_en), (seed, trial, m, D, kind)
+
+
+def test_closed_forms():
+    rng = np.random.default_rng(5)
+    D = 136
+    x = rng.random(D) / D
+    p = rng.random((1, D)) / D
+    # m = 1: Euclidean distance
+    assert abs(O.convex_hull_distance(x, p) - np.linalg.norm(x - p[0])) < 1e-15
+    # m = 2: clamped segment projection
+    P = rng.random((2, D)) / D
+    t = np.clip(np.dot(x - P[0], P[1] - P[0]) / np.dot(P[1] - P[0], P[1] - P[0]), 0, 1)
+    want = np.linalg.norm(P[0] + t * (P[1] - P[0]) - x)
+    assert abs(O.convex_hull_distance(x, P) - want) < 1e-12
+    # empty hull guard
+    d, st = O.convex_hull_distance(x, np.zeros((0, D)), return_status=True)
+    assert np.isinf(d) and st == 2
+    # invariance: vertex permutation and translation
+    P = rng.random((5, D)) / D
+    d0 = O.convex_hull_distance(x, P)
+    assert abs(O.convex_hull_distance(x, P[::-1].copy()) - d0) < 1e-12
+    sh = rng.random(D)
+    assert abs(O.convex_hull_distance(x + sh, P + sh) - d0) < 1e-10
