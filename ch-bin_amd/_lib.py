@@ -1,0 +1,248 @@
+"""ctypes binding of libchbin_hip.so (C ABI: include/chbin_hip.h).
+
+Fails loudly: if the shared library has not been built, or no MI355X is visible, every compute
+call raises -- there is no CPU fallback in this package.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchbin_hip.so")
+
+CHB_MAX_NEIGHBORS = 16
+
+_lib = None
+_lock = threading.Lock()
+_ctx_by_device = {}
+
+
+class ChbError(RuntimeError):
+    pass
+
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+# every symbol include/chbin_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "chb_last_error": (C.c_char_p, []),
+    "chb_version": (C.c_int, []),
+    "chb_device_count": (C.c_int, []),
+    "chb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "chb_destroy": (C.c_int, [C.c_void_p]),
+    "chb_set_samples": (C.c_int, [C.c_void_p, _f64p, C.c_int64, C.c_int64]),
+    "chb_set_samples_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "chb_pairwise_distance": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _f64p]),
+    "chb_topm_per_bin": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_int, _i64p, C.c_int64, _i64p,
+                                   C.c_void_p, _i32p]),
+    "chb_find_nearest_from_row": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _f64p, C.c_int64, C.c_int,
+                                            _i64p, C.POINTER(C.c_int32)]),
+    "chb_hull_distance_batch": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _i64p, C.c_int, _f64p,
+                                          C.c_void_p]),
+    "chb_hull_distance_points": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int, C.c_int64,
+                                           C.POINTER(C.c_double), C.c_void_p]),
+    "chb_fit_cluster": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, C.c_int64, C.c_int, C.c_int,
+                                  C.c_int, _i64p, C.POINTER(C.c_int), _i64p, C.c_void_p]),
+    "chb_fit_begin": (C.c_int, [C.c_void_p, C.c_int64, _i64p, C.c_int]),
+    "chb_batch_begin": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_int64, C.c_int64]),
+    "chb_batch_round": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _i64p, C.c_void_p]),
+    "chb_batch_commit": (C.c_int, [C.c_void_p, _i64p]),
+    "chb_fit_labels": (C.c_int, [C.c_void_p, _i64p]),
+    "chb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "chb_profile_reset": (C.c_int, [C.c_void_p]),
+    "chb_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "chb_fit_stats": (C.c_int, [C.c_void_p, _i64p]),
+}
+
+
+def load():
+    """dlopen the HIP library and declare every entry point (no GPU needed for this)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ChbError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                    "g.build()'` (or `make -C ch-bin_amd/csrc`). There is no CPU fallback.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().chb_last_error()
+        raise ChbError(f"libchbin_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+class Context:
+    """One libchbin_hip context (one GPU).  Holds the resident feature matrix."""
+
+    def __init__(self, device=0):
+        lib = load()
+        if lib.chb_device_count() <= 0:
+            raise ChbError("no HIP device visible: chbin_amd needs an MI355X (no CPU fallback)")
+        self._h = C.c_void_p()
+        check(lib.chb_create(int(device), C.byref(self._h)))
+        self._lib = lib
+        self.device = int(device)
+        self._samples_key = None
+        self.N = self.D = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.chb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- samples
+    def set_samples(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float64)  # DataFrame.values may be F-ordered
+        if X.ndim != 2:
+            raise ValueError("samples must be a 2-D array")
+        check(self._lib.chb_set_samples(self._h, X, X.shape[0], X.shape[1]))
+        self.N, self.D = X.shape
+        self._samples_key = None
+
+    def set_samples_cached(self, X):
+        """Upload only if this is not the array that is already resident."""
+        key = (X.__array_interface__["data"][0], X.shape, X.strides, str(X.dtype))
+        if key != self._samples_key:
+            self.set_samples(X)
+            self._samples_key = key
+
+    def set_samples_device(self, ptr, N, D):
+        check(self._lib.chb_set_samples_device(self._h, C.c_void_p(int(ptr)), int(N), int(D)))
+        self.N, self.D = int(N), int(D)
+        self._samples_key = None
+
+    # ---- entry points
+    def pairwise_distance(self, r0=0, r1=None):
+        r1 = self.N if r1 is None else r1
+        out = np.empty((r1 - r0, self.N), dtype=np.float64)
+        check(self._lib.chb_pairwise_distance(self._h, int(r0), int(r1), out))
+        return out
+
+    def topm_per_bin(self, labels, B, m, query_idx):
+        labels = np.ascontiguousarray(labels, dtype=np.int64)
+        q = np.ascontiguousarray(query_idx, dtype=np.int64)
+        Q = q.shape[0]
+        idx = np.empty((Q, B, m), dtype=np.int64)
+        dist = np.empty((Q, B, m), dtype=np.float64)
+        cnt = np.empty((Q, B), dtype=np.int32)
+        check(self._lib.chb_topm_per_bin(self._h, labels, int(B), int(m), q, Q, idx,
+                                         dist.ctypes.data, cnt))
+        return idx, dist, cnt
+
+    def find_nearest_from_row(self, c, labels, row, m):
+        labels = np.ascontiguousarray(labels, dtype=np.int64)
+        row = np.ascontiguousarray(row, dtype=np.float64)
+        out = np.empty(max(int(m), 1), dtype=np.int64)
+        cnt = C.c_int32(0)
+        check(self._lib.chb_find_nearest_from_row(self._h, int(c), labels, row, labels.shape[0],
+                                                  int(m), out, C.byref(cnt)))
+        return out[: cnt.value].copy()
+
+    def hull_distance_batch(self, query_idx, hull_idx, want_alpha=False):
+        q = np.ascontiguousarray(query_idx, dtype=np.int64)
+        hx = np.ascontiguousarray(hull_idx, dtype=np.int64)
+        P, m_max = hx.shape
+        dist = np.empty(P, dtype=np.float64)
+        alpha = np.zeros((P, m_max), dtype=np.float64) if want_alpha else None
+        check(self._lib.chb_hull_distance_batch(self._h, q, P, hx, int(m_max), dist,
+                                                None if alpha is None else alpha.ctypes.data))
+        return (dist, alpha) if want_alpha else dist
+
+    def hull_distance_points(self, x, pts, want_alpha=False):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, x.shape[0])
+        m = pts.shape[0]
+        d = C.c_double(0.0)
+        alpha = np.zeros(max(m, 1), dtype=np.float64)
+        if m == 0:
+            pts = np.zeros((1, x.shape[0]))
+        check(self._lib.chb_hull_distance_points(self._h, x, pts, int(m), x.shape[0], C.byref(d),
+                                                 alpha.ctypes.data))
+        return (d.value, alpha[:m]) if want_alpha else d.value
+
+    def fit_cluster(self, B, initial_bins, perms, m, max_iter, batch=0, want_min_dist=False):
+        initial = np.ascontiguousarray(initial_bins, dtype=np.int64)
+        perms = np.ascontiguousarray(perms, dtype=np.int64).reshape(max_iter, -1) \
+            if max_iter > 0 else np.zeros((0, 0), dtype=np.int64)
+        n_move = perms.shape[1] if max_iter > 0 else 0
+        out = np.empty(self.N, dtype=np.int64)
+        changed = np.zeros(max(max_iter, 1), dtype=np.int64)
+        iters = C.c_int(0)
+        mind = np.empty(self.N, dtype=np.float64) if want_min_dist else None
+        perms_arg = perms if perms.size else np.zeros(1, dtype=np.int64)
+        check(self._lib.chb_fit_cluster(self._h, int(B), initial, perms_arg, int(n_move), int(m),
+                                        int(max_iter), int(batch), out, C.byref(iters), changed,
+                                        None if mind is None else mind.ctypes.data))
+        res = (out, iters.value, changed[: iters.value])
+        return res + (mind,) if want_min_dist else res
+
+    # stepwise (multi-GPU driver)
+    def fit_begin(self, B, initial_bins, m):
+        check(self._lib.chb_fit_begin(self._h, int(B), np.ascontiguousarray(initial_bins, dtype=np.int64), int(m)))
+
+    def batch_begin(self, perm_slice, q_lo, q_hi):
+        p = np.ascontiguousarray(perm_slice, dtype=np.int64)
+        check(self._lib.chb_batch_begin(self._h, p, p.shape[0], int(q_lo), int(q_hi)))
+
+    def batch_round(self, lab_prev, active, lab_new, min_dist=None):
+        check(self._lib.chb_batch_round(self._h, np.ascontiguousarray(lab_prev, dtype=np.int64),
+                                        int(active), lab_new,
+                                        None if min_dist is None else min_dist.ctypes.data))
+
+    def batch_commit(self, final_labels):
+        check(self._lib.chb_batch_commit(self._h, np.ascontiguousarray(final_labels, dtype=np.int64)))
+
+    def fit_labels(self):
+        out = np.empty(self.N, dtype=np.int64)
+        check(self._lib.chb_fit_labels(self._h, out))
+        return out
+
+    # measurement
+    def profile_enable(self, on=True):
+        check(self._lib.chb_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self._lib.chb_profile_reset(self._h))
+
+    def profile_get(self, kernel):
+        ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
+        check(self._lib.chb_profile_get(self._h, kernel.encode(), C.byref(ms), C.byref(n), C.byref(w)))
+        return {"ms": ms.value, "launches": n.value, "work": w.value}
+
+    def fit_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        check(self._lib.chb_fit_stats(self._h, out))
+        return {"batches": int(out[0]), "rounds": int(out[1]), "hull_evaluated": int(out[2]),
+                "hull_needed": int(out[3])}
+
+
+def default_context(device=None):
+    """Process-wide context for `device` (default: LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("CHBIN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _lock:
+        ctx = _ctx_by_device.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        with _lock:
+            _ctx_by_device[device] = ctx
+    return ctx

@@ -1,0 +1,10 @@
+"""Host-side mirror of the reference package `ch_bin.core.clustering` (same function names,
+argument meaning and error behaviour) on top of libchbin_hip.so."""
+from .algorithm import fit_cluster  # noqa: F401
+from .distance_matrix import (  # noqa: F401
+    create_distance_matrix,
+    create_in_mem_distance_matrix,
+    find_nearest_from_cluster,
+)
+from .hull_distance import calculate_distance, convex_hull_distance  # noqa: F401
+from .solve_qp import SOLVERS, solve_qp  # noqa: F401

@@ -1,0 +1,233 @@
+// Label bookkeeping kernels of the speculative-batch sweep: membership buckets (CSR by bin),
+// the strict-'>' argmin over bins (algorithm.py:47-60) and the first-changed-position reduction.
+#include "chb_internal.h"
+
+namespace chb {
+namespace {
+
+constexpr double kInf = __builtin_huge_val();
+
+__global__ void fill_i32_kernel(int *p, int v, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void mark_batch_kernel(int *inb, const int *bq, int K, int set)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) inb[bq[i]] = set ? i : -1;
+}
+
+__global__ void gather_labels_kernel(const int *labels, const int *bq, int K, int *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) out[i] = labels[bq[i]];
+}
+
+__global__ void scatter_labels_kernel(int *labels, const int *bq, const int *lab, int K)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) labels[bq[i]] = lab[i];
+}
+
+// ---- base members: every labelled sample that is not in the current batch
+
+__global__ void count_base_kernel(const int *labels, const int *inb, int N, int B, int *cnt)
+{
+    extern __shared__ int hist[];
+    for (int b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
+        const int l = labels[p];
+        if (l >= 0 && l < B && inb[p] < 0) atomicAdd(&hist[l], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x)
+        if (hist[b]) atomicAdd(&cnt[b], hist[b]);
+}
+
+__global__ void scan_kernel(const int *cnt, int B, int *bin_ptr, int *cursor)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < B; ++b) {
+            bin_ptr[b] = run;
+            cursor[b] = run;
+            run += cnt[b];
+        }
+        bin_ptr[B] = run;
+    }
+}
+
+__global__ void fill_base_kernel(const int *labels, const int *inb, int N, int B, int *cursor,
+                                 int *memb_id)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const int l = labels[p];
+    if (l >= 0 && l < B && inb[p] < 0) memb_id[atomicAdd(&cursor[l], 1)] = p;
+}
+
+// ---- the batch's own members.  Position i appears (a) in bin lab_prev[i] for every LATER query
+// (code i+1: eligible iff query pos > i) -- its speculative new label -- and (b) in bin lab_old[i]
+// for every EARLIER query (code -(i+1): eligible iff query pos < i) -- it has not been visited yet
+// when those queries run (algorithm.py:46-60 visits in permutation order).
+// lab_old == nullptr selects the "everyone but myself" form used by chb_topm_per_bin:
+// code -(1<<30) - i, eligible iff query pos != i.
+
+__global__ void count_batch_kernel(const int *lab_prev, const int *lab_old, int K, int B, int *cnt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const int a = lab_prev[i];
+    if (a >= 0 && a < B) atomicAdd(&cnt[a], 1);
+    if (lab_old) {
+        const int b = lab_old[i];
+        if (b >= 0 && b < B) atomicAdd(&cnt[b], 1);
+    }
+}
+
+__global__ void fill_batch_kernel(const int *lab_prev, const int *lab_old, const int *bq, int K,
+                                  int B, int *cursor, int *memb_id, int *memb_code)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const int a = lab_prev[i];
+    if (a >= 0 && a < B) {
+        const int e = atomicAdd(&cursor[a], 1);
+        memb_id[e] = bq[i];
+        memb_code[e] = lab_old ? (i + 1) : (-(1 << 30) - i);
+    }
+    if (lab_old) {
+        const int b = lab_old[i];
+        if (b >= 0 && b < B) {
+            const int e = atomicAdd(&cursor[b], 1);
+            memb_id[e] = bq[i];
+            memb_code[e] = -(i + 1);
+        }
+    }
+}
+
+// algorithm.py:47-60: min_distance = inf, min_cluster = current label; strict '>' so the lowest
+// bin wins ties and NaN never wins.
+__global__ void argmin_kernel(const double *dist, const int *lab_old, const int *lab_prev,
+                              int pos_begin, int pos_end, int B, int *lab_new, double *mind,
+                              int *first_change)
+{
+    const int pos = pos_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= pos_end) return;
+    double best = kInf;
+    int bc = lab_old[pos];
+    const double *row = dist + (size_t)pos * B;
+    for (int c = 0; c < B; ++c) {
+        const double d = row[c];
+        if (best > d) { best = d; bc = c; }
+    }
+    lab_new[pos] = bc;
+    mind[pos] = best;
+    if (bc != lab_prev[pos]) atomicMin(first_change, pos);
+}
+
+// distance_matrix.py:47-62 on a caller-supplied distance row: m rounds of a block-wide
+// lexicographic (distance, index) argmin above the previously selected key.
+__global__ __launch_bounds__(256) void select_row_kernel(const int *labels, const double *row, int N,
+                                                         int c, int m, int *out_idx, int *out_cnt)
+{
+    __shared__ double sd[256];
+    __shared__ int si[256];
+    double last_d = -kInf;
+    int last_i = -1, cnt = 0;
+    for (int r = 0; r < m; ++r) {
+        double bd = kInf;
+        int bi = 0x7fffffff;
+        for (int p = threadIdx.x; p < N; p += 256) {
+            if (labels[p] != c) continue;
+            const double d = row[p];
+            if (!(d == d)) continue;  // NaN never selected
+            const bool above = d > last_d || (d == last_d && p > last_i);
+            if (above && (d < bd || (d == bd && p < bi))) { bd = d; bi = p; }
+        }
+        sd[threadIdx.x] = bd; si[threadIdx.x] = bi;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if ((int)threadIdx.x < off) {
+                const double od = sd[threadIdx.x + off];
+                const int oi = si[threadIdx.x + off];
+                if (od < sd[threadIdx.x] || (od == sd[threadIdx.x] && oi < si[threadIdx.x])) {
+                    sd[threadIdx.x] = od; si[threadIdx.x] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        const double gd = sd[0];
+        const int gi = si[0];
+        __syncthreads();
+        if (gi == 0x7fffffff) break;
+        if (threadIdx.x == 0) out_idx[r] = gi;
+        last_d = gd; last_i = gi; ++cnt;
+    }
+    if (threadIdx.x == 0) {
+        for (int r = cnt; r < m; ++r) out_idx[r] = -1;
+        *out_cnt = cnt;
+    }
+}
+
+}  // namespace
+
+void launch_select_row(const int *labels, const double *row, int N, int c, int m, int *out_idx,
+                       int *out_cnt, hipStream_t s)
+{
+    hipLaunchKernelGGL(select_row_kernel, dim3(1), dim3(256), 0, s, labels, row, N, c, m, out_idx, out_cnt);
+}
+
+void launch_fill_i32(int *p, int v, int n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+}
+void launch_mark_batch(int *inb, const int *bq, int K, int set, hipStream_t s)
+{
+    if (K > 0) hipLaunchKernelGGL(mark_batch_kernel, dim3((K + 255) / 256), dim3(256), 0, s, inb, bq, K, set);
+}
+void launch_gather_labels(const int *labels, const int *bq, int K, int *out, hipStream_t s)
+{
+    if (K > 0) hipLaunchKernelGGL(gather_labels_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, bq, K, out);
+}
+void launch_scatter_labels(int *labels, const int *bq, const int *lab, int K, hipStream_t s)
+{
+    if (K > 0) hipLaunchKernelGGL(scatter_labels_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, bq, lab, K);
+}
+
+void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
+                        int *cursor, int *memb_id, hipStream_t s)
+{
+    launch_fill_i32(cnt, 0, B, s);
+    int blocks = (N + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, cnt, B, bin_ptr, cursor);
+    hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 0, s, labels, inb, N, B, cursor, memb_id);
+}
+
+void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
+                         int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code,
+                         hipStream_t s)
+{
+    launch_fill_i32(cnt, 0, B, s);
+    if (K > 0)
+        hipLaunchKernelGGL(count_batch_kernel, dim3((K + 255) / 256), dim3(256), 0, s, lab_prev, lab_old, K, B, cnt);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, cnt, B, bin_ptr, cursor);
+    if (K > 0)
+        hipLaunchKernelGGL(fill_batch_kernel, dim3((K + 255) / 256), dim3(256), 0, s, lab_prev, lab_old, bq, K, B, cursor, memb_id, memb_code);
+}
+
+void launch_argmin(const double *dist, const int *lab_old, const int *lab_prev, int pos_begin,
+                   int pos_end, int B, int *lab_new, double *mind, int *first_change,
+                   hipStream_t s)
+{
+    const int n = pos_end - pos_begin;
+    if (n > 0)
+        hipLaunchKernelGGL(argmin_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dist, lab_old, lab_prev, pos_begin, pos_end, B, lab_new, mind, first_change);
+}
+
+}  // namespace chb

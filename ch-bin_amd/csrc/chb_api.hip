@@ -1,0 +1,764 @@
+// Host side of libchbin_hip.so: the C ABI declared in include/chbin_hip.h.
+//
+// The fit loop reproduces algorithm.py:37-76 exactly -- including the in-place (Gauss-Seidel)
+// label updates -- while evaluating K contigs at a time:
+//
+//   batch = K consecutive positions of the sweep's permutation.
+//   T0(j,c): the m nearest members of bin c among samples OUTSIDE the batch (labels frozen at batch
+//            start).  One heavy launch per batch (topm_base).
+//   round r: every position j takes, for each bin c, T0(j,c) merged with the batch members that
+//            belong to c when j is visited: EARLIER positions under their label of round r-1,
+//            LATER positions under their pre-batch label (they have not been visited yet).
+//            Then hull distances, strict-'>' argmin (algorithm.py:57), giving label_r.
+//   Let f = first position with label_r != label_{r-1}.  Positions <= f were computed from labels
+//   that can no longer change, hence are final; the next round only re-evaluates positions > f.
+//   No change (f = K) means label_r is the unique fixed point = the sequential result.
+// In sweep 1 the pre-batch labels of the batch are all -1; in later sweeps they are last sweep's
+// labels and a batch typically converges in one round.
+#include "chb_internal.h"
+#include "../../include/chbin_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+using namespace chb;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(CHB_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+struct ProfEntry {
+    double ms = 0.0;
+    int64_t launches = 0;
+    double work = 0.0;
+};
+
+struct Pending {
+    hipEvent_t a, b;
+    std::string name;
+    double work;
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct chb_ctx {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    // samples
+    DevBuf<double> X;
+    int64_t N = 0;
+    int D = 0, Dp = 0;
+    // fit state
+    int B = 0, m = 0;
+    bool fit_open = false;
+    DevBuf<int> labels, inb;
+    // batch state
+    int K = 0, Kcap = 0, q_lo = 0, q_hi = 0;
+    bool batch_open = false;
+    DevBuf<int> bq, lab_old, lab_prev, lab_new, first_change;
+    DevBuf<double> mind, dist;
+    DevBuf<double> l0d, l1d;
+    DevBuf<int> l0i, l1i, l0c, l1c;
+    DevBuf<int> cnt, bin_ptr, cursor, memb_id;
+    DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
+    DevBuf<int> perm;
+    // scratch for the indexed / explicit-point entry points
+    DevBuf<int> xq, xhull;
+    DevBuf<double> xdist, xalpha, xpts;
+    // profiling
+    bool prof = false;
+    std::map<std::string, ProfEntry> prof_acc;
+    std::vector<Pending> pending;
+    int64_t stats[4] = {0, 0, 0, 0};
+
+    Lists L0() { return Lists{l0d.p, l0i.p, l0c.p}; }
+    Lists L1() { return Lists{l1d.p, l1i.p, l1c.p}; }
+};
+
+namespace {
+
+struct Timed {
+    chb_ctx *h;
+    Pending p;
+    bool on;
+    Timed(chb_ctx *h_, const char *name, double work) : h(h_), on(h_->prof)
+    {
+        if (!on) return;
+        p.name = name; p.work = work;
+        (void)hipEventCreate(&p.a);
+        (void)hipEventCreate(&p.b);
+        (void)hipEventRecord(p.a, h->stream);
+    }
+    ~Timed()
+    {
+        if (!on) return;
+        (void)hipEventRecord(p.b, h->stream);
+        h->pending.push_back(p);
+    }
+};
+
+void drain_profile(chb_ctx *h)
+{
+    for (auto &p : h->pending) {
+        (void)hipEventSynchronize(p.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, p.a, p.b);
+        auto &e = h->prof_acc[p.name];
+        e.ms += ms; e.launches += 1; e.work += p.work;
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    h->pending.clear();
+}
+
+int ensure_batch_buffers(chb_ctx *h, int Kcap)
+{
+    const size_t B = h->B, m = h->m, K = Kcap;
+    HIPCHK(h->bq.ensure(K));
+    HIPCHK(h->lab_old.ensure(K));
+    HIPCHK(h->lab_prev.ensure(K));
+    HIPCHK(h->lab_new.ensure(K));
+    HIPCHK(h->first_change.ensure(1));
+    HIPCHK(h->mind.ensure(K));
+    HIPCHK(h->dist.ensure(K * B));
+    HIPCHK(h->l0d.ensure(K * B * m));
+    HIPCHK(h->l1d.ensure(K * B * m));
+    HIPCHK(h->l0i.ensure(K * B * m));
+    HIPCHK(h->l1i.ensure(K * B * m));
+    HIPCHK(h->l0c.ensure(K * B));
+    HIPCHK(h->l1c.ensure(K * B));
+    HIPCHK(h->cnt.ensure(B));
+    HIPCHK(h->bin_ptr.ensure(B + 1));
+    HIPCHK(h->cursor.ensure(B));
+    HIPCHK(h->memb_id.ensure((size_t)h->N));
+    HIPCHK(h->cnt2.ensure(B));
+    HIPCHK(h->bin_ptr2.ensure(B + 1));
+    HIPCHK(h->cursor2.ensure(B));
+    HIPCHK(h->memb2_id.ensure(2 * K));
+    HIPCHK(h->memb2_code.ensure(2 * K));
+    h->Kcap = Kcap;
+    return CHB_OK;
+}
+
+int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
+{
+    if (!h->X.p) return fail(CHB_ESTATE, "chb_set_samples has not been called");
+    if (B <= 0 || B > (1 << 20)) return fail(CHB_EINVAL, "num_clusters out of range");
+    if (m < 1 || m > CHB_MAX_NEIGHBORS)
+        return fail(CHB_EUNSUPPORTED, "num_neighbors must be in [1, 16]");
+    h->B = (int)B; h->m = m;
+    std::vector<int> lab((size_t)h->N);
+    for (int64_t i = 0; i < h->N; ++i) {
+        const int64_t v = initial[i];
+        if (v >= B) return fail(CHB_EINVAL, "initial_bins contains a label >= num_clusters");
+        lab[(size_t)i] = v < 0 ? -1 : (int)v;
+    }
+    HIPCHK(h->labels.ensure((size_t)h->N));
+    HIPCHK(h->inb.ensure((size_t)h->N));
+    HIPCHK(hipMemcpyAsync(h->labels.p, lab.data(), sizeof(int) * h->N, hipMemcpyHostToDevice, h->stream));
+    launch_fill_i32(h->inb.p, -1, (int)h->N, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->fit_open = true; h->batch_open = false; h->Kcap = 0;
+    return CHB_OK;
+}
+
+// bq already holds the K sample indices (device)
+int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
+{
+    h->K = K; h->q_lo = q_lo; h->q_hi = q_hi;
+    hipStream_t s = h->stream;
+    launch_gather_labels(h->labels.p, h->bq.p, K, h->lab_old.p, s);
+    launch_mark_batch(h->inb.p, h->bq.p, K, 1, s);
+    {
+        Timed t(h, "bucket", (double)h->N);
+        launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
+                           h->cursor.p, h->memb_id.p, s);
+    }
+    TopmArgs a{};
+    a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = q_lo; a.pos_end = q_hi;
+    a.bin_ptr = h->bin_ptr.p; a.memb_id = h->memb_id.p; a.memb_code = nullptr;
+    a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
+    a.in = Lists{nullptr, nullptr, nullptr};
+    a.out = h->L0();
+    {
+        Timed t(h, "topm_base", (double)(q_hi - q_lo));
+        launch_topm(a, s);
+    }
+    HIPCHK(hipGetLastError());
+    h->batch_open = true;
+    return CHB_OK;
+}
+
+// lab_prev (device) holds the labels of the previous round.  Evaluates [max(active,q_lo), q_hi).
+int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
+{
+    hipStream_t s = h->stream;
+    const int lo = std::max(active, h->q_lo), hi = h->q_hi;
+    launch_fill_i32(h->first_change.p, h->K, 1, s);
+    if (hi > lo) {
+        {
+            Timed t(h, "bucket", (double)h->K);
+            launch_bucket_batch(h->lab_prev.p, h->lab_old.p, h->bq.p, h->K, h->B, h->cnt2.p,
+                                h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, s);
+        }
+        TopmArgs a{};
+        a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = lo; a.pos_end = hi;
+        a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;
+        a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
+        a.in = h->L0(); a.out = h->L1();
+        {
+            Timed t(h, "topm_update", (double)(hi - lo));
+            launch_topm(a, s);
+        }
+        QpArgs q{};
+        q.X = h->X.p; q.D = h->D; q.Dp = h->Dp; q.bq = h->bq.p; q.pos_begin = lo; q.pos_end = hi;
+        q.B = h->B; q.m = h->m; q.Kcap = h->Kcap; q.lists = h->L1(); q.dist = h->dist.p;
+        {
+            Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
+            launch_hull_qp(q, s);
+        }
+        {
+            Timed t(h, "argmin", (double)(hi - lo));
+            launch_argmin(h->dist.p, h->lab_old.p, h->lab_prev.p, lo, hi, h->B, h->lab_new.p,
+                          h->mind.p, h->first_change.p, s);
+        }
+        h->stats[2] += (int64_t)(hi - lo) * h->B;
+    }
+    HIPCHK(hipGetLastError());
+    if (first_change_host) {
+        HIPCHK(hipMemcpyAsync(first_change_host, h->first_change.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    h->stats[1] += 1;
+    return CHB_OK;
+}
+
+int batch_commit_dev(chb_ctx *h, const int *final_dev)
+{
+    hipStream_t s = h->stream;
+    launch_scatter_labels(h->labels.p, h->bq.p, final_dev, h->K, s);
+    launch_mark_batch(h->inb.p, h->bq.p, h->K, 0, s);
+    HIPCHK(hipGetLastError());
+    h->batch_open = false;
+    return CHB_OK;
+}
+
+std::vector<int> to_i32(const int64_t *p, size_t n)
+{
+    std::vector<int> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = (int)p[i];
+    return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *chb_last_error(void) { return g_err.c_str(); }
+int chb_version(void) { return 1; }
+
+int chb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int chb_create(int device_id, chb_ctx **out)
+{
+    if (!out) return fail(CHB_EINVAL, "out is null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(CHB_ENODEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(CHB_EINVAL, "device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    chb_ctx *h = new chb_ctx();
+    h->dev = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
+    *out = h;
+    return CHB_OK;
+}
+
+int chb_destroy(chb_ctx *h)
+{
+    if (!h) return CHB_OK;
+    (void)hipSetDevice(h->dev);
+    (void)hipStreamSynchronize(h->stream);
+    drain_profile(h);
+    DevBuf<int> *ib[] = {&h->labels, &h->inb, &h->bq, &h->lab_old, &h->lab_prev, &h->lab_new,
+                         &h->first_change, &h->l0i, &h->l1i, &h->l0c, &h->l1c, &h->cnt, &h->bin_ptr,
+                         &h->cursor, &h->memb_id, &h->cnt2, &h->bin_ptr2, &h->cursor2, &h->memb2_id,
+                         &h->memb2_code, &h->perm, &h->xq, &h->xhull};
+    for (auto *b : ib) b->release();
+    DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->xdist, &h->xalpha, &h->xpts};
+    for (auto *b : db) b->release();
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return CHB_OK;
+}
+
+static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D, bool from_device)
+{
+    if (!h) return fail(CHB_EINVAL, "null context");
+    if (!X || N <= 0 || D <= 0) return fail(CHB_EINVAL, "samples must be a non-empty N x D matrix");
+    if (N >= (1LL << 31) - 64 || D > (1 << 20)) return fail(CHB_EUNSUPPORTED, "N or D too large");
+    HIPCHK(hipSetDevice(h->dev));
+    const int Dp = (int)((D + kKChunk - 1) / kKChunk) * kKChunk;
+    HIPCHK(h->X.ensure((size_t)N * Dp));
+    if (Dp != D) HIPCHK(hipMemsetAsync(h->X.p, 0, sizeof(double) * (size_t)N * Dp, h->stream));
+    HIPCHK(hipMemcpy2DAsync(h->X.p, sizeof(double) * Dp, X, sizeof(double) * D, sizeof(double) * D,
+                            (size_t)N, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                            h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->N = N; h->D = (int)D; h->Dp = Dp;
+    h->fit_open = false; h->batch_open = false;
+    return CHB_OK;
+}
+
+int chb_set_samples(chb_ctx *h, const double *X, int64_t N, int64_t D)
+{
+    return set_samples_common(h, X, N, D, false);
+}
+
+int chb_set_samples_device(chb_ctx *h, const double *X, int64_t N, int64_t D)
+{
+    return set_samples_common(h, X, N, D, true);
+}
+
+int chb_pairwise_distance(chb_ctx *h, int64_t r0, int64_t r1, double *out)
+{
+    if (!h || !out) return fail(CHB_EINVAL, "null argument");
+    if (!h->X.p) return fail(CHB_ESTATE, "chb_set_samples has not been called");
+    if (r0 < 0 || r1 > h->N || r0 > r1) return fail(CHB_EINVAL, "row range out of bounds");
+    HIPCHK(hipSetDevice(h->dev));
+    const int64_t chunk = std::max<int64_t>(64, (int64_t)(1LL << 28) / std::max<int64_t>(h->N, 1));
+    DevBuf<double> buf;
+    HIPCHK(buf.ensure((size_t)std::min(chunk, r1 - r0) * h->N));
+    for (int64_t a = r0; a < r1; a += chunk) {
+        const int64_t b = std::min(r1, a + chunk);
+        {
+            Timed t(h, "pairwise", (double)(b - a) * h->N);
+            launch_pairwise(h->X.p, (int)h->N, h->Dp, (int)a, (int)b, buf.p, h->stream);
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(out + (a - r0) * h->N, buf.p, sizeof(double) * (b - a) * h->N,
+                               hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { buf.release(); return fail(CHB_EHIP, hipGetErrorString(e)); }
+    }
+    buf.release();
+    return CHB_OK;
+}
+
+int chb_fit_begin(chb_ctx *h, int64_t B, const int64_t *initial_bins, int m)
+{
+    if (!h || !initial_bins) return fail(CHB_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    return fit_begin_impl(h, B, initial_bins, m);
+}
+
+int chb_batch_begin(chb_ctx *h, const int64_t *perm_slice, int64_t K, int64_t q_lo, int64_t q_hi)
+{
+    if (!h || !perm_slice) return fail(CHB_EINVAL, "null argument");
+    if (!h->fit_open) return fail(CHB_ESTATE, "chb_fit_begin has not been called");
+    if (h->batch_open) return fail(CHB_ESTATE, "previous batch not committed");
+    if (K <= 0 || K > (1 << 24) || q_lo < 0 || q_hi > K || q_lo > q_hi)
+        return fail(CHB_EINVAL, "bad batch geometry");
+    HIPCHK(hipSetDevice(h->dev));
+    for (int64_t i = 0; i < K; ++i)
+        if (perm_slice[i] < 0 || perm_slice[i] >= h->N) return fail(CHB_EINVAL, "perm entry out of range");
+    if ((int)K > h->Kcap) { int rc = ensure_batch_buffers(h, (int)K); if (rc) return rc; }
+    std::vector<int> v = to_i32(perm_slice, (size_t)K);
+    HIPCHK(hipMemcpyAsync(h->bq.p, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return batch_begin_dev(h, (int)K, (int)q_lo, (int)q_hi);
+}
+
+int chb_batch_round(chb_ctx *h, const int64_t *lab_prev, int64_t active, int64_t *lab_new,
+                    double *min_dist)
+{
+    if (!h || !lab_prev || !lab_new) return fail(CHB_EINVAL, "null argument");
+    if (!h->batch_open) return fail(CHB_ESTATE, "no open batch");
+    HIPCHK(hipSetDevice(h->dev));
+    const int K = h->K;
+    std::vector<int> v = to_i32(lab_prev, (size_t)K);
+    HIPCHK(hipMemcpyAsync(h->lab_prev.p, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
+    int rc = batch_round_dev(h, (int)active, nullptr);
+    if (rc) return rc;
+    const int lo = std::max((int)active, h->q_lo), hi = h->q_hi;
+    if (hi > lo) {
+        std::vector<int> ln((size_t)(hi - lo));
+        HIPCHK(hipMemcpyAsync(ln.data(), h->lab_new.p + lo, sizeof(int) * (hi - lo), hipMemcpyDeviceToHost, h->stream));
+        if (min_dist)
+            HIPCHK(hipMemcpyAsync(min_dist + lo, h->mind.p + lo, sizeof(double) * (hi - lo), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int i = lo; i < hi; ++i) lab_new[i] = ln[(size_t)(i - lo)];
+    } else {
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return CHB_OK;
+}
+
+int chb_batch_commit(chb_ctx *h, const int64_t *final_labels)
+{
+    if (!h || !final_labels) return fail(CHB_EINVAL, "null argument");
+    if (!h->batch_open) return fail(CHB_ESTATE, "no open batch");
+    HIPCHK(hipSetDevice(h->dev));
+    std::vector<int> v = to_i32(final_labels, (size_t)h->K);
+    HIPCHK(hipMemcpyAsync(h->lab_prev.p, v.data(), sizeof(int) * h->K, hipMemcpyHostToDevice, h->stream));
+    int rc = batch_commit_dev(h, h->lab_prev.p);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CHB_OK;
+}
+
+int chb_fit_labels(chb_ctx *h, int64_t *labels_out)
+{
+    if (!h || !labels_out) return fail(CHB_EINVAL, "null argument");
+    if (!h->fit_open) return fail(CHB_ESTATE, "chb_fit_begin has not been called");
+    HIPCHK(hipSetDevice(h->dev));
+    std::vector<int> v((size_t)h->N);
+    HIPCHK(hipMemcpyAsync(v.data(), h->labels.p, sizeof(int) * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < h->N; ++i) labels_out[i] = v[(size_t)i];
+    return CHB_OK;
+}
+
+int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const int64_t *perms,
+                    int64_t n_move, int m, int max_iter, int batch, int64_t *labels_out,
+                    int *iters_run, int64_t *changed_per_iter, double *min_dist_out)
+{
+    if (!h || !initial_bins || !labels_out) return fail(CHB_EINVAL, "null argument");
+    if (n_move > 0 && !perms) return fail(CHB_EINVAL, "perms is null");
+    if (max_iter < 0 || n_move < 0 || n_move > h->N) return fail(CHB_EINVAL, "bad n_move/max_iter");
+    HIPCHK(hipSetDevice(h->dev));
+    int rc = fit_begin_impl(h, B, initial_bins, m);
+    if (rc) return rc;
+    const int64_t N = h->N;
+    for (int64_t i = 0; i < (int64_t)max_iter * n_move; ++i)
+        if (perms[i] < 0 || perms[i] >= N) return fail(CHB_EINVAL, "perm entry out of range");
+    int Kmax = batch > 0 ? batch : 4096;
+    if (Kmax > n_move) Kmax = (int)std::max<int64_t>(n_move, 1);
+    rc = ensure_batch_buffers(h, Kmax);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    memset(h->stats, 0, sizeof(h->stats));
+
+    std::vector<int> prev((size_t)N), cur((size_t)N);
+    for (int64_t i = 0; i < N; ++i) prev[(size_t)i] = initial_bins[i] < 0 ? -1 : (int)initial_bins[i];
+    std::vector<double> mind_host;
+    if (min_dist_out) {
+        for (int64_t i = 0; i < N; ++i) min_dist_out[i] = NAN;
+        mind_host.resize((size_t)Kmax);
+    }
+    int64_t assigned0 = 0;
+    for (int64_t i = 0; i < N; ++i) assigned0 += prev[(size_t)i] >= 0;
+
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        const int64_t *perm = perms + (int64_t)it * n_move;
+        std::vector<int> p32 = to_i32(perm, (size_t)n_move);
+        HIPCHK(h->perm.ensure((size_t)std::max<int64_t>(n_move, 1)));
+        if (n_move)
+            HIPCHK(hipMemcpyAsync(h->perm.p, p32.data(), sizeof(int) * n_move, hipMemcpyHostToDevice, s));
+        int64_t t0 = 0;
+        while (t0 < n_move) {
+            // sweep 1 starts from few labelled members: do not let a batch outnumber them
+            int64_t members = (it == 0) ? assigned0 + t0 : N;
+            int K = (int)std::min<int64_t>(Kmax, n_move - t0);
+            if (members < K) K = (int)std::max<int64_t>(std::min<int64_t>(64, n_move - t0), members);
+            HIPCHK(hipMemcpyAsync(h->bq.p, h->perm.p + t0, sizeof(int) * K, hipMemcpyDeviceToDevice, s));
+            rc = batch_begin_dev(h, K, 0, K);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(h->lab_prev.p, h->lab_old.p, sizeof(int) * K, hipMemcpyDeviceToDevice, s));
+            int active = 0;
+            for (;;) {
+                int f = K;
+                rc = batch_round_dev(h, active, &f);
+                if (rc) return rc;
+                // positions [active, K) now carry this round's labels
+                HIPCHK(hipMemcpyAsync(h->lab_prev.p + active, h->lab_new.p + active,
+                                      sizeof(int) * (K - active), hipMemcpyDeviceToDevice, s));
+                if (f >= K) break;
+                active = f + 1;
+                if (active >= K) break;
+            }
+            if (min_dist_out) {
+                HIPCHK(hipMemcpyAsync(mind_host.data(), h->mind.p, sizeof(double) * K, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                for (int i = 0; i < K; ++i) min_dist_out[perm[t0 + i]] = mind_host[(size_t)i];
+            }
+            rc = batch_commit_dev(h, h->lab_prev.p);
+            if (rc) return rc;
+            h->stats[0] += 1;
+            t0 += K;
+        }
+        h->stats[3] += n_move * (int64_t)h->B;
+        HIPCHK(hipMemcpyAsync(cur.data(), h->labels.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        int64_t diff = 0;  // algorithm.py:63
+        for (int64_t i = 0; i < N; ++i) diff += prev[(size_t)i] != cur[(size_t)i];
+        if (changed_per_iter) changed_per_iter[it] = diff;
+        if (diff == 0) { ++it; break; }  // algorithm.py:64-66
+        prev = cur;                       // algorithm.py:71-72
+    }
+    if (it == 0) cur = prev;
+    for (int64_t i = 0; i < N; ++i) labels_out[i] = cur[(size_t)i];
+    if (iters_run) *iters_run = it;
+    return CHB_OK;
+}
+
+int chb_topm_per_bin(chb_ctx *h, const int64_t *labels, int64_t B, int m, const int64_t *query_idx,
+                     int64_t Q, int64_t *nbr_idx, double *nbr_dist, int32_t *nbr_cnt)
+{
+    if (!h || !labels || !query_idx || !nbr_idx || !nbr_cnt) return fail(CHB_EINVAL, "null argument");
+    if (Q < 0) return fail(CHB_EINVAL, "Q < 0");
+    HIPCHK(hipSetDevice(h->dev));
+    std::vector<int64_t> lab((size_t)h->N);
+    for (int64_t i = 0; i < h->N; ++i) lab[(size_t)i] = (labels[i] >= 0 && labels[i] < B) ? labels[i] : -1;
+    int rc = fit_begin_impl(h, B, lab.data(), m);
+    if (rc) return rc;
+    for (int64_t i = 0; i < Q; ++i)
+        if (query_idx[i] < 0 || query_idx[i] >= h->N) return fail(CHB_EINVAL, "query index out of range");
+    const int Kmax = (int)std::min<int64_t>(std::max<int64_t>(Q, 1), 4096);
+    rc = ensure_batch_buffers(h, Kmax);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    std::vector<double> hd;
+    std::vector<int> hi, hc;
+    int64_t t0 = 0;
+    while (t0 < Q) {
+        // a chunk must not contain the same sample twice
+        std::unordered_set<int64_t> seen;
+        int K = 0;
+        while (t0 + K < Q && K < Kmax && seen.insert(query_idx[t0 + K]).second) ++K;
+        std::vector<int> v = to_i32(query_idx + t0, (size_t)K);
+        HIPCHK(hipMemcpyAsync(h->bq.p, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, s));
+        rc = batch_begin_dev(h, K, 0, K);
+        if (rc) return rc;
+        // every other query of the chunk is an ordinary member: code "pos != i"
+        launch_bucket_batch(h->lab_old.p, nullptr, h->bq.p, K, h->B, h->cnt2.p, h->bin_ptr2.p,
+                            h->cursor2.p, h->memb2_id.p, h->memb2_code.p, s);
+        TopmArgs a{};
+        a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = 0; a.pos_end = K;
+        a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;
+        a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
+        a.in = h->L0(); a.out = h->L1();
+        {
+            Timed t(h, "topm_update", (double)K);
+            launch_topm(a, s);
+        }
+        HIPCHK(hipGetLastError());
+        const size_t nB = (size_t)h->B, nm = (size_t)m, cap = (size_t)h->Kcap;
+        hd.resize(nB * cap * nm); hi.resize(nB * cap * nm); hc.resize(nB * cap);
+        HIPCHK(hipMemcpyAsync(hd.data(), h->l1d.p, sizeof(double) * hd.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hi.data(), h->l1i.p, sizeof(int) * hi.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hc.data(), h->l1c.p, sizeof(int) * hc.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int i = 0; i < K; ++i)
+            for (size_t c = 0; c < nB; ++c) {
+                const size_t slot = c * cap + (size_t)i;
+                const size_t o = ((size_t)(t0 + i) * nB + c);
+                nbr_cnt[o] = hc[slot];
+                for (size_t e = 0; e < nm; ++e) {
+                    nbr_idx[o * nm + e] = hi[slot * nm + e];
+                    if (nbr_dist) nbr_dist[o * nm + e] = hd[slot * nm + e];
+                }
+            }
+        rc = batch_commit_dev(h, h->lab_old.p);  // labels unchanged
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+        t0 += K;
+    }
+    h->fit_open = false;
+    return CHB_OK;
+}
+
+static int hull_indexed(chb_ctx *h, const double *Xdev, int D, int Dp, int64_t nrows,
+                        const int64_t *query_idx, int64_t P, const int64_t *hull_idx, int m_max,
+                        double *dist, double *alpha)
+{
+    if (m_max < 1 || m_max > CHB_MAX_NEIGHBORS) return fail(CHB_EUNSUPPORTED, "m_max must be in [1, 16]");
+    if (P <= 0) return CHB_OK;
+    hipStream_t s = h->stream;
+    // compact each vertex list (padding may sit anywhere at the ABI) and remember the slots
+    std::vector<int> q((size_t)P), hx((size_t)P * m_max, -1), slot((size_t)P * m_max, -1);
+    for (int64_t p = 0; p < P; ++p) {
+        if (query_idx[p] < 0 || query_idx[p] >= nrows) return fail(CHB_EINVAL, "query index out of range");
+        q[(size_t)p] = (int)query_idx[p];
+        int n = 0;
+        for (int a = 0; a < m_max; ++a) {
+            const int64_t id = hull_idx[p * m_max + a];
+            if (id < 0) continue;
+            if (id >= nrows) return fail(CHB_EINVAL, "hull index out of range");
+            hx[(size_t)p * m_max + n] = (int)id;
+            slot[(size_t)p * m_max + n] = a;
+            ++n;
+        }
+    }
+    HIPCHK(h->xq.ensure((size_t)P));
+    HIPCHK(h->xhull.ensure((size_t)P * m_max));
+    HIPCHK(h->xdist.ensure((size_t)P));
+    HIPCHK(h->xalpha.ensure((size_t)P * m_max));
+    HIPCHK(hipMemcpyAsync(h->xq.p, q.data(), sizeof(int) * P, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->xhull.p, hx.data(), sizeof(int) * P * m_max, hipMemcpyHostToDevice, s));
+    {
+        Timed t(h, "hull_qp", (double)P);
+        launch_hull_qp_indexed(Xdev, D, Dp, h->xq.p, h->xhull.p, (int)P, m_max, h->xdist.p,
+                               h->xalpha.p, s);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dist, h->xdist.p, sizeof(double) * P, hipMemcpyDeviceToHost, s));
+    std::vector<double> al;
+    if (alpha) {
+        al.resize((size_t)P * m_max);
+        HIPCHK(hipMemcpyAsync(al.data(), h->xalpha.p, sizeof(double) * P * m_max, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    if (alpha) {
+        for (size_t i = 0; i < (size_t)P * m_max; ++i) alpha[i] = 0.0;
+        for (int64_t p = 0; p < P; ++p)
+            for (int a = 0; a < m_max; ++a) {
+                const int sl = slot[(size_t)p * m_max + a];
+                if (sl >= 0) alpha[p * m_max + sl] = al[(size_t)p * m_max + a];
+            }
+    }
+    return CHB_OK;
+}
+
+int chb_hull_distance_batch(chb_ctx *h, const int64_t *query_idx, int64_t P, const int64_t *hull_idx,
+                            int m_max, double *dist, double *alpha)
+{
+    if (!h || !query_idx || !hull_idx || !dist) return fail(CHB_EINVAL, "null argument");
+    if (!h->X.p) return fail(CHB_ESTATE, "chb_set_samples has not been called");
+    HIPCHK(hipSetDevice(h->dev));
+    return hull_indexed(h, h->X.p, h->D, h->Dp, h->N, query_idx, P, hull_idx, m_max, dist, alpha);
+}
+
+int chb_hull_distance_points(chb_ctx *h, const double *x, const double *pts, int m, int64_t D,
+                             double *dist, double *alpha)
+{
+    if (!h || !x || !dist || (m > 0 && !pts)) return fail(CHB_EINVAL, "null argument");
+    if (m < 0 || D <= 0) return fail(CHB_EINVAL, "bad m or D");
+    if (m == 0) { *dist = INFINITY; return CHB_OK; }
+    if (m > CHB_MAX_NEIGHBORS) return fail(CHB_EUNSUPPORTED, "more than 16 hull vertices");
+    HIPCHK(hipSetDevice(h->dev));
+    const int Dp = (int)((D + kKChunk - 1) / kKChunk) * kKChunk;
+    std::vector<double> rows((size_t)(m + 1) * Dp, 0.0);
+    memcpy(rows.data(), x, sizeof(double) * D);
+    for (int a = 0; a < m; ++a) memcpy(rows.data() + (size_t)(a + 1) * Dp, pts + (size_t)a * D, sizeof(double) * D);
+    HIPCHK(h->xpts.ensure(rows.size()));
+    HIPCHK(hipMemcpyAsync(h->xpts.p, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice, h->stream));
+    int64_t q = 0;
+    std::vector<int64_t> idx((size_t)m);
+    for (int a = 0; a < m; ++a) idx[(size_t)a] = a + 1;
+    return hull_indexed(h, h->xpts.p, (int)D, Dp, m + 1, &q, 1, idx.data(), m, dist, alpha);
+}
+
+int chb_find_nearest_from_row(chb_ctx *h, int64_t c, const int64_t *labels, const double *row,
+                              int64_t N, int m, int64_t *out_idx, int32_t *out_cnt)
+{
+    if (!h || !labels || !row || !out_idx || !out_cnt) return fail(CHB_EINVAL, "null argument");
+    if (N <= 0 || N >= (1LL << 31)) return fail(CHB_EINVAL, "bad N");
+    if (m < 1) return fail(CHB_EINVAL, "m must be >= 1");
+    HIPCHK(hipSetDevice(h->dev));
+    hipStream_t s = h->stream;
+    std::vector<int> lab((size_t)N);
+    for (int64_t i = 0; i < N; ++i) lab[(size_t)i] = (labels[i] < -1 || labels[i] > 0x7ffffff0) ? -2 : (int)labels[i];
+    if (c < 0 || c > 0x7ffffff0) { *out_cnt = 0; for (int i = 0; i < m; ++i) out_idx[i] = -1; return CHB_OK; }
+    DevBuf<int> dl, di;
+    DevBuf<double> dr;
+    hipError_t e = dl.ensure((size_t)N);
+    if (e == hipSuccess) e = dr.ensure((size_t)N);
+    if (e == hipSuccess) e = di.ensure((size_t)m + 1);
+    if (e == hipSuccess) e = hipMemcpyAsync(dl.p, lab.data(), sizeof(int) * N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dr.p, row, sizeof(double) * N, hipMemcpyHostToDevice, s);
+    std::vector<int> out((size_t)m + 1);
+    if (e == hipSuccess) {
+        launch_select_row(dl.p, dr.p, (int)N, (int)c, m, di.p, di.p + m, s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), di.p, sizeof(int) * (m + 1), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    dl.release(); di.release(); dr.release();
+    if (e != hipSuccess) return fail(CHB_EHIP, hipGetErrorString(e));
+    for (int i = 0; i < m; ++i) out_idx[i] = out[(size_t)i];
+    *out_cnt = out[(size_t)m];
+    return CHB_OK;
+}
+
+int chb_profile_enable(chb_ctx *h, int on)
+{
+    if (!h) return fail(CHB_EINVAL, "null context");
+    drain_profile(h);
+    h->prof = on != 0;
+    return CHB_OK;
+}
+
+int chb_profile_reset(chb_ctx *h)
+{
+    if (!h) return fail(CHB_EINVAL, "null context");
+    drain_profile(h);
+    h->prof_acc.clear();
+    return CHB_OK;
+}
+
+int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *launches, double *work_units)
+{
+    if (!h || !kernel) return fail(CHB_EINVAL, "null argument");
+    (void)hipStreamSynchronize(h->stream);
+    drain_profile(h);
+    ProfEntry e;
+    auto it = h->prof_acc.find(kernel);
+    if (it != h->prof_acc.end()) e = it->second;
+    if (total_ms) *total_ms = e.ms;
+    if (launches) *launches = e.launches;
+    if (work_units) *work_units = e.work;
+    return CHB_OK;
+}
+
+int chb_fit_stats(chb_ctx *h, int64_t *out4)
+{
+    if (!h || !out4) return fail(CHB_EINVAL, "null argument");
+    for (int i = 0; i < 4; ++i) out4[i] = h->stats[i];
+    return CHB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Internal declarations shared by the HIP translation units of libchbin_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace chb {
+
+constexpr int kMaxM = 16;       // CHB_MAX_NEIGHBORS
+constexpr int kQTile = 64;      // queries per workgroup tile
+constexpr int kPTile = 64;      // bin members per workgroup tile
+constexpr int kKChunk = 8;      // feature columns staged per pipeline step
+constexpr int kLdsStride = 66;  // doubles per staged k-row (64 + pad: conflict-free transposed writes)
+
+// Per-(bin, batch position) nearest-member lists, layout [bin][Kcap][m].
+struct Lists {
+    double *d;   // distance, ascending by (distance, index); +inf padding
+    int *idx;    // sample index; INT_MAX padding
+    int *cnt;    // [bin][Kcap]
+};
+
+struct TopmArgs {
+    const double *X;     // [N][Dp] row-major, zero padded to Dp % kKChunk == 0
+    int Dp;
+    const int *bq;       // [K] sample index of each batch position
+    int pos_begin, pos_end;
+    const int *bin_ptr;  // [B+1] CSR over member entries
+    const int *memb_id;  // sample index of each entry
+    const int *memb_code;  // nullptr: always eligible. code>0: eligible iff query pos > code-1,
+                           // -(1<<30) < code < 0: eligible iff query pos < -code-1,
+                           // code <= -(1<<30): eligible iff query pos != -(1<<30)-code
+    int B, m, Kcap;
+    Lists in;            // in.d == nullptr: start from empty lists
+    Lists out;
+};
+
+void launch_topm(const TopmArgs &a, hipStream_t s);
+
+// rows [r0,r1) of the full Euclidean distance matrix, out[(r-r0)*N + j]
+void launch_pairwise(const double *X, int N, int Dp, int r0, int r1, double *out, hipStream_t s);
+
+struct QpArgs {
+    const double *X;
+    int D, Dp;
+    const int *bq;
+    int pos_begin, pos_end;
+    int B, m, Kcap;
+    Lists lists;
+    double *dist;  // [Kcap][B]
+};
+void launch_hull_qp(const QpArgs &a, hipStream_t s);
+
+// explicit problems: query sample q[p], hull_idx[p][m_max] (<0 padding)
+void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx, int P,
+                            int m_max, double *dist, double *alpha, hipStream_t s);
+
+// label / bucket helpers
+void launch_fill_i32(int *p, int v, int n, hipStream_t s);
+void launch_mark_batch(int *inb, const int *bq, int K, int set, hipStream_t s);
+void launch_gather_labels(const int *labels, const int *bq, int K, int *out, hipStream_t s);
+void launch_scatter_labels(int *labels, const int *bq, const int *lab, int K, hipStream_t s);
+// CSR of all labelled samples outside the batch
+void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
+                        int *cursor, int *memb_id, hipStream_t s);
+// CSR of the batch's own members: earlier positions under lab_prev, later positions under lab_old
+void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
+                         int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code,
+                         hipStream_t s);
+// select up to m smallest (row[p], p) among labels[p] == c; one workgroup
+void launch_select_row(const int *labels, const double *row, int N, int c, int m, int *out_idx,
+                       int *out_cnt, hipStream_t s);
+// strict-'>' argmin over bins (algorithm.py:57), first change position
+void launch_argmin(const double *dist, const int *lab_old, const int *lab_prev, int pos_begin,
+                   int pos_end, int B, int *lab_new, double *mind, int *first_change,
+                   hipStream_t s);
+
+}  // namespace chb

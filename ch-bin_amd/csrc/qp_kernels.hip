@@ -1,0 +1,328 @@
+// Batched point-to-convex-hull distance for gfx950.
+//
+// Replaces hull_distance.py:7-35 (convex_hull_distance: P = 2 X X^T, q = -2 X x, sum(alpha) = 1,
+// alpha >= 0, ||alpha X - x||) together with solve_qp.py:18-51 / :96-132 (nearest-PD repair,
+// quadprog's Goldfarb-Idnani solve, cvxopt fallback) for every (contig, bin) pair of a batch.
+//
+// The QP min ||sum_a alpha_a x_a - x||^2 over the simplex is the minimum-norm point of
+// conv{y_a = x_a - x}.  It is solved in Gram space:
+//   phase 1 (lanes along the feature dimension): one wavefront streams the hull-vertex rows of a
+//     problem (coalesced 512-B loads), forms y_a = x_a - x and the shifted Gram
+//     Q_ab = <y_a, y_b>; wavefront shuffle reduction; Q goes to LDS.  64 problems per wavefront.
+//   phase 2 (one problem per lane): Wolfe's minimum-norm-point active-set method on the m x m Gram
+//     held in registers (fixed-size, mask-driven, fully unrolled so nothing is dynamically
+//     indexed); affine sub-problems by LDL^T of the lifted Gram Q_SS + s*11^T, which is positive
+//     definite exactly when the support is affinely independent -- so duplicate / collinear
+//     vertices (singular 2XX^T, the case the reference repairs with nearest-PD jitter and a cvxopt
+//     fallback) need no special handling.
+//   distance = sqrt(alpha^T Q alpha).
+// The result is the same projection distance the reference's QP defines (unique even when alpha
+// is not); agreement with the CPU oracle's Goldfarb-Idnani restatement is ~1e-13 relative.
+#include "chb_internal.h"
+
+#include <math.h>
+
+namespace chb {
+namespace {
+
+constexpr double kInf = __builtin_huge_val();
+
+template <int M>
+struct Sym {
+    static constexpr int NP = M * (M + 1) / 2;
+    __device__ static constexpr int at(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+};
+
+// Affine minimiser on support S: solve (Q_SS + s 11^T) b = 1, beta = b / sum(b).
+// Rows/columns outside S are replaced by identity.  Returns false when a pivot collapses
+// (support numerically affinely dependent).
+template <int M>
+__device__ __forceinline__ bool solve_affine(const double (&Q)[Sym<M>::NP], double s, unsigned S,
+                                             double (&beta)[M])
+{
+    double L[M * (M - 1) / 2 + 1];
+    double dg[M];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        const bool ink = (S >> k) & 1u;
+        const double akk = ink ? Q[Sym<M>::at(k, k)] + s : 1.0;
+        double dk = akk;
+#pragma unroll
+        for (int j = 0; j < k; ++j) dk -= L[k * (k - 1) / 2 + j] * L[k * (k - 1) / 2 + j] * dg[j];
+        if (ink && !(dk > 1e-13 * akk)) ok = false;
+        dg[k] = dk;
+        const double inv = 1.0 / dk;
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) {
+            const bool ini = (S >> i) & 1u;
+            double v = (ink && ini) ? Q[Sym<M>::at(i, k)] + s : 0.0;
+#pragma unroll
+            for (int j = 0; j < k; ++j) v -= L[i * (i - 1) / 2 + j] * L[k * (k - 1) / 2 + j] * dg[j];
+            L[i * (i - 1) / 2 + k] = v * inv;
+        }
+    }
+    if (!ok) return false;
+    double z[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        double v = ((S >> i) & 1u) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < i; ++j) v -= L[i * (i - 1) / 2 + j] * z[j];
+        z[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) z[i] = z[i] / dg[i];
+    double sum = 0.0;
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+        double v = z[i];
+#pragma unroll
+        for (int j = i + 1; j < M; ++j) v -= L[j * (j - 1) / 2 + i] * beta[j];
+        beta[i] = v;
+        sum += v;
+    }
+    const double inv = 1.0 / sum;
+#pragma unroll
+    for (int i = 0; i < M; ++i) beta[i] *= inv;
+    return sum > 0.0;
+}
+
+// Minimum of alpha^T Q alpha over the simplex on the first m (<= M) vertices.  Returns the value
+// (squared hull distance) and the weights.
+template <int M>
+__device__ __forceinline__ double min_norm_point(const double (&Q)[Sym<M>::NP], int m,
+                                                 double (&alpha)[M])
+{
+    double scale = 0.0;
+    int i0 = 0;
+    double best = kInf;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        alpha[i] = 0.0;
+        if (i < m) {
+            const double qii = Q[Sym<M>::at(i, i)];
+            scale = fmax(scale, qii);
+            if (qii < best) { best = qii; i0 = i; }
+        }
+    }
+    if (!(scale > 0.0)) {  // every vertex coincides with the query (or NaN input)
+#pragma unroll
+        for (int i = 0; i < M; ++i) alpha[i] = (i == 0) ? 1.0 : 0.0;
+        return scale == 0.0 ? 0.0 : scale;
+    }
+    unsigned S = 1u << i0, banned = 0u;
+#pragma unroll
+    for (int i = 0; i < M; ++i) alpha[i] = (i == i0) ? 1.0 : 0.0;
+    const double tol = 1.4210854715202004e-14 * scale;  // 64 eps * scale
+
+    for (int it = 0; it < 3 * M + 8; ++it) {
+        double g[M];
+        double val = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double gi = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) gi += Q[Sym<M>::at(i, j)] * alpha[j];
+            g[i] = gi;
+            val += alpha[i] * gi;
+        }
+        int jb = -1;
+        double gmin = kInf;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+            if (i < m && !(((S | banned) >> i) & 1u) && g[i] < gmin) { gmin = g[i]; jb = i; }
+        if (jb < 0 || !(gmin < val - tol)) break;
+        S |= 1u << jb;
+        for (int mi = 0; mi <= M; ++mi) {
+            double beta[M];
+            if (!solve_affine<M>(Q, scale, S, beta)) {
+                S &= ~(1u << jb);
+                banned |= 1u << jb;
+                break;
+            }
+            bool allpos = true;
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+                if (((S >> i) & 1u) && !(beta[i] > 0.0)) allpos = false;
+            if (allpos) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) alpha[i] = ((S >> i) & 1u) ? beta[i] : 0.0;
+                break;
+            }
+            double theta = 1.0;
+            int kr = -1;
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+                if (((S >> i) & 1u) && !(beta[i] > 0.0)) {
+                    const double den = alpha[i] - beta[i];
+                    const double r = den > 0.0 ? alpha[i] / den : 0.0;
+                    if (kr < 0 || r < theta) { theta = r; kr = i; }
+                }
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const double v = alpha[i] + theta * (beta[i] - alpha[i]);
+                alpha[i] = (((S >> i) & 1u) && i != kr) ? v : 0.0;
+            }
+            S &= ~(1u << kr);
+            if (kr == jb) banned |= 1u << jb;
+        }
+    }
+    double val = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        double gi = 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) gi += Q[Sym<M>::at(i, j)] * alpha[j];
+        val += alpha[i] * gi;
+    }
+    return val;
+}
+
+__device__ __forceinline__ double wave_allreduce_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// INDEXED = false: problems are (batch position, bin) pairs whose vertices come from the top-m
+// lists.  INDEXED = true: explicit (query sample, vertex index list) problems.
+template <int M, int WAVES, bool INDEXED>
+__global__ __launch_bounds__(64 * WAVES) void hull_qp_kernel(QpArgs a, int nprob, const int *xq,
+                                                              const int *xhull, int xm,
+                                                              double *xdist, double *xalpha)
+{
+    constexpr int NP = Sym<M>::NP;
+    __shared__ double sQ[WAVES][NP][64];
+    __shared__ int sN[WAVES][64];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g0 = (blockIdx.x * WAVES + w) * 64;
+    if (g0 >= nprob) return;
+    const int m = INDEXED ? xm : a.m;
+
+    for (int i = 0; i < 64; ++i) {
+        const int g = g0 + i;
+        if (g >= nprob) break;
+        int qid, n = 0;
+        const double *vrow[M];
+        if (INDEXED) {
+            qid = xq[g];
+#pragma unroll
+            for (int v = 0; v < M; ++v) {
+                vrow[v] = a.X;
+                if (v < m) {
+                    const int id = xhull[(size_t)g * m + v];
+                    // vertices are compacted: padding (<0) must trail the list
+                    if (id >= 0 && n == v) { vrow[v] = a.X + (size_t)id * a.Dp; n = v + 1; }
+                }
+            }
+        } else {
+            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+            qid = a.bq[pos];
+            const size_t slot = (size_t)c * a.Kcap + pos;
+            n = a.lists.cnt[slot];
+#pragma unroll
+            for (int v = 0; v < M; ++v) {
+                int id = 0;
+                if (v < n) id = a.lists.idx[slot * m + v];
+                vrow[v] = a.X + (size_t)id * a.Dp;
+            }
+        }
+        n = __builtin_amdgcn_readfirstlane(n);
+        const double *xrow = a.X + (size_t)qid * a.Dp;
+
+        double part[NP];
+#pragma unroll
+        for (int e = 0; e < NP; ++e) part[e] = 0.0;
+        for (int k = lane; k < a.Dp; k += 64) {
+            const double xk = xrow[k];
+            double y[M];
+#pragma unroll
+            for (int v = 0; v < M; ++v) y[v] = (v < n) ? vrow[v][k] - xk : 0.0;
+#pragma unroll
+            for (int u = 0; u < M; ++u)
+#pragma unroll
+                for (int v = 0; v <= u; ++v) part[Sym<M>::at(u, v)] += y[u] * y[v];
+        }
+#pragma unroll
+        for (int e = 0; e < NP; ++e) part[e] = wave_allreduce_sum(part[e]);
+        if (lane == 0) {
+#pragma unroll
+            for (int e = 0; e < NP; ++e) sQ[w][e][i] = part[e];
+            sN[w][i] = n;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+
+    const int g = g0 + lane;
+    if (g >= nprob) return;
+    double Q[NP];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) Q[e] = sQ[w][e][lane];
+    const int n = sN[w][lane];
+    double alpha[M];
+    double dist;
+    if (n <= 0) {
+        dist = kInf;
+#pragma unroll
+        for (int v = 0; v < M; ++v) alpha[v] = 0.0;
+    } else {
+        const double val = min_norm_point<M>(Q, n, alpha);
+        dist = sqrt(fmax(val, 0.0));
+    }
+    if (INDEXED) {
+        xdist[g] = dist;
+        if (xalpha) {
+#pragma unroll
+            for (int v = 0; v < M; ++v)
+                if (v < m) xalpha[(size_t)g * m + v] = alpha[v];
+        }
+    } else {
+        const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+        a.dist[(size_t)pos * a.B + c] = dist;
+    }
+}
+
+template <bool INDEXED>
+void dispatch(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull, double *xdist,
+              double *xalpha, hipStream_t s)
+{
+    if (nprob <= 0) return;
+    if (m <= 5) {
+        constexpr int WV = 4;
+        const int grid = (nprob + 64 * WV - 1) / (64 * WV);
+        hipLaunchKernelGGL((hull_qp_kernel<5, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a,
+                           nprob, xq, xhull, m, xdist, xalpha);
+    } else if (m <= 8) {
+        constexpr int WV = 2;
+        const int grid = (nprob + 64 * WV - 1) / (64 * WV);
+        hipLaunchKernelGGL((hull_qp_kernel<8, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a,
+                           nprob, xq, xhull, m, xdist, xalpha);
+    } else {
+        constexpr int WV = 1;
+        const int grid = (nprob + 64 * WV - 1) / (64 * WV);
+        hipLaunchKernelGGL((hull_qp_kernel<16, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a,
+                           nprob, xq, xhull, m, xdist, xalpha);
+    }
+}
+
+}  // namespace
+
+void launch_hull_qp(const QpArgs &a, hipStream_t s)
+{
+    const int nprob = (a.pos_end - a.pos_begin) * a.B;
+    dispatch<false>(a, nprob, a.m, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx, int P,
+                            int m_max, double *dist, double *alpha, hipStream_t s)
+{
+    QpArgs a{};
+    a.X = X; a.D = D; a.Dp = Dp; a.m = m_max;
+    dispatch<true>(a, P, m_max, q, hull_idx, dist, alpha, s);
+}
+
+}  // namespace chb

@@ -1,0 +1,290 @@
+// Distance tiles and per-(query, bin) nearest-member selection for gfx950.
+//
+// Replaces, without ever materialising the N x N matrix:
+//   distance_matrix.py:33-44  cdist(arr, arr, "euclidean")         (reference; scipy C)
+//   algorithm.py:51           distance_row[:] = distance_matrix[i]  (row fetch)
+//   distance_matrix.py:47-62  find_nearest_from_cluster             (np.where over all N + argpartition)
+//
+// One 256-thread workgroup owns (64 batch queries) x (one bin): it streams the bin's members in tiles
+// of 64 rows, accumulates a 64x64 tile of squared distances with a 4x4 register micro-tile per
+// thread (fp64 VALU; LDS-staged transposed k-chunks, double buffered), and keeps each query's
+// current m best members of THIS bin in the registers of the 16 lanes that share the query
+// (lane tx holds list entry tx), so selection needs no LDS and no barrier.
+//
+// Numerics: every squared distance is sum_k (q_k - p_k)^2 accumulated sequentially in k with
+// separate multiply and add (this file is compiled with -ffp-contract=off), then a correctly
+// rounded sqrt: bit-identical to scipy's cdist (the CPU checker restates the same loop).
+// Ordering of members is (distance, sample index) ascending -- total, so the result does not
+// depend on the order in which members are streamed.
+#include "chb_internal.h"
+
+#include <limits.h>
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+namespace chb {
+namespace {
+
+constexpr double kInf = __builtin_huge_val();
+
+__device__ __forceinline__ bool lex_less(double d0, int i0, double d1, int i1)
+{
+    return d0 < d1 || (d0 == d1 && i0 < i1);
+}
+
+// s-domain (squared distance) admission bound for a list whose m-th entry has distance e:
+// sqrt(s) <= e  implies  s <= e*e*(1 + 2^-50)
+__device__ __forceinline__ double tau_from(double e) { return e * e * (1.0 + 0x1p-50); }
+
+// Offer the (up to) 4 candidates held by every lane of a 16-lane group to the group's sorted
+// list (lane tx holds entry tx).  Wave-synchronous; all 64 lanes must call it together.
+__device__ __forceinline__ void select_into(double (&s)[4], const int (&mid)[4], double &ld, int &li,
+                                            int &lc, double &tau, int m, int tx, int gbase)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (!(s[j] <= tau)) s[j] = kInf;
+    for (;;) {
+        double bs = s[0];
+        int bi = mid[0], bj = 0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (lex_less(s[j], mid[j], bs, bi)) { bs = s[j]; bi = mid[j]; bj = j; }
+        double gs = bs;
+        int gi = bi;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            double os = __shfl_xor(gs, off, 16);
+            int oi = __shfl_xor(gi, off, 16);
+            if (lex_less(os, oi, gs, gi)) { gs = os; gi = oi; }
+        }
+        const bool have = gs < kInf;
+        if (!__any(have)) break;
+        if (have && bs == gs && bi == gi) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j == bj) s[j] = kInf;
+        }
+        const double d = sqrt(gs);
+        const bool lt = (tx < lc) && lex_less(ld, li, d, gi);
+        const unsigned long long bal = __ballot(lt);
+        const int pos = __popcll((bal >> gbase) & 0xFFFFull);
+        const double ud = __shfl_up(ld, 1, 16);
+        const int ui = __shfl_up(li, 1, 16);
+        const bool ins = have && pos < m;
+        if (ins) {
+            if (tx == pos) { ld = d; li = gi; }
+            else if (tx > pos) { ld = ud; li = ui; }
+            lc = lc + 1 < m ? lc + 1 : m;
+        }
+        const double e = __shfl(ld, m - 1, 16);
+        if (ins && lc >= m) {
+            tau = tau_from(e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!(s[j] <= tau)) s[j] = kInf;
+        }
+    }
+}
+
+// PW = false: top-m selection per (query tile, bin).  PW = true: write the distance tile itself
+// (chb_pairwise_distance); "bins" are then contiguous member ranges and bq is null.
+template <bool PW>
+__global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int total, int pw_n,
+                                                   int pw_group, double *pw_out)
+{
+    __shared__ __attribute__((aligned(16))) double sQ[2][kKChunk][kLdsStride];
+    __shared__ __attribute__((aligned(16))) double sP[2][kKChunk][kLdsStride];
+    __shared__ int sMid[2][kPTile];
+    __shared__ int sMcode[2][kPTile];
+
+    // XCD-aware order: blocks b and b+8 share an XCD (and its L2), so hand each XCD a contiguous
+    // range of work items; consecutive items share a bin, i.e. the same member rows.
+    const int per = (total + 7) >> 3;
+    const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (W >= total) return;
+    const int c = W / nqt, qt = W - c * nqt;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int gbase = lane & 48;
+    const int srow = tid >> 2, skp = tid & 3;
+
+    int mb, nmem;
+    if (PW) {
+        mb = c * pw_group;
+        nmem = pw_n - mb < pw_group ? pw_n - mb : pw_group;
+    } else {
+        mb = a.bin_ptr[c];
+        nmem = a.bin_ptr[c + 1] - mb;
+    }
+    const int pos0 = a.pos_begin + qt * kQTile;
+    const int m = a.m;
+
+    // list state of my 4 queries: this lane holds entry #tx
+    double ld[4], tau[4];
+    int li[4], lc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ld[i] = kInf; li[i] = INT_MAX; lc[i] = 0; tau[i] = kInf;
+        if (!PW && a.in.d != nullptr) {
+            const int qpos = pos0 + 4 * ty + i;
+            if (qpos < a.pos_end) {
+                const size_t slot = (size_t)c * a.Kcap + qpos;
+                lc[i] = a.in.cnt[slot];
+                if (tx < lc[i]) { ld[i] = a.in.d[slot * m + tx]; li[i] = a.in.idx[slot * m + tx]; }
+                if (lc[i] >= m) tau[i] = tau_from(a.in.d[slot * m + m - 1]);
+            }
+        }
+    }
+
+    // staging role: thread (srow, skp) moves feature columns [2*skp, 2*skp+1] of one row per chunk
+    int sq = pos0 + srow;
+    if (sq >= a.pos_end) sq = a.pos_end - 1;
+    const int qid = PW ? sq : a.bq[sq];
+    const double *qrow = a.X + (size_t)qid * a.Dp + 2 * skp;
+    const double *prow = a.X + 2 * skp;
+    const int nch = a.Dp / kKChunk;
+    const int ntile = (nmem + kPTile - 1) / kPTile;
+    const int nsteps = ntile * nch;
+
+    double2 rq, rp;
+    int pmid = -1, pcode = 0;
+    int nt = 0, nc = 0;  // (tile, chunk) of the step being prefetched
+    auto prefetch = [&]() {
+        if (nc == 0) {
+            const int e = nt * kPTile + srow;
+            if (e < nmem) {
+                pmid = PW ? mb + e : a.memb_id[mb + e];
+                pcode = (!PW && a.memb_code) ? a.memb_code[mb + e] : 0;
+            } else {
+                pmid = -1; pcode = 0;
+            }
+            prow = a.X + (size_t)(pmid < 0 ? 0 : pmid) * a.Dp + 2 * skp;
+        }
+        rq = *reinterpret_cast<const double2 *>(qrow + nc * kKChunk);
+        rp = *reinterpret_cast<const double2 *>(prow + nc * kKChunk);
+    };
+    auto stash = [&](int buf) {
+        sQ[buf][2 * skp][srow] = rq.x;
+        sQ[buf][2 * skp + 1][srow] = rq.y;
+        sP[buf][2 * skp][srow] = rp.x;
+        sP[buf][2 * skp + 1][srow] = rp.y;
+        if (nc == 0 && skp == 0) { sMid[nt & 1][srow] = pmid; sMcode[nt & 1][srow] = pcode; }
+        if (++nc == nch) { nc = 0; ++nt; }
+    };
+
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+
+    if (nsteps > 0) { prefetch(); stash(0); }
+    __syncthreads();
+
+    int ct = 0, cc = 0;  // (tile, chunk) of the step being computed
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const bool has_next = step + 1 < nsteps;
+        if (has_next) prefetch();
+#pragma unroll
+        for (int k = 0; k < kKChunk; ++k) {
+            const double2 qa = *reinterpret_cast<const double2 *>(&sQ[buf][k][4 * ty]);
+            const double2 qb = *reinterpret_cast<const double2 *>(&sQ[buf][k][4 * ty + 2]);
+            const double2 pa = *reinterpret_cast<const double2 *>(&sP[buf][k][2 * tx]);
+            const double2 pb = *reinterpret_cast<const double2 *>(&sP[buf][k][32 + 2 * tx]);
+            const double q[4] = {qa.x, qa.y, qb.x, qb.y};
+            const double p[4] = {pa.x, pa.y, pb.x, pb.y};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double df = q[i] - p[j];
+                    acc[i][j] = acc[i][j] + df * df;
+                }
+        }
+        if (has_next) stash(buf ^ 1);
+        __syncthreads();
+        if (++cc == nch) {
+            // tile finished: offer its 64 members to the lists (or write the distances out)
+            int mid[4], code[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ml = (j < 2) ? 2 * tx + j : 32 + 2 * tx + (j - 2);
+                mid[j] = sMid[ct & 1][ml];
+                code[j] = sMcode[ct & 1][ml];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qpos = pos0 + 4 * ty + i;
+                const bool qvalid = qpos < a.pos_end;
+                if (PW) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (qvalid && mid[j] >= 0)
+                            pw_out[(size_t)(qpos - a.pos_begin) * pw_n + mid[j]] = sqrt(acc[i][j]);
+                } else {
+                    double s[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bool ok = qvalid && mid[j] >= 0;
+                        if (code[j] > 0) ok = ok && (qpos > code[j] - 1);
+                        else if (code[j] <= -(1 << 30)) ok = ok && (qpos != -(1 << 30) - code[j]);
+                        else if (code[j] < 0) ok = ok && (qpos < -code[j] - 1);
+                        s[j] = ok ? acc[i][j] : kInf;
+                    }
+                    select_into(s, mid, ld[i], li[i], lc[i], tau[i], m, tx, gbase);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+            }
+            cc = 0; ++ct;
+        }
+    }
+
+    if (!PW) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qpos = pos0 + 4 * ty + i;
+            if (qpos < a.pos_end) {
+                const size_t slot = (size_t)c * a.Kcap + qpos;
+                if (tx < m) {
+                    a.out.d[slot * m + tx] = tx < lc[i] ? ld[i] : kInf;
+                    a.out.idx[slot * m + tx] = tx < lc[i] ? li[i] : -1;
+                }
+                if (tx == 0) a.out.cnt[slot] = lc[i];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+void launch_topm(const TopmArgs &a, hipStream_t s)
+{
+    const int nq = a.pos_end - a.pos_begin;
+    if (nq <= 0 || a.B <= 0) return;
+    const int nqt = (nq + kQTile - 1) / kQTile;
+    const int total = nqt * a.B;
+    const int grid = ((total + 7) / 8) * 8;
+    hipLaunchKernelGGL(tile_kernel<false>, dim3(grid), dim3(256), 0, s, a, nqt, total, 0, 0,
+                       (double *)nullptr);
+}
+
+void launch_pairwise(const double *X, int N, int Dp, int r0, int r1, double *out, hipStream_t s)
+{
+    if (r1 <= r0) return;
+    TopmArgs a{};
+    a.X = X; a.Dp = Dp; a.bq = nullptr; a.pos_begin = r0; a.pos_end = r1;
+    a.m = 1; a.Kcap = 0; a.B = 0;
+    const int group = 1024;
+    const int ngroups = (N + group - 1) / group;
+    const int nqt = (r1 - r0 + kQTile - 1) / kQTile;
+    const int total = nqt * ngroups;
+    const int grid = ((total + 7) / 8) * 8;
+    hipLaunchKernelGGL(tile_kernel<true>, dim3(grid), dim3(256), 0, s, a, nqt, total, N, group, out);
+}
+
+}  // namespace chb

@@ -1,0 +1,126 @@
+/*
+ * chbin_hip.h -- C ABI of libchbin_hip.so, the MI355X (gfx950) implementation of CH-Bin's
+ * convex-hull binning hot path (ch_bin/core/clustering, AlgoDistanceMetric=convex).
+ *
+ * The reference (kdsuneraavinash/CH-Bin) is pure Python and has no FFI of its own; its seams are
+ * plain Python functions.  Each entry point below names the reference function it replaces
+ * (file:line into the reference tree).  The Python host side in ch-bin_amd/ binds these with
+ * ctypes and re-exposes the reference's own signatures; INTEGRATION.md shows the stub a CH-Bin
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative CHB_E* code on failure; chb_last_error()
+ *     returns a thread-local human-readable message.  No exceptions cross the ABI.
+ *   - pointers are caller-owned HOST pointers unless the name says `_device`; C-contiguous;
+ *     nothing is retained after return except by chb_set_samples_device (borrowed, see below).
+ *   - labels / indices are int64 at the ABI (numpy's default, what pandas hands the reference:
+ *     cli/clustering.py:52); -1 = unassigned.  Features are float64 (cli/clustering.py:53).
+ *   - calls are blocking; a context is not thread-safe (the reference caller is single-threaded).
+ *   - there is NO CPU fallback: without a gfx950 device every compute call fails with
+ *     CHB_ENODEVICE.
+ */
+#ifndef CHBIN_HIP_H
+#define CHBIN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHB_OK 0
+#define CHB_EINVAL (-1)    /* bad argument */
+#define CHB_ENODEVICE (-2) /* no usable HIP device */
+#define CHB_EHIP (-3)      /* a HIP runtime call failed */
+#define CHB_ESTATE (-4)    /* call sequence violated (e.g. no samples set) */
+#define CHB_EUNSUPPORTED (-5)
+
+#define CHB_MAX_NEIGHBORS 16 /* AlgoNumNeighbors supported by the kernels (default.ini:16 -> 5) */
+
+typedef struct chb_ctx chb_ctx;
+
+const char *chb_last_error(void);
+int chb_version(void);
+/* number of visible HIP devices (0 when there is none); never fails */
+int chb_device_count(void);
+
+/* one context per process per GPU */
+int chb_create(int device_id, chb_ctx **out);
+int chb_destroy(chb_ctx *h);
+
+/* Feature matrix `samples` of fit_cluster (algorithm.py:13): copied to HBM once and kept resident. */
+int chb_set_samples(chb_ctx *h, const double *X, int64_t N, int64_t D);
+/* same, from a device buffer (e.g. a torch tensor's data_ptr); copied device-to-device */
+int chb_set_samples_device(chb_ctx *h, const double *X_device, int64_t N, int64_t D);
+
+/* distance_matrix.py:33-44 create_in_mem_distance_matrix / :12-30 create_distance_matrix:
+ * rows [row_begin,row_end) of the N x N Euclidean matrix, bit-identical to scipy cdist
+ * (sqrt of the k-sequential, unfused sum of squared differences).  out: (row_end-row_begin) x N. */
+int chb_pairwise_distance(chb_ctx *h, int64_t row_begin, int64_t row_end, double *out);
+
+/* distance_matrix.py:47-62 find_nearest_from_cluster, batched over queries and ALL bins:
+ * for query contig query_idx[q] and bin c, the (up to) m members of bin c nearest to the query,
+ * ordered by (distance, index); the query itself is never a member (algorithm.py:50).
+ * nbr_idx: Q*B*m (-1 padded), nbr_dist: Q*B*m (+inf padded, may be NULL), nbr_cnt: Q*B. */
+int chb_topm_per_bin(chb_ctx *h, const int64_t *labels, int64_t B, int m, const int64_t *query_idx,
+                     int64_t Q, int64_t *nbr_idx, double *nbr_dist, int32_t *nbr_cnt);
+
+/* distance_matrix.py:47-62 find_nearest_from_cluster with the reference's exact signature: the
+ * caller supplies one row of a distance matrix (any provenance) and the current labels; selects
+ * among {p : labels[p] == c} the (up to) m smallest by (row[p], p).  out_idx[m] (-1 padded). */
+int chb_find_nearest_from_row(chb_ctx *h, int64_t c, const int64_t *labels, const double *row,
+                              int64_t N, int m, int64_t *out_idx, int32_t *out_cnt);
+
+/* hull_distance.py:7-35 convex_hull_distance (+ solve_qp.py:96-132), batched:
+ * problem p = distance from sample query_idx[p] to conv{ samples[hull_idx[p*m_max + a]] }, entries
+ * < 0 are padding; an empty hull gives +inf.  alpha (P*m_max, may be NULL) receives the convex
+ * weights in hull_idx order (0 at padding). */
+int chb_hull_distance_batch(chb_ctx *h, const int64_t *query_idx, int64_t P, const int64_t *hull_idx,
+                            int m_max, double *dist, double *alpha);
+
+/* hull_distance.py:90-108 calculate_distance(x, mat_p, qp_solver, "convex") for explicit points:
+ * x[D], pts[m][D].  Does not touch the resident samples. */
+int chb_hull_distance_points(chb_ctx *h, const double *x, const double *pts, int m, int64_t D,
+                             double *dist, double *alpha);
+
+/* algorithm.py:12-76 fit_cluster(samples, num_clusters, initial_bins, distance_matrix,
+ * num_neighbors, max_iterations, "convex", qp_solver): the whole reassignment loop with the
+ * reference's sequential (Gauss-Seidel) semantics reproduced exactly by speculative batches.
+ *   initial_bins[N]      -1 = movable (algorithm.py:38), others are fixed seeds
+ *   perms[max_iter*n_move] the permutations algorithm.py:45 would draw, pre-drawn by the caller
+ *                        from the legacy numpy RNG so the MT19937 stream matches ch_bin.py:22
+ *   batch               speculative batch size (0 = default)
+ *   labels_out[N], *iters_run, changed_per_iter[max_iter] (algorithm.py:63-68 counts),
+ *   min_dist_out[N] (may be NULL): winning hull distance of each movable contig's last visit */
+int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const int64_t *perms,
+                    int64_t n_move, int m, int max_iter, int batch, int64_t *labels_out,
+                    int *iters_run, int64_t *changed_per_iter, double *min_dist_out);
+
+/* ---- stepwise form of the same loop (one process per GPU; the host side exchanges labels
+ * between ranks with RCCL/gloo between rounds).  Query slice [q_lo,q_hi) of each batch is the
+ * part this rank evaluates; labels stay replicated on every rank. */
+int chb_fit_begin(chb_ctx *h, int64_t B, const int64_t *initial_bins, int m);
+/* open a batch: perm_slice[K] are the contigs visited, in order */
+int chb_batch_begin(chb_ctx *h, const int64_t *perm_slice, int64_t K, int64_t q_lo, int64_t q_hi);
+/* one speculative round: lab_prev[K] in; for positions [max(active,q_lo), q_hi) writes
+ * lab_new[pos] and min_dist[pos] (arrays of length K, other entries untouched) */
+int chb_batch_round(chb_ctx *h, const int64_t *lab_prev, int64_t active, int64_t *lab_new,
+                    double *min_dist);
+/* close the batch: labels[perm_slice[i]] = final[i] */
+int chb_batch_commit(chb_ctx *h, const int64_t *final_labels);
+int chb_fit_labels(chb_ctx *h, int64_t *labels_out);
+
+/* ---- measurement: HIP-event timing of every kernel launch on the context's stream */
+int chb_profile_enable(chb_ctx *h, int on);
+int chb_profile_reset(chb_ctx *h);
+/* kernel: "topm_base" | "topm_update" | "hull_qp" | "argmin" | "bucket" | "pairwise" */
+int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *launches,
+                    double *work_units);
+/* counters of the last chb_fit_cluster call: [0]=batches [1]=rounds [2]=hull distances evaluated
+ * (incl. speculative re-evaluation) [3]=hull distances the sequential loop needs (sweeps*n_move*B) */
+int chb_fit_stats(chb_ctx *h, int64_t *out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHBIN_HIP_H */

@@ -1,0 +1,60 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/chbin_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import chbin_amd
+from chbin_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "chbin_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(chb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in chbin_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+
+
+def test_loads_and_reports_without_compute():
+    lib = _lib.load()
+    assert lib.chb_version() >= 1
+    assert lib.chb_device_count() >= 0
+    assert isinstance(lib.chb_last_error(), (bytes, type(None)))
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every compute entry point must fail loudly."""
+    if _lib.load().chb_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import numpy as np
+    from chbin_amd import clustering
+    with pytest.raises(_lib.ChbError):
+        _lib.Context(0)
+    with pytest.raises(_lib.ChbError):
+        clustering.calculate_distance(np.zeros(4), np.zeros((2, 4)), "quadprog", "convex")
+    with pytest.raises(_lib.ChbError):
+        clustering.fit_cluster(np.zeros((4, 4)), 1, np.zeros(4, dtype=np.int64), None)
+
+
+def test_product_never_imports_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "ch-bin_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b)|(#include\s+[\"<][^\n]*oracle)|(libchb_oracle)|(oracle/)",
+                     re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(src), (dirpath, f)

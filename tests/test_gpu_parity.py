@@ -1,0 +1,327 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+fixtures.  Bit-exact for labels, indices and the cdist-style distances; hull (QP) distances
+within 1e-9 absolute (north star tolerance: 1e-5)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+QP_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import chbin_amd  # noqa: F401
+    from chbin_amd import _lib
+    return _lib.default_context()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _synth(*a, **k):
+    import chbin_amd
+    return chbin_amd.synth.make_synthetic(*a, **k)
+
+
+def _perms(initial, n):
+    import chbin_amd
+    return chbin_amd.synth.draw_permutations(initial, n, seed=0)
+
+
+# ------------------------------------------------------------------ distances (K1)
+
+def test_pairwise_bit_exact_vs_golden_and_oracle(ctx, O, golden_dir):
+    g = np.load(os.path.join(golden_dir, "cdist.npz"))
+    ctx.set_samples(g["X"])
+    M = ctx.pairwise_distance()
+    assert np.array_equal(M, g["M"])  # scipy cdist, captured from the reference function
+    rng = np.random.default_rng(0)
+    for N, D in ((300, 136), (257, 140), (65, 7), (1, 3), (1500, 33)):
+        X = rng.random((N, D)) / D
+        ctx.set_samples(X)
+        assert np.array_equal(ctx.pairwise_distance(), O.cdist(X)), (N, D)
+    # row ranges
+    X = rng.random((500, 136))
+    ctx.set_samples(X)
+    assert np.array_equal(ctx.pairwise_distance(123, 321), O.cdist(X)[123:321])
+
+
+def test_mirror_create_distance_matrix(ctx, O, tmp_path):
+    from chbin_amd import clustering
+    X = np.random.default_rng(1).random((200, 20))
+    M = clustering.create_in_mem_distance_matrix(X)
+    assert np.array_equal(M, O.cdist(X))
+    f = clustering.create_distance_matrix(X, tmp_path)
+    assert f.name == "distance_matrix.npy"
+    assert np.array_equal(np.load(f), M)
+    # reuse-if-exists semantics (distance_matrix.py:19-22)
+    assert clustering.create_distance_matrix(X * 2, tmp_path) == f
+    assert np.array_equal(np.load(f), M)
+
+
+# ------------------------------------------------------------------ selection (K2)
+
+def test_find_nearest_from_row_vs_golden(ctx, O, golden_dir):
+    from chbin_amd import clustering
+    g = np.load(os.path.join(golden_dir, "find_nearest.npz"))
+    X, labels, m = g["X"], g["labels"], int(g["m"])
+    for i, c, want in zip(g["rows"], g["bins"], g["selected_sorted"]):
+        cur = labels.copy()
+        cur[i] = -1
+        row = O.cdist_row(X, int(i))
+        got = clustering.find_nearest_from_cluster(int(c), cur, row, m)
+        assert np.array_equal(np.sort(got), want[want >= 0])
+        assert np.array_equal(got, O.find_nearest_from_cluster(int(c), cur, row, m))
+
+
+@pytest.mark.parametrize("m", [1, 5, 15, 16])
+def test_topm_per_bin_vs_oracle(ctx, O, m):
+    rng = np.random.default_rng(m)
+    N, D, B = 900, 136, 7
+    X, _, true = _synth(N, D, B, seed=2, sigma=5e-3, mix=0.4)
+    X[10] = X[3]; X[11] = X[3]; X[500] = X[499]          # exact duplicates -> distance ties
+    labels = true.copy()
+    labels[rng.random(N) < 0.25] = -1
+    labels[labels == 6] = -1                               # empty bin
+    keep = np.flatnonzero(labels == 5)
+    labels[keep[3:]] = -1                                  # bin with 3 (< m) members
+    labels[[3, 10, 11]] = 2
+    ctx.set_samples(X)
+    queries = np.concatenate([rng.choice(N, 150, replace=False), [3, 10, 11, 499, 500, 3]])
+    idx, dist, cnt = ctx.topm_per_bin(labels, B, m, queries)
+    for qi, q in enumerate(queries):
+        cur = labels.copy()
+        cur[q] = -1
+        row = O.cdist_row(X, int(q))
+        for c in range(B):
+            want = O.find_nearest_from_cluster(c, cur, row, m)
+            n = cnt[qi, c]
+            assert n == len(want), (q, c)
+            assert np.array_equal(idx[qi, c, :n], want), (q, c)
+            assert np.array_equal(dist[qi, c, :n], row[want]), (q, c)   # bit-exact distances
+            assert np.all(idx[qi, c, n:] == -1)
+
+
+# ------------------------------------------------------------------ hull distance (K3+K4)
+
+def _hull_cases(rng, n, D, mmax):
+    xs, Ps = [], []
+    for t in range(n):
+        m = int(rng.integers(1, mmax + 1))
+        P = rng.random((m, D)) / D
+        kind = t % 6
+        if kind == 0:
+            x = rng.random(D) / D
+        elif kind == 1:
+            x = rng.dirichlet(np.ones(m)) @ P                     # inside the hull: distance 0
+        elif kind == 2:
+            x = P[rng.integers(m)] + 1e-4 * rng.standard_normal(D) / D
+        elif kind == 3 and m > 1:
+            P[m - 1] = P[0]                                       # duplicate vertex (singular Gram)
+            x = rng.random(D) / D
+        elif kind == 4 and m > 2:
+            P[2] = 0.3 * P[0] + 0.7 * P[1]                        # collinear vertices
+            x = rng.random(D) / D
+        else:
+            x = P[0].copy()                                       # query coincides with a vertex
+        xs.append(x); Ps.append(P)
+    return xs, Ps
+
+
+@pytest.mark.parametrize("mmax,D", [(5, 136), (8, 136), (16, 140), (5, 3), (12, 6)])
+def test_hull_distance_points_vs_oracle_and_enumerator(ctx, O, mmax, D):
+    rng = np.random.default_rng(100 + mmax + D)
+    xs, Ps = _hull_cases(rng, 120, D, mmax)
+    for x, P in zip(xs, Ps):
+        d, alpha = ctx.hull_distance_points(x, P, want_alpha=True)
+        scale = max(np.linalg.norm(P - x, axis=1).max(), 1e-300)
+        d_or = O.convex_hull_distance(x, P)
+        assert abs(d - d_or) <= QP_TOL + 1e-7 * scale * (d_or < 1e-6 * scale), (len(P), d, d_or)
+        if len(P) <= 12:
+            d_en = O.enum_hull_distance(x, P)
+            assert abs(d - d_en) <= QP_TOL + 1e-7 * scale * (d_en < 1e-6 * scale), (len(P), d, d_en)
+        # alpha is a feasible convex weight vector reproducing the distance (hull_distance.py:34-35)
+        assert np.all(alpha >= 0) and abs(alpha.sum() - 1) < 1e-12
+        assert abs(np.linalg.norm(alpha @ P - x) - d) <= QP_TOL + 1e-7 * scale * (d < 1e-6 * scale)
+
+
+def test_hull_distance_golden_qp_problems(ctx, O, golden_dir):
+    from chbin_amd import clustering
+    g = np.load(os.path.join(golden_dir, "qp_args.npz"))
+    for k in range(len(g["m"])):
+        m = int(g["m"][k])
+        x, P = g["x"][k], g["P"][k][:m]
+        d = clustering.calculate_distance(x, P, "quadprog", "convex")
+        assert abs(d - g["dist_with_oracle_gi"][k]) < QP_TOL
+
+
+def test_hull_distance_batch_indexed(ctx, O):
+    rng = np.random.default_rng(7)
+    X, _, _ = _synth(400, 136, 4, seed=5, sigma=4e-3)
+    ctx.set_samples(X)
+    P = 300
+    q = rng.integers(0, 400, P)
+    hull = np.full((P, 8), -1, dtype=np.int64)
+    for p in range(P):
+        n = int(rng.integers(0, 9))
+        ids = rng.choice(400, n, replace=False)
+        slots = np.sort(rng.choice(8, n, replace=False))          # padding anywhere
+        hull[p, slots] = ids
+    dist, alpha = ctx.hull_distance_batch(q, hull, want_alpha=True)
+    for p in range(P):
+        ids = hull[p][hull[p] >= 0]
+        if len(ids) == 0:
+            assert np.isinf(dist[p])
+            continue
+        want = O.convex_hull_distance(X[q[p]], X[ids])
+        assert abs(dist[p] - want) < QP_TOL
+        assert np.all(alpha[p][hull[p] < 0] == 0)
+        assert abs(np.linalg.norm(alpha[p][hull[p] >= 0] @ X[ids] - X[q[p]]) - dist[p]) < 1e-9
+
+
+def test_mirror_errors():
+    from chbin_amd import clustering
+    x = np.zeros(4)
+    with pytest.raises(NotImplementedError):
+        clustering.calculate_distance(x, np.zeros((2, 4)), "quadprog", "manhattan")
+    with pytest.raises(NotImplementedError):
+        clustering.calculate_distance(x, np.zeros((2, 4)), "nosuch", "convex")
+    with pytest.raises(NotImplementedError):
+        clustering.fit_cluster(np.zeros((4, 4)), 1, np.zeros(4, dtype=np.int64), None, qp_solver="nosuch")
+
+
+# ------------------------------------------------------------------ the whole loop (a12/a13)
+
+def test_fit_cluster_golden_flow(ctx, O, golden_dir):
+    """Labels produced by the reference's own fit_cluster loop (captured fixture)."""
+    from chbin_amd import clustering
+    g = np.load(os.path.join(golden_dir, "fit_cluster_flow.npz"))
+    np.random.seed(0)  # ch_bin.py:22
+    got = clustering.fit_cluster(g["X"], int(g["B"]), g["initial"], None,
+                                 num_neighbors=int(g["m"]), max_iterations=int(g["max_iter"]))
+    assert got.dtype == np.int64
+    assert np.array_equal(got, g["labels"])
+    # the global RNG was advanced exactly as algorithm.py:45 would have
+    after = np.random.random()
+    np.random.seed(0)
+    pts = np.where(g["initial"] == -1)[0]
+    sweeps = O.fit_cluster(g["X"], int(g["B"]), g["initial"], g["perms"], int(g["m"]), int(g["max_iter"]))[1]
+    for _ in range(sweeps):
+        np.random.permutation(pts)
+    assert after == np.random.random()
+
+
+CASES = [
+    # N, D, B, m, max_iter, sigma, mix, n_seed, batch
+    (600, 40, 6, 5, 10, 9e-3, 0.5, 10, 0),
+    (600, 40, 6, 5, 10, 9e-3, 0.5, 10, 64),
+    (600, 40, 6, 5, 10, 9e-3, 0.5, 10, 1),        # batch of one == plain sequential
+    (900, 136, 8, 5, 6, 6e-3, 0.6, 8, 257),
+    (900, 136, 8, 15, 4, 6e-3, 0.6, 20, 300),     # function-default neighbour count (algorithm.py:17)
+    (1200, 140, 5, 5, 10, 9e-3, 0.9, 4, 4096),    # heavy overlap: many movers, many rounds
+    (700, 24, 9, 3, 5, 4e-3, 0.0, 2, 128),        # bins start smaller than m
+    (2000, 136, 8, 5, 3, 1.5e-3, 0.0, None, 0),   # SURVEY 8(d) generator as-is
+]
+
+
+@pytest.mark.parametrize("N,D,B,m,iters,sigma,mix,n_seed,batch", CASES)
+def test_fit_cluster_labels_bit_exact(ctx, O, N, D, B, m, iters, sigma, mix, n_seed, batch):
+    S = 5 if D == 140 else 1
+    X, initial, _ = _synth(N, D, B, S=S, seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
+    perms = _perms(initial, iters)
+    want, its_o, ch_o = O.fit_cluster(X, B, initial, perms, m, iters)
+    ctx.set_samples(X)
+    got, its, ch, mind = ctx.fit_cluster(B, initial, perms, m, iters, batch=batch, want_min_dist=True)
+    assert its == its_o
+    assert np.array_equal(ch, ch_o)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[initial >= 0], initial[initial >= 0])   # seeds never move
+    st = ctx.fit_stats()
+    assert st["hull_needed"] == its * perms.shape[1] * B
+    # winning distances of the last sweep agree with the oracle's sequential replay
+    labels = initial.copy()
+    for k in range(its):
+        labels, md = O.sweep(X, B, labels, perms[k], m)
+    assert np.allclose(mind[perms[its - 1]], md, rtol=0, atol=QP_TOL, equal_nan=True)
+
+
+def test_fit_cluster_degenerate_inputs(ctx, O):
+    # duplicates of whole contigs, a bin id with no seed at all, and a contig equal to a seed
+    X, initial, true = _synth(500, 30, 5, seed=9, sigma=5e-3, mix=0.3, n_seed=6)
+    X[100:110] = X[0]
+    X[200] = X[np.flatnonzero(initial == 1)[0]]
+    initial[initial == 4] = -1                      # bin 4 has no members: +inf, never chosen
+    perms = _perms(initial, 5)
+    want, its_o, _ = O.fit_cluster(X, 5, initial, perms, 5, 5)
+    ctx.set_samples(X)
+    got, its, _ = ctx.fit_cluster(5, initial, perms, 5, 5, batch=100)
+    assert its == its_o and np.array_equal(got, want)
+    assert not np.any(got == 4)
+    # nothing to move at all
+    init2 = true.copy()
+    got2, its2, ch2 = ctx.fit_cluster(5, init2, np.zeros((3, 0), dtype=np.int64), 5, 3)
+    assert np.array_equal(got2, init2) and its2 == 1 and ch2[0] == 0
+    # no seeds at all: every hull is empty, labels stay -1 (cli/clustering.py:79 then raises)
+    init3 = np.full(500, -1, dtype=np.int64)
+    got3, _, _ = ctx.fit_cluster(5, init3, _perms(init3, 2), 5, 2)
+    assert np.all(got3 == -1)
+
+
+def test_stepwise_two_slices_equals_sequential(ctx, O):
+    """The multi-GPU decomposition (each rank evaluates a slice of every batch, labels exchanged
+    between rounds) driven from one process with two contexts on the same GPU."""
+    from chbin_amd import _lib
+    from chbin_amd.distributed import run_sweeps
+    X, initial, _ = _synth(800, 64, 6, seed=21, sigma=8e-3, mix=0.5, n_seed=8)
+    perms = _perms(initial, 4)
+    want, its_o, _ = O.fit_cluster(X, 6, initial, perms, 5, 4)
+    c2 = _lib.Context(0)
+    try:
+        got, its, _ = run_sweeps([ctx, c2], X, 6, initial, perms, 5, 4, batch=200)
+    finally:
+        c2.close()
+    assert its == its_o and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("N,D,B,S", [(4000, 136, 16, 1)])
+def test_config2_scale_parity(ctx, O, N, D, B, S):
+    """A BASELINE config-2 shaped case at a size the oracle finishes in seconds."""
+    X, initial, true = _synth(N, D, B, S=S, seed=0)
+    perms = _perms(initial, 3)
+    want, its_o, _ = O.fit_cluster(X, B, initial, perms, 5, 3)
+    ctx.set_samples(X)
+    got, its, _ = ctx.fit_cluster(B, initial, perms, 5, 3)
+    assert its == its_o and np.array_equal(got, want)
+    assert (got == true).mean() > 0.99
+
+
+def test_full_size_fixed_point_property(ctx, O):
+    """BASELINE config 3 (N=100k, D=136, B=64, m=5).  The oracle cannot replay 6.4M QPs per sweep,
+    but two size-independent properties pin the result: (1) the first contigs of sweep 1 depend only
+    on the seeds and on each other, so the oracle replays that prefix exactly; (2) once a sweep
+    changes nothing, every contig's label is the argmin of its hull distances given everyone
+    else's final label -- checked by the oracle on a random sample."""
+    N, D, B, m = 100_000, 136, 64, 5
+    X, initial, true = _synth(N, D, B, seed=0)
+    perms = _perms(initial, 4)
+    ctx.set_samples(X)
+    first, _, _ = ctx.fit_cluster(B, initial, perms[:1], m, 1)
+    n_pref = 40
+    lab_o, _ = O.sweep(X, B, initial, perms[0][:n_pref], m)
+    assert np.array_equal(first[perms[0][:n_pref]], lab_o[perms[0][:n_pref]])
+    got, its, changed, mind = ctx.fit_cluster(B, initial, perms, m, 4, want_min_dist=True)
+    assert changed[-1] == 0 and its < 4
+    assert np.all(got >= 0)
+    assert np.array_equal(got[initial >= 0], initial[initial >= 0])
+    rng = np.random.default_rng(3)
+    sample = rng.choice(np.flatnonzero(initial < 0), 30, replace=False)
+    for j in sample:
+        lab_j, md = O.sweep(X, B, got, np.array([j]), m)
+        assert lab_j[j] == got[j]
+        assert abs(md[0] - mind[j]) < QP_TOL
