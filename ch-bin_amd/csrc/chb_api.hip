@@ -105,6 +105,8 @@ struct chb_ctx {
     std::map<std::string, ProfEntry> prof_acc;
     std::vector<Pending> pending;
     int64_t stats[4] = {0, 0, 0, 0};
+    // work-unit hints for the profile (pairs = queries x members streamed)
+    double hint_base_members = 0.0, hint_batch_entries = 0.0;
 
     Lists L0() { return Lists{l0d.p, l0i.p, l0c.p}; }
     Lists L1() { return Lists{l1d.p, l1i.p, l1c.p}; }
@@ -216,7 +218,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
     a.in = Lists{nullptr, nullptr, nullptr};
     a.out = h->L0();
     {
-        Timed t(h, "topm_base", (double)(q_hi - q_lo));
+        Timed t(h, "topm_base", (double)(q_hi - q_lo) * h->hint_base_members);
         launch_topm(a, s);
     }
     HIPCHK(hipGetLastError());
@@ -242,7 +244,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
         a.in = h->L0(); a.out = h->L1();
         {
-            Timed t(h, "topm_update", (double)(hi - lo));
+            Timed t(h, "topm_update", (double)(hi - lo) * h->hint_batch_entries);
             launch_topm(a, s);
         }
         QpArgs q{};
@@ -490,6 +492,7 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
     }
     int64_t assigned0 = 0;
     for (int64_t i = 0; i < N; ++i) assigned0 += prev[(size_t)i] >= 0;
+    int64_t labelled = assigned0;
 
     int it = 0;
     for (; it < max_iter; ++it) {
@@ -505,6 +508,8 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
             int K = (int)std::min<int64_t>(Kmax, n_move - t0);
             if (members < K) K = (int)std::max<int64_t>(std::min<int64_t>(64, n_move - t0), members);
             HIPCHK(hipMemcpyAsync(h->bq.p, h->perm.p + t0, sizeof(int) * K, hipMemcpyDeviceToDevice, s));
+            h->hint_base_members = (double)((it == 0) ? assigned0 + t0 : labelled - K);
+            h->hint_batch_entries = (double)((it == 0) ? K : 2 * K);
             rc = batch_begin_dev(h, K, 0, K);
             if (rc) return rc;
             HIPCHK(hipMemcpyAsync(h->lab_prev.p, h->lab_old.p, sizeof(int) * K, hipMemcpyDeviceToDevice, s));
@@ -534,7 +539,11 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
         HIPCHK(hipMemcpyAsync(cur.data(), h->labels.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         int64_t diff = 0;  // algorithm.py:63
-        for (int64_t i = 0; i < N; ++i) diff += prev[(size_t)i] != cur[(size_t)i];
+        labelled = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            diff += prev[(size_t)i] != cur[(size_t)i];
+            labelled += cur[(size_t)i] >= 0;
+        }
         if (changed_per_iter) changed_per_iter[it] = diff;
         if (diff == 0) { ++it; break; }  // algorithm.py:64-66
         prev = cur;                       // algorithm.py:71-72
