@@ -189,6 +189,9 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
         const int buf = step & 1;
         const bool has_next = step + 1 < nsteps;
         if (has_next) prefetch();
+        // keep the global loads of the next chunk in flight across the whole compute block: the
+        // scheduler must neither sink them nor hoist the LDS stores that consume them
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < kKChunk; ++k) {
             const double2 qa = *reinterpret_cast<const double2 *>(&sQ[buf][k][4 * ty]);
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
                     acc[i][j] = acc[i][j] + df * df;
                 }
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (has_next) stash(buf ^ 1);
         __syncthreads();
         if (++cc == nch) {
