@@ -98,7 +98,7 @@ struct chb_ctx {
     DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
     DevBuf<int> perm;
     // scratch for the indexed / explicit-point entry points
-    DevBuf<int> xq, xhull;
+    DevBuf<int> xq, xhull, xcnt;
     DevBuf<double> xdist, xalpha, xpts;
     // profiling
     bool prof = false;
@@ -326,7 +326,7 @@ int chb_destroy(chb_ctx *h)
     DevBuf<int> *ib[] = {&h->labels, &h->inb, &h->bq, &h->lab_old, &h->lab_prev, &h->lab_new,
                          &h->first_change, &h->l0i, &h->l1i, &h->l0c, &h->l1c, &h->cnt, &h->bin_ptr,
                          &h->cursor, &h->memb_id, &h->cnt2, &h->bin_ptr2, &h->cursor2, &h->memb2_id,
-                         &h->memb2_code, &h->perm, &h->xq, &h->xhull};
+                         &h->memb2_code, &h->perm, &h->xq, &h->xhull, &h->xcnt};
     for (auto *b : ib) b->release();
     DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
@@ -512,7 +512,9 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
             h->hint_batch_entries = (double)((it == 0) ? K : 2 * K);
             rc = batch_begin_dev(h, K, 0, K);
             if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(h->lab_prev.p, h->lab_old.p, sizeof(int) * K, hipMemcpyDeviceToDevice, s));
+            // starting labels of the rounds: last sweep's label, or for still-unlabelled contigs
+            // (sweep 1) the bin of the nearest outside member
+            launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, K, h->B, h->m, h->Kcap, h->lab_prev.p, s);
             int active = 0;
             for (;;) {
                 int f = K;
@@ -628,7 +630,7 @@ static int hull_indexed(chb_ctx *h, const double *Xdev, int D, int Dp, int64_t n
     if (P <= 0) return CHB_OK;
     hipStream_t s = h->stream;
     // compact each vertex list (padding may sit anywhere at the ABI) and remember the slots
-    std::vector<int> q((size_t)P), hx((size_t)P * m_max, -1), slot((size_t)P * m_max, -1);
+    std::vector<int> q((size_t)P), hx((size_t)P * m_max, -1), slot((size_t)P * m_max, -1), hn((size_t)P, 0);
     for (int64_t p = 0; p < P; ++p) {
         if (query_idx[p] < 0 || query_idx[p] >= nrows) return fail(CHB_EINVAL, "query index out of range");
         q[(size_t)p] = (int)query_idx[p];
@@ -641,16 +643,19 @@ static int hull_indexed(chb_ctx *h, const double *Xdev, int D, int Dp, int64_t n
             slot[(size_t)p * m_max + n] = a;
             ++n;
         }
+        hn[(size_t)p] = n;
     }
     HIPCHK(h->xq.ensure((size_t)P));
     HIPCHK(h->xhull.ensure((size_t)P * m_max));
+    HIPCHK(h->xcnt.ensure((size_t)P));
+    HIPCHK(hipMemcpyAsync(h->xcnt.p, hn.data(), sizeof(int) * P, hipMemcpyHostToDevice, s));
     HIPCHK(h->xdist.ensure((size_t)P));
     HIPCHK(h->xalpha.ensure((size_t)P * m_max));
     HIPCHK(hipMemcpyAsync(h->xq.p, q.data(), sizeof(int) * P, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->xhull.p, hx.data(), sizeof(int) * P * m_max, hipMemcpyHostToDevice, s));
     {
         Timed t(h, "hull_qp", (double)P);
-        launch_hull_qp_indexed(Xdev, D, Dp, h->xq.p, h->xhull.p, (int)P, m_max, h->xdist.p,
+        launch_hull_qp_indexed(Xdev, D, Dp, h->xq.p, h->xhull.p, h->xcnt.p, (int)P, m_max, h->xdist.p,
                                h->xalpha.p, s);
     }
     HIPCHK(hipGetLastError());

@@ -49,9 +49,10 @@ struct QpArgs {
 };
 void launch_hull_qp(const QpArgs &a, hipStream_t s);
 
-// explicit problems: query sample q[p], hull_idx[p][m_max] (<0 padding)
-void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx, int P,
-                            int m_max, double *dist, double *alpha, hipStream_t s);
+// explicit problems: query sample q[p], hull_idx[p][m_max] compacted, hull_cnt[p] vertices
+void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,
+                            const int *hull_cnt, int P, int m_max, double *dist, double *alpha,
+                            hipStream_t s);
 
 // label / bucket helpers
 void launch_fill_i32(int *p, int v, int n, hipStream_t s);
@@ -65,6 +66,9 @@ void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cn
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code,
                          hipStream_t s);
+// round-0 label guess: lab_old where >= 0, else bin of the nearest outside member
+void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old, int K, int B,
+                  int m, int Kcap, int *lab_prev, hipStream_t s);
 // select up to m smallest (row[p], p) among labels[p] == c; one workgroup
 void launch_select_row(const int *labels, const double *row, int N, int c, int m, int *out_idx,
                        int *out_cnt, hipStream_t s);

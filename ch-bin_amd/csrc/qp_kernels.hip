@@ -6,9 +6,9 @@
 //
 // The QP min ||sum_a alpha_a x_a - x||^2 over the simplex is the minimum-norm point of
 // conv{y_a = x_a - x}.  It is solved in Gram space:
-//   phase 1 (lanes along the feature dimension): one wavefront streams the hull-vertex rows of a
-//     problem (coalesced 512-B loads), forms y_a = x_a - x and the shifted Gram
-//     Q_ab = <y_a, y_b>; wavefront shuffle reduction; Q goes to LDS.  64 problems per wavefront.
+//   phase 1 (fp64 matrix core): every lane streams one hull-vertex row, forms y_a = x_a - x, and
+//     v_mfma_f64_16x16x4_f64 accumulates the shifted Gram Q_ab = <y_a, y_b> of 16/M problems per
+//     tile (no cross-lane reduction); the diagonal blocks go to LDS.  ~64 problems per wavefront.
 //   phase 2 (one problem per lane): Wolfe's minimum-norm-point active-set method on the m x m Gram
 //     held in registers (fixed-size, mask-driven, fully unrolled so nothing is dynamically
 //     indexed); affine sub-problems by LDL^T of the lifted Gram Q_SS + s*11^T, which is positive
@@ -179,86 +179,90 @@ __device__ __forceinline__ double min_norm_point(const double (&Q)[Sym<M>::NP], 
     return val;
 }
 
-__device__ __forceinline__ double wave_allreduce_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 // INDEXED = false: problems are (batch position, bin) pairs whose vertices come from the top-m
-// lists.  INDEXED = true: explicit (query sample, vertex index list) problems.
+// lists.  INDEXED = true: explicit (query sample, compacted vertex index list, count) problems.
+//
+// Phase 1 maps the shifted Gram onto the fp64 matrix core: v_mfma_f64_16x16x4_f64 computes
+// D = A(16x4) * B(4x16) + C with lane l supplying A[l&15][l>>4] and B[l>>4][l&15] -- for a Gram
+// A = Y and B = Y^T are the SAME register.  The 16 rows of a tile are the vertices of 16/M
+// consecutive problems (3 problems of 5 vertices at the default AlgoNumNeighbors); the diagonal
+// M x M blocks of the 16x16 product are their Gram matrices, and the k-reduction over the feature
+// dimension happens inside the MFMA accumulator: no cross-lane reduction at all.  Each lane streams
+// ONE vertex row (every 4th feature), 8 loads in flight per operand.
 template <int M, int WAVES, bool INDEXED>
 __global__ __launch_bounds__(64 * WAVES) void hull_qp_kernel(QpArgs a, int nprob, const int *xq,
-                                                              const int *xhull, int xm,
-                                                              double *xdist, double *xalpha)
+                                                              const int *xhull, const int *xn,
+                                                              int xm, double *xdist, double *xalpha)
 {
     constexpr int NP = Sym<M>::NP;
+    constexpr int PPT = 16 / M;    // problems per MFMA tile
+    constexpr int NT = 64 / PPT;   // tiles per wavefront
+    constexpr int PPW = PPT * NT;  // problems per wavefront (one per lane in phase 2)
     __shared__ double sQ[WAVES][NP][64];
     __shared__ int sN[WAVES][64];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int g0 = (blockIdx.x * WAVES + w) * 64;
+    const int g0 = (blockIdx.x * WAVES + w) * PPW;
     if (g0 >= nprob) return;
     const int m = INDEXED ? xm : a.m;
+    const int row = lane & 15, kq = lane >> 4;
+    const int rp = row / M, rv = row - rp * M;
 
-    for (int i = 0; i < 64; ++i) {
-        const int g = g0 + i;
-        if (g >= nprob) break;
-        int qid, n = 0;
-        const double *vrow[M];
-        if (INDEXED) {
-            qid = xq[g];
-#pragma unroll
-            for (int v = 0; v < M; ++v) {
-                vrow[v] = a.X;
-                if (v < m) {
-                    const int id = xhull[(size_t)g * m + v];
-                    // vertices are compacted: padding (<0) must trail the list
-                    if (id >= 0 && n == v) { vrow[v] = a.X + (size_t)id * a.Dp; n = v + 1; }
-                }
-            }
-        } else {
-            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
-            qid = a.bq[pos];
-            const size_t slot = (size_t)c * a.Kcap + pos;
-            n = a.lists.cnt[slot];
-#pragma unroll
-            for (int v = 0; v < M; ++v) {
-                int id = 0;
-                if (v < n) id = a.lists.idx[slot * m + v];
-                vrow[v] = a.X + (size_t)id * a.Dp;
+    for (int t = 0; t < NT; ++t) {
+        const int gt = g0 + t * PPT;
+        if (gt >= nprob) break;
+        const int g = gt + rp;
+        const bool valid = rp < PPT && g < nprob;
+        int n = 0, id = 0, qid = 0;
+        if (valid) {
+            if (INDEXED) {
+                qid = xq[g];
+                n = xn[g];
+                if (rv < n) id = xhull[(size_t)g * m + rv];
+            } else {
+                const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+                qid = a.bq[pos];
+                const size_t slot = (size_t)c * a.Kcap + pos;
+                n = a.lists.cnt[slot];
+                if (rv < n) id = a.lists.idx[slot * m + rv];
             }
         }
-        n = __builtin_amdgcn_readfirstlane(n);
-        const double *xrow = a.X + (size_t)qid * a.Dp;
-
-        double part[NP];
+        const bool live = valid && rv < n;
+        const double *vptr = a.X + (size_t)id * a.Dp + kq;
+        const double *qptr = a.X + (size_t)qid * a.Dp + kq;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < a.Dp; k0 += 32) {
+            double v[8], x[8];
 #pragma unroll
-        for (int e = 0; e < NP; ++e) part[e] = 0.0;
-        for (int k = lane; k < a.Dp; k += 64) {
-            const double xk = xrow[k];
-            double y[M];
+            for (int s = 0; s < 8; ++s) {
+                const int kk = k0 + 4 * s;
+                const bool in = live && kk < a.Dp;
+                v[s] = in ? vptr[kk] : 0.0;
+                x[s] = in ? qptr[kk] : 0.0;
+            }
 #pragma unroll
-            for (int v = 0; v < M; ++v) y[v] = (v < n) ? vrow[v][k] - xk : 0.0;
-#pragma unroll
-            for (int u = 0; u < M; ++u)
-#pragma unroll
-                for (int v = 0; v <= u; ++v) part[Sym<M>::at(u, v)] += y[u] * y[v];
+            for (int s = 0; s < 8; ++s) {
+                const double y = v[s] - x[s];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, acc, 0, 0, 0);
+            }
         }
+        // lane holds D[kq + 4r][row]; keep the lower triangles of the diagonal blocks
 #pragma unroll
-        for (int e = 0; e < NP; ++e) part[e] = wave_allreduce_sum(part[e]);
-        if (lane == 0) {
-#pragma unroll
-            for (int e = 0; e < NP; ++e) sQ[w][e][i] = part[e];
-            sN[w][i] = n;
+        for (int r = 0; r < 4; ++r) {
+            const int i = kq + 4 * r;
+            const int pi = i / M, vi = i - pi * M;
+            if (pi == rp && pi < PPT && vi >= rv && gt + pi < nprob)
+                sQ[w][Sym<M>::at(vi, rv)][t * PPT + pi] = acc[r];
         }
+        if (valid && rv == 0) sN[w][t * PPT + rp] = n;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
 
     const int g = g0 + lane;
-    if (g >= nprob) return;
+    if (lane >= PPW || g >= nprob) return;
     double Q[NP];
 #pragma unroll
     for (int e = 0; e < NP; ++e) Q[e] = sQ[w][e][lane];
@@ -286,27 +290,26 @@ __global__ __launch_bounds__(64 * WAVES) void hull_qp_kernel(QpArgs a, int nprob
     }
 }
 
+template <int M, int WV, bool INDEXED>
+void launch_one(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull, const int *xn,
+                double *xdist, double *xalpha, hipStream_t s)
+{
+    constexpr int PPW = (16 / M) * (64 / (16 / M));
+    const int nwaves = (nprob + PPW - 1) / PPW;
+    const int grid = (nwaves + WV - 1) / WV;
+    hipLaunchKernelGGL((hull_qp_kernel<M, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a, nprob,
+                       xq, xhull, xn, m, xdist, xalpha);
+}
+
 template <bool INDEXED>
-void dispatch(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull, double *xdist,
-              double *xalpha, hipStream_t s)
+void dispatch(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull, const int *xn,
+              double *xdist, double *xalpha, hipStream_t s)
 {
     if (nprob <= 0) return;
-    if (m <= 5) {
-        constexpr int WV = 4;
-        const int grid = (nprob + 64 * WV - 1) / (64 * WV);
-        hipLaunchKernelGGL((hull_qp_kernel<5, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a,
-                           nprob, xq, xhull, m, xdist, xalpha);
-    } else if (m <= 8) {
-        constexpr int WV = 2;
-        const int grid = (nprob + 64 * WV - 1) / (64 * WV);
-        hipLaunchKernelGGL((hull_qp_kernel<8, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a,
-                           nprob, xq, xhull, m, xdist, xalpha);
-    } else {
-        constexpr int WV = 1;
-        const int grid = (nprob + 64 * WV - 1) / (64 * WV);
-        hipLaunchKernelGGL((hull_qp_kernel<16, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a,
-                           nprob, xq, xhull, m, xdist, xalpha);
-    }
+    if (m <= 4) launch_one<4, 4, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
+    else if (m <= 5) launch_one<5, 4, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
+    else if (m <= 8) launch_one<8, 2, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
+    else launch_one<16, 1, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
 }
 
 }  // namespace
@@ -314,15 +317,16 @@ void dispatch(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull
 void launch_hull_qp(const QpArgs &a, hipStream_t s)
 {
     const int nprob = (a.pos_end - a.pos_begin) * a.B;
-    dispatch<false>(a, nprob, a.m, nullptr, nullptr, nullptr, nullptr, s);
+    dispatch<false>(a, nprob, a.m, nullptr, nullptr, nullptr, nullptr, nullptr, s);
 }
 
-void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx, int P,
-                            int m_max, double *dist, double *alpha, hipStream_t s)
+void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,
+                            const int *hull_cnt, int P, int m_max, double *dist, double *alpha,
+                            hipStream_t s)
 {
     QpArgs a{};
     a.X = X; a.D = D; a.Dp = Dp; a.m = m_max;
-    dispatch<true>(a, P, m_max, q, hull_idx, dist, alpha, s);
+    dispatch<true>(a, P, m_max, q, hull_idx, hull_cnt, dist, alpha, s);
 }
 
 }  // namespace chb
