@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (AMD public spec; the local guide lists no fp64 row)
+BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -103,7 +104,8 @@ def main():
     ms_per_step = dt / max(args.steps, 1) * 1e3
     value = qp_per_step * args.steps / dt
 
-    prof = {k: ctx.profile_get(k) for k in ("topm_base", "topm_update", "hull_qp", "argmin", "bucket")}
+    prof = {k: ctx.profile_get(k) for k in ("prefilter", "rescore", "topm_fallback", "topm_base", "topm_update",
+                                            "hull_qp", "argmin", "bucket")}
     stats = ctx.fit_stats()
 
     out = None
@@ -123,6 +125,24 @@ def main():
                              "total_ms": p["ms"],
                              "note": "fp64 VALU (non-fused sub/mul/add, 1 flop per instruction); "
                                      "peak is the fp64 vector==matrix FMA peak, so 0.5 is the ceiling"})
+        # shortlist stage: bf16 MFMA dot products, 2*Dz flops per (query, member) pair
+        p = prof["prefilter"]
+        if p["launches"]:
+            Dz = (D + 15) // 16 * 16
+            ach = p["work"] * 2.0 * Dz / (p["ms"] * 1e-3) / 1e12
+            kern.append({"kernel": "prefilter", "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": p["ms"] / p["launches"], "launches": p["launches"],
+                         "total_ms": p["ms"], "pairs_per_s": p["work"] / (p["ms"] * 1e-3),
+                         "note": "bf16 v_mfma_f32_32x32x16 shortlist; selection (VALU) and LDS "
+                                 "staging, not the matrix core, set its time"})
+        for name in ("rescore", "topm_fallback"):
+            p = prof[name]
+            if p["launches"]:
+                kern.append({"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": None, "traffic": None,
+                             "avg_launch_ms": p["ms"] / p["launches"], "launches": p["launches"],
+                             "total_ms": p["ms"]})
         p = prof["hull_qp"]
         if p["launches"]:
             bytes_qp = 8.0 * (m * D + D / B + 1)
@@ -180,6 +200,8 @@ def main():
             "cpu_baseline": cpu,
             "end_to_end_bin_assign": e2e,
             "fit_stats_last_call": stats,
+            "prefilter": {"enabled": ctx.counter("prefilter_enabled"),
+                          "shortlist_overflows_last_call": ctx.counter("prefilter_overflow")},
         }
         print(json.dumps(out))
     if use_dist:

@@ -57,6 +57,7 @@ SIGNATURES = {
     "chb_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "chb_fit_stats": (C.c_int, [C.c_void_p, _i64p]),
+    "chb_counter": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
 }
 
 
@@ -227,6 +228,11 @@ class Context:
         ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
         check(self._lib.chb_profile_get(self._h, kernel.encode(), C.byref(ms), C.byref(n), C.byref(w)))
         return {"ms": ms.value, "launches": n.value, "work": w.value}
+
+    def counter(self, name):
+        v = C.c_int64(0)
+        check(self._lib.chb_counter(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def fit_stats(self):
         out = np.zeros(4, dtype=np.int64)

@@ -97,6 +97,13 @@ struct chb_ctx {
     DevBuf<int> cnt, bin_ptr, cursor, memb_id;
     DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
     DevBuf<int> perm;
+    // two-stage selection: bf16 shadow copy + shortlists
+    DevBuf<unsigned short> Z;
+    DevBuf<float> znrm, zrho;
+    DevBuf<double> colwork;
+    int Dz = 0;
+    bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
+    DevBuf<int> cand, cand_cnt, flags64, overflow;
     // scratch for the indexed / explicit-point entry points
     DevBuf<int> xq, xhull, xcnt;
     DevBuf<double> xdist, xalpha, xpts;
@@ -173,6 +180,12 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->cursor2.ensure(B));
     HIPCHK(h->memb2_id.ensure(2 * K));
     HIPCHK(h->memb2_code.ensure(2 * K));
+    if (h->use_prefilter && h->shadow_ok) {
+        HIPCHK(h->cand.ensure(K * B * (size_t)kCandCap));
+        HIPCHK(h->cand_cnt.ensure(K * B));
+        HIPCHK(h->flags64.ensure(B * ((K + kQTile - 1) / kQTile)));
+        HIPCHK(h->overflow.ensure(1));
+    }
     h->Kcap = Kcap;
     return CHB_OK;
 }
@@ -196,6 +209,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     launch_fill_i32(h->inb.p, -1, (int)h->N, h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     h->fit_open = true; h->batch_open = false; h->Kcap = 0;
+    h->overflow_total_valid = false;
     return CHB_OK;
 }
 
@@ -217,7 +231,35 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
     a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
     a.in = Lists{nullptr, nullptr, nullptr};
     a.out = h->L0();
-    {
+    if (h->use_prefilter && h->shadow_ok && h->cand.p) {
+        // two-stage exact selection: bf16 matrix-core shortlist, exact fp64 on the shortlist,
+        // brute force only for (query tile, bin) pairs whose shortlist overflowed
+        const int nq64 = (q_hi - q_lo + kQTile - 1) / kQTile;
+        launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
+        if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
+        PrefilterArgs pa{};
+        pa.sh = Shadow{h->Z.p, h->znrm.p, h->zrho.p, h->Dz};
+        pa.bq = h->bq.p; pa.pos_begin = q_lo; pa.pos_end = q_hi;
+        pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p;
+        pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
+        pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
+        {
+            Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
+            launch_prefilter(pa, h->flags64.p, s);
+        }
+        RescoreArgs ra{};
+        ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = q_lo; ra.pos_end = q_hi;
+        ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
+        ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.out = h->L0();
+        {
+            Timed t(h, "rescore", (double)(q_hi - q_lo) * h->B);
+            launch_rescore(ra, s);
+        }
+        {
+            Timed t(h, "topm_fallback", 0.0);
+            launch_topm_flagged(a, h->flags64.p, s);
+        }
+    } else {
         Timed t(h, "topm_base", (double)(q_hi - q_lo) * h->hint_base_members);
         launch_topm(a, s);
     }
@@ -311,6 +353,7 @@ int chb_create(int device_id, chb_ctx **out)
     HIPCHK(hipSetDevice(device_id));
     chb_ctx *h = new chb_ctx();
     h->dev = device_id;
+    if (const char *e = getenv("CHB_PREFILTER")) h->use_prefilter = atoi(e) != 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
@@ -326,10 +369,11 @@ int chb_destroy(chb_ctx *h)
     DevBuf<int> *ib[] = {&h->labels, &h->inb, &h->bq, &h->lab_old, &h->lab_prev, &h->lab_new,
                          &h->first_change, &h->l0i, &h->l1i, &h->l0c, &h->l1c, &h->cnt, &h->bin_ptr,
                          &h->cursor, &h->memb_id, &h->cnt2, &h->bin_ptr2, &h->cursor2, &h->memb2_id,
-                         &h->memb2_code, &h->perm, &h->xq, &h->xhull, &h->xcnt};
+                         &h->memb2_code, &h->perm, &h->xq, &h->xhull, &h->xcnt, &h->cand, &h->cand_cnt, &h->flags64, &h->overflow};
     for (auto *b : ib) b->release();
     DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
+    h->Z.release(); h->znrm.release(); h->zrho.release(); h->colwork.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
     return CHB_OK;
@@ -347,9 +391,24 @@ static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D,
     HIPCHK(hipMemcpy2DAsync(h->X.p, sizeof(double) * Dp, X, sizeof(double) * D, sizeof(double) * D,
                             (size_t)N, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                             h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
     h->N = N; h->D = (int)D; h->Dp = Dp;
     h->fit_open = false; h->batch_open = false;
+    // bf16 shadow copy for the shortlist stage (prefilter_kernels.hip)
+    h->shadow_ok = false;
+    const int Dz = (int)((D + 15) / 16) * 16;
+    if (h->use_prefilter && Dz <= 256) {
+        HIPCHK(h->Z.ensure((size_t)N * Dz));
+        HIPCHK(h->znrm.ensure((size_t)N));
+        HIPCHK(h->zrho.ensure((size_t)N));
+        HIPCHK(h->colwork.ensure((size_t)257 * D));
+        launch_col_sums(h->X.p, (int)N, (int)D, Dp, h->colwork.p, h->stream);
+        launch_build_shadow(h->X.p, (int)N, (int)D, Dp, h->colwork.p + (size_t)256 * D, h->Z.p, Dz,
+                            h->znrm.p, h->zrho.p, h->stream);
+        HIPCHK(hipGetLastError());
+        h->Dz = Dz;
+        h->shadow_ok = true;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
     return CHB_OK;
 }
 
@@ -766,6 +825,23 @@ int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *l
     if (launches) *launches = e.launches;
     if (work_units) *work_units = e.work;
     return CHB_OK;
+}
+
+int chb_counter(chb_ctx *h, const char *name, int64_t *out)
+{
+    if (!h || !name || !out) return fail(CHB_EINVAL, "null argument");
+    *out = 0;
+    if (!strcmp(name, "prefilter_overflow")) {
+        if (h->overflow.p && h->overflow_total_valid) {
+            int v = 0;
+            HIPCHK(hipMemcpyAsync(&v, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            *out = v;
+        }
+        return CHB_OK;
+    }
+    if (!strcmp(name, "prefilter_enabled")) { *out = (h->use_prefilter && h->shadow_ok) ? 1 : 0; return CHB_OK; }
+    return fail(CHB_EINVAL, "unknown counter");
 }
 
 int chb_fit_stats(chb_ctx *h, int64_t *out4)

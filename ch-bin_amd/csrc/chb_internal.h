@@ -34,6 +34,50 @@ struct TopmArgs {
 };
 
 void launch_topm(const TopmArgs &a, hipStream_t s);
+// same, but only work items (bin, query tile of 64) whose flag is set run; the rest exit at once
+void launch_topm_flagged(const TopmArgs &a, const int *flags64, hipStream_t s);
+
+// ---- two-stage exact selection (prefilter_kernels.hip + rescore in topm_kernels.hip)
+constexpr int kCandCap = 96;   // shortlist capacity per (bin, batch position)
+
+// Per-sample data of the low-precision shadow copy: centred features rounded to bf16, the exact
+// squared norm of the rounded vector and the exact rounding distance rho = ||zhat - z||.
+struct Shadow {
+    const unsigned short *Z;  // [N][Dz] bf16, Dz % 16 == 0, zero padded
+    const float *nrm;         // [N] ||zhat||^2 (rounded up)
+    const float *rho;         // [N] ||zhat - z|| (rounded up)
+    int Dz;
+};
+void launch_col_sums(const double *X, int N, int D, int Dp, double *colsum, hipStream_t s);
+void launch_build_shadow(const double *X, int N, int D, int Dp, const double *colsum,
+                         unsigned short *Z, int Dz, float *nrm, float *rho, hipStream_t s);
+
+struct PrefilterArgs {
+    Shadow sh;
+    const int *bq;
+    int pos_begin, pos_end;
+    const int *bin_ptr;
+    const int *memb_id;
+    int B, m, Kcap;
+    int *cand;       // [B][Kcap][kCandCap] sample indices
+    int *cand_cnt;   // [B][Kcap]
+    int *overflow;   // [1] number of (bin, position) pairs whose shortlist overflowed
+};
+// flags64[bin][ceil(nq/64)] (pre-zeroed): set for (query tile of 64, bin) pairs whose shortlist overflowed
+void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s);
+size_t prefilter_lds_bytes(int Dz);
+
+struct RescoreArgs {
+    const double *X;
+    int Dp;
+    const int *bq;
+    int pos_begin, pos_end;
+    int B, m, Kcap;
+    const int *cand;
+    const int *cand_cnt;
+    Lists out;
+};
+void launch_rescore(const RescoreArgs &a, hipStream_t s);
 
 // rows [r0,r1) of the full Euclidean distance matrix, out[(r-r0)*N + j]
 void launch_pairwise(const double *X, int N, int Dp, int r0, int r1, double *out, hipStream_t s);

@@ -1,0 +1,361 @@
+// Stage 1 of the two-stage EXACT nearest-member selection: a bf16 matrix-core shortlist.
+//
+// The reference selects the m nearest members of every bin from an exact distance row
+// (distance_matrix.py:47-62 over distance_matrix.py:33-44).  Computing every one of the N^2
+// distances in unfused fp64 is what bounds the sweep, yet only ~m of the ~N/B members of a bin can
+// ever be selected.  This file produces, for each (batch position j, bin c), a SHORTLIST that is
+// guaranteed to contain the exact top-m; topm_kernels.hip:rescore_kernel then evaluates the exact
+// cdist-rounded distance on the shortlist only.  The final result is bit-identical to the
+// brute-force path (and is checked against it in tests/).
+//
+// Guarantee.  Let z = x - mu (any fixed centre mu), zh = bf16(z) and rho_p = ||zh_p - z_p||_2,
+// measured exactly per sample when the shadow copy is built.  By the triangle inequality
+//     | ||x_j - x_p|| - ||zh_j - zh_p|| |  <=  rho_j + rho_p .
+// ||zh_j - zh_p||^2 = n_j + n_p - 2 <zh_j, zh_p> with n = ||zh||^2 exact and the dot product from
+// v_mfma_f32_32x32x16_bf16 (bf16 products are exact in fp32; accumulation error <= g (n_j + n_p)
+// with g = 1e-4, several times the worst-case fp32 summation bound for D <= 512).  Hence for every
+// member p:  LB(j,p) <= d(j,p) <= UB(j,p).  The kernel keeps tau = (an upper bound of) the m-th
+// smallest UB seen so far in the bin -- at least m members are provably within tau -- and
+// shortlists every member with LB <= tau.  Any member of the true top-m has d <= tau, hence
+// LB <= tau: it is on the list.  A relative slack of 1e-6 covers fp32 rounding of the bound
+// arithmetic itself and the fp64 rounding of the exact distances.
+// If a shortlist overflows its capacity the (query tile, bin) is flagged and recomputed by the
+// brute-force tile kernel, so correctness never depends on the data.
+#include "chb_internal.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace chb {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float kGamma = 1e-4f;
+constexpr float kSlack = 1e-6f;
+constexpr int kPfQ = 128;  // batch positions per workgroup (32 per wavefront)
+constexpr int kPfP = 32;   // members per tile
+
+__global__ void col_partial_kernel(const double *X, int N, int D, int Dp, int rows_per_block,
+                                   double *partial)
+{
+    const int k = threadIdx.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int kk = k; kk < D; kk += blockDim.x) {
+        double s = 0.0;
+        for (int r = r0; r < r1; ++r) s += X[(size_t)r * Dp + kk];
+        partial[(size_t)blockIdx.x * D + kk] = s;
+    }
+}
+
+__global__ void col_final_kernel(const double *partial, int nblocks, int D, int N, double *colmean)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= D) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * D + k];
+    colmean[k] = s / (double)N;
+}
+
+__device__ __forceinline__ float round_up_f32(double v)
+{
+    float f = (float)v;
+    if ((double)f < v) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+// one wavefront per sample
+__global__ __launch_bounds__(64) void build_shadow_kernel(const double *X, int N, int D, int Dp,
+                                                          const double *mu, unsigned short *Z,
+                                                          int Dz, float *nrm, float *rho)
+{
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x;
+    double n2 = 0.0, e2 = 0.0;
+    for (int k = lane; k < Dz; k += 64) {
+        unsigned short hb = 0;
+        if (k < D) {
+            const double z = X[(size_t)p * Dp + k] - mu[k];
+            const float zf = (float)z;
+            unsigned int u = __float_as_uint(zf);
+            u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;   // round-to-nearest-even to bf16
+            hb = (unsigned short)u;
+            const double zh = (double)__uint_as_float(((unsigned int)hb) << 16);
+            n2 += zh * zh;
+            e2 += (zh - z) * (zh - z);
+        }
+        Z[(size_t)p * Dz + k] = hb;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        n2 += __shfl_xor(n2, off, 64);
+        e2 += __shfl_xor(e2, off, 64);
+    }
+    if (lane == 0) {
+        nrm[p] = round_up_f32(n2 * (1.0 + 1e-12));
+        rho[p] = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
+    }
+}
+
+template <int ML>
+__device__ __forceinline__ void list_insert(float (&l)[ML], float v)
+{
+#pragma unroll
+    for (int i = 0; i < ML; ++i) {
+        const float lo = fminf(l[i], v);
+        v = fmaxf(l[i], v);
+        l[i] = lo;
+    }
+}
+
+template <int ML>
+__global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
+                                                        int stride, int *flags64, int nqt64)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *sQz = smem;                               // [kPfQ][stride]
+    unsigned char *sPz = sQz + (size_t)kPfQ * stride;        // [2][kPfP][stride]
+    float *sPn = reinterpret_cast<float *>(sPz + (size_t)2 * kPfP * stride);  // [2][kPfP]
+    float *sPr = sPn + 2 * kPfP;                             // [2][kPfP]
+    int *sPid = reinterpret_cast<int *>(sPr + 2 * kPfP);     // [2][kPfP]
+
+    const int per = (total + 7) >> 3;
+    const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (W >= total) return;
+    const int c = W / nqt, qt = W - c * nqt;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int mb = a.bin_ptr[c];
+    const int nmem = a.bin_ptr[c + 1] - mb;
+    const int pos0 = a.pos_begin + qt * kPfQ;
+    const int Dz = a.sh.Dz;
+    const int cpr = Dz >> 3;            // 16-byte chunks per row
+    const int ksteps = Dz >> 4;
+    const int m = a.m;
+
+    // my query
+    const int qpos = pos0 + 32 * w + col;
+    const bool qvalid = qpos < a.pos_end;
+    const int qid = a.bq[qvalid ? qpos : a.pos_end - 1];
+    const float nj = a.sh.nrm[qid];
+    const float rq = a.sh.rho[qid];
+    const float nj_hi = nj * (1.0f + kGamma) * (1.0f + kSlack);
+    const float nj_lo = nj * (1.0f - kGamma) * (1.0f - kSlack);
+
+    // stage the 128 query rows
+    for (int ch = tid; ch < kPfQ * cpr; ch += 256) {
+        const int r = ch / cpr, cc = ch - r * cpr;
+        int sp = pos0 + r;
+        if (sp >= a.pos_end) sp = a.pos_end - 1;
+        const uint4 v = *reinterpret_cast<const uint4 *>(a.sh.Z + (size_t)a.bq[sp] * Dz + cc * 8);
+        *reinterpret_cast<uint4 *>(sQz + (size_t)r * stride + cc * 16) = v;
+    }
+
+    float ub[ML];
+#pragma unroll
+    for (int i = 0; i < ML; ++i) ub[i] = INFINITY;
+    float tau = INFINITY;   // m-th smallest UB over both lane halves of this query
+    int ccount = 0;
+
+    const int ntile = (nmem + kPfP - 1) / kPfP;
+    const int nchunk = kPfP * cpr;      // chunks per member tile (<= 4 per thread for Dz <= 256)
+    uint4 st[4];
+    float st_n = INFINITY, st_r = 0.f;
+    int st_id = -1;
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = tid + 256 * i;
+            if (ch < nchunk) {
+                const int r = ch / cpr, cc = ch - r * cpr;
+                const int e = t * kPfP + r;
+                const int id = e < nmem ? a.memb_id[mb + e] : 0;
+                st[i] = *reinterpret_cast<const uint4 *>(a.sh.Z + (size_t)id * Dz + cc * 8);
+            }
+        }
+        if (tid < kPfP) {
+            const int e = t * kPfP + tid;
+            if (e < nmem) {
+                st_id = a.memb_id[mb + e];
+                st_n = a.sh.nrm[st_id];
+                st_r = a.sh.rho[st_id];
+            } else {
+                st_id = -1; st_n = INFINITY; st_r = 0.f;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = tid + 256 * i;
+            if (ch < nchunk) {
+                const int r = ch / cpr, cc = ch - r * cpr;
+                *reinterpret_cast<uint4 *>(sPz + ((size_t)buf * kPfP + r) * stride + cc * 16) = st[i];
+            }
+        }
+        if (tid < kPfP) {
+            sPn[buf * kPfP + tid] = st_n;
+            sPr[buf * kPfP + tid] = st_r;
+            sPid[buf * kPfP + tid] = st_id;
+        }
+    };
+
+    if (ntile > 0) { fetch(0); stash(0); }
+    __syncthreads();
+
+    const unsigned char *qbase = sQz + (size_t)(32 * w + col) * stride + h * 16;
+    const size_t slot = (size_t)c * a.Kcap + qpos;
+    int *cand = a.cand + slot * kCandCap;
+
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntile) fetch(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + h * 16;
+        for (int s = 0; s < ksteps; ++s) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + s * 32);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(qbase + s * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+        }
+
+        // rows held by this lane: (r&3) + 8*(r>>2) + 4*h
+        float np[16];
+        float rt = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(&sPn[buf * kPfP + 8 * g + 4 * h]);
+            const float4 rr = *reinterpret_cast<const float4 *>(&sPr[buf * kPfP + 8 * g + 4 * h]);
+            np[4 * g + 0] = v.x; np[4 * g + 1] = v.y; np[4 * g + 2] = v.z; np[4 * g + 3] = v.w;
+            rt = fmaxf(rt, fmaxf(fmaxf(rr.x, rr.y), fmaxf(rr.z, rr.w)));
+        }
+        rt = fmaxf(rt, __shfl_xor(rt, 32, 64));
+        const float rsum = (rq + rt) * (1.0f + kSlack);
+
+        float u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = fmaf(-2.0f, acc[r], np[r]);
+
+        // (1) tighten tau with this tile: members whose UB' = sqrt(s + E) + rho_j + rho_tile < tau
+        float C1 = FLT_MAX;
+        if (tau < INFINITY) {
+            const float lo = tau - rsum;
+            C1 = lo > 0.f ? lo * lo * (1.0f - 4.0f * kSlack) - nj_hi : -FLT_MAX;
+        }
+        bool ins = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float t1 = fmaf(kGamma, np[r], u[r]);
+            if (t1 < C1) {
+                const float ubv = sqrtf(fmaxf(t1 + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
+                list_insert<ML>(ub, ubv);
+                ins = true;
+            }
+        }
+        if (__any(ins)) {
+            float mg[ML];
+#pragma unroll
+            for (int i = 0; i < ML; ++i) mg[i] = ub[i];
+#pragma unroll
+            for (int i = 0; i < ML; ++i) list_insert<ML>(mg, __shfl_xor(ub[i], 32, 64));
+#pragma unroll
+            for (int i = 0; i < ML; ++i)
+                if (i == m - 1) tau = mg[i];
+        }
+
+        // (2) shortlist: LB' = sqrt(s - E) - rho_j - rho_tile <= tau
+        float C2 = FLT_MAX;
+        if (tau < INFINITY) {
+            const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+            C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
+        }
+        unsigned mask = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float t2 = fmaf(-kGamma, np[r], u[r]);
+            if (t2 <= C2) mask |= 1u << r;
+        }
+        const int cnt = __popc(mask);
+        const int pc = __shfl_xor(cnt, 32, 64);
+        int off = ccount + (h ? pc : 0);
+        ccount += cnt + pc;
+        if (qvalid) {
+            while (mask) {
+                const int r = __ffs(mask) - 1;
+                mask &= mask - 1u;
+                const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (off < kCandCap) cand[off] = sPid[buf * kPfP + prow];
+                ++off;
+            }
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntile) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (qvalid && h == 0) {
+        a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
+        if (ccount > kCandCap) {
+            atomicAdd(a.overflow, 1);
+            flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
+        }
+    }
+}
+
+}  // namespace
+
+void launch_col_sums(const double *X, int N, int D, int Dp, double *work, hipStream_t s)
+{
+    // work: [nblocks*D partials][D means]
+    const int nblocks = 256;
+    const int rpb = (N + nblocks - 1) / nblocks;
+    double *partial = work;
+    double *mean = work + (size_t)nblocks * D;
+    hipLaunchKernelGGL(col_partial_kernel, dim3(nblocks), dim3(256), 0, s, X, N, D, Dp, rpb, partial);
+    hipLaunchKernelGGL(col_final_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partial, nblocks, D, N, mean);
+}
+
+void launch_build_shadow(const double *X, int N, int D, int Dp, const double *colmean,
+                         unsigned short *Z, int Dz, float *nrm, float *rho, hipStream_t s)
+{
+    hipLaunchKernelGGL(build_shadow_kernel, dim3(N), dim3(64), 0, s, X, N, D, Dp, colmean, Z, Dz, nrm, rho);
+}
+
+size_t prefilter_lds_bytes(int Dz)
+{
+    const int stride = Dz * 2 + 16;
+    return (size_t)(kPfQ + 2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4);
+}
+
+void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s)
+{
+    const int nq = a.pos_end - a.pos_begin;
+    if (nq <= 0 || a.B <= 0) return;
+    const int nqt = (nq + kPfQ - 1) / kPfQ;
+    const int total = nqt * a.B;
+    const int grid = ((total + 7) / 8) * 8;
+    const int stride = a.sh.Dz * 2 + 16;
+    const size_t lds = prefilter_lds_bytes(a.sh.Dz);
+    const int nqt64 = (nq + kQTile - 1) / kQTile;
+    static bool attr_done[3] = {false, false, false};
+    if (a.m <= 5) {
+        if (!attr_done[0]) { (void)hipFuncSetAttribute((const void *)prefilter_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[0] = true; }
+        hipLaunchKernelGGL(prefilter_kernel<5>, dim3(grid), dim3(256), lds, s, a, nqt, total, stride, flags64, nqt64);
+    } else if (a.m <= 8) {
+        if (!attr_done[1]) { (void)hipFuncSetAttribute((const void *)prefilter_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
+        hipLaunchKernelGGL(prefilter_kernel<8>, dim3(grid), dim3(256), lds, s, a, nqt, total, stride, flags64, nqt64);
+    } else {
+        if (!attr_done[2]) { (void)hipFuncSetAttribute((const void *)prefilter_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[2] = true; }
+        hipLaunchKernelGGL(prefilter_kernel<16>, dim3(grid), dim3(256), lds, s, a, nqt, total, stride, flags64, nqt64);
+    }
+}
+
+}  // namespace chb

@@ -37,52 +37,53 @@ __device__ __forceinline__ bool lex_less(double d0, int i0, double d1, int i1)
 // sqrt(s) <= e  implies  s <= e*e*(1 + 2^-50)
 __device__ __forceinline__ double tau_from(double e) { return e * e * (1.0 + 0x1p-50); }
 
-// Offer the (up to) 4 candidates held by every lane of a 16-lane group to the group's sorted
-// list (lane tx holds entry tx).  Wave-synchronous; all 64 lanes must call it together.
-__device__ __forceinline__ void select_into(double (&s)[4], const int (&mid)[4], double &ld, int &li,
+// Offer the (up to) NC candidates held by every lane of a W-lane group to the group's sorted
+// list (lane t of the group holds entry t).  Wave-synchronous; all 64 lanes must call it together.
+template <int W, int NC>
+__device__ __forceinline__ void select_into(double (&s)[NC], const int (&mid)[NC], double &ld, int &li,
                                             int &lc, double &tau, int m, int tx, int gbase)
 {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NC; ++j)
         if (!(s[j] <= tau)) s[j] = kInf;
     for (;;) {
         double bs = s[0];
         int bi = mid[0], bj = 0;
 #pragma unroll
-        for (int j = 1; j < 4; ++j)
+        for (int j = 1; j < NC; ++j)
             if (lex_less(s[j], mid[j], bs, bi)) { bs = s[j]; bi = mid[j]; bj = j; }
         double gs = bs;
         int gi = bi;
 #pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
-            double os = __shfl_xor(gs, off, 16);
-            int oi = __shfl_xor(gi, off, 16);
+        for (int off = W / 2; off >= 1; off >>= 1) {
+            double os = __shfl_xor(gs, off, W);
+            int oi = __shfl_xor(gi, off, W);
             if (lex_less(os, oi, gs, gi)) { gs = os; gi = oi; }
         }
         const bool have = gs < kInf;
         if (!__any(have)) break;
         if (have && bs == gs && bi == gi) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NC; ++j)
                 if (j == bj) s[j] = kInf;
         }
         const double d = sqrt(gs);
         const bool lt = (tx < lc) && lex_less(ld, li, d, gi);
         const unsigned long long bal = __ballot(lt);
-        const int pos = __popcll((bal >> gbase) & 0xFFFFull);
-        const double ud = __shfl_up(ld, 1, 16);
-        const int ui = __shfl_up(li, 1, 16);
+        const int pos = __popcll((bal >> gbase) & ((W == 64) ? ~0ull : ((1ull << (W & 63)) - 1ull)));
+        const double ud = __shfl_up(ld, 1, W);
+        const int ui = __shfl_up(li, 1, W);
         const bool ins = have && pos < m;
         if (ins) {
             if (tx == pos) { ld = d; li = gi; }
             else if (tx > pos) { ld = ud; li = ui; }
             lc = lc + 1 < m ? lc + 1 : m;
         }
-        const double e = __shfl(ld, m - 1, 16);
+        const double e = __shfl(ld, m - 1, W);
         if (ins && lc >= m) {
             tau = tau_from(e);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NC; ++j)
                 if (!(s[j] <= tau)) s[j] = kInf;
         }
     }
@@ -92,7 +93,7 @@ __device__ __forceinline__ void select_into(double (&s)[4], const int (&mid)[4],
 // (chb_pairwise_distance); "bins" are then contiguous member ranges and bq is null.
 template <bool PW>
 __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int total, int pw_n,
-                                                   int pw_group, double *pw_out)
+                                                   int pw_group, double *pw_out, const int *flags)
 {
     __shared__ __attribute__((aligned(16))) double sQ[2][kKChunk][kLdsStride];
     __shared__ __attribute__((aligned(16))) double sP[2][kKChunk][kLdsStride];
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
     const int per = (total + 7) >> 3;
     const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (W >= total) return;
+    if (flags != nullptr && flags[W] == 0) return;   // fallback launch: only flagged work items
     const int c = W / nqt, qt = W - c * nqt;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
                         else if (code[j] < 0) ok = ok && (qpos < -code[j] - 1);
                         s[j] = ok ? acc[i][j] : kInf;
                     }
-                    select_into(s, mid, ld[i], li[i], lc[i], tau[i], m, tx, gbase);
+                    select_into<16, 4>(s, mid, ld[i], li[i], lc[i], tau[i], m, tx, gbase);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
@@ -264,6 +266,57 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
     }
 }
 
+// Stage 2 of the two-stage selection: exact distances on the shortlist of one (position, bin)
+// pair per half-wavefront (one candidate per lane, k-sequential unfused sum = cdist rounding),
+// then the same (distance, index) top-m list as the brute-force kernel.
+__global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a, int npairs)
+{
+    const int lane = threadIdx.x & 63, hl = lane & 31, hbase = lane & 32;
+    const int pair = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool pvalid = pair < npairs;
+    int pos = a.pos_begin, c = 0, cnt = 0;
+    if (pvalid) {
+        pos = a.pos_begin + pair / a.B;
+        c = pair - (pair / a.B) * a.B;
+    }
+    const size_t slot = (size_t)c * a.Kcap + pos;
+    if (pvalid) cnt = a.cand_cnt[slot];
+    const int qid = a.bq[pos];
+    const double *qrow = a.X + (size_t)qid * a.Dp;
+    const int m = a.m;
+
+    double ld = kInf, tau = kInf;
+    int li = INT_MAX, lc = 0;
+    int cmax = cnt;
+    cmax = max(cmax, __shfl_xor(cmax, 32, 64));
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
+    for (int base = 0; base < cmax; base += 32) {
+        const int ci = base + hl;
+        const bool have = ci < cnt;
+        const int id = have ? a.cand[slot * kCandCap + ci] : 0;
+        const double *prow = a.X + (size_t)id * a.Dp;
+        double sacc = 0.0;
+        for (int k = 0; k < a.Dp; k += 2) {
+            const double2 pv = *reinterpret_cast<const double2 *>(prow + k);
+            const double2 qv = *reinterpret_cast<const double2 *>(qrow + k);
+            const double d0 = qv.x - pv.x;
+            sacc = sacc + d0 * d0;
+            const double d1 = qv.y - pv.y;
+            sacc = sacc + d1 * d1;
+        }
+        double s1[1] = {have ? sacc : kInf};
+        const int id1[1] = {have ? id : INT_MAX};
+        select_into<32, 1>(s1, id1, ld, li, lc, tau, m, hl, hbase);
+    }
+    if (pvalid) {
+        if (hl < m) {
+            a.out.d[slot * m + hl] = hl < lc ? ld : kInf;
+            a.out.idx[slot * m + hl] = hl < lc ? li : -1;
+        }
+        if (hl == 0) a.out.cnt[slot] = lc;
+    }
+}
+
 }  // namespace
 
 void launch_topm(const TopmArgs &a, hipStream_t s)
@@ -274,7 +327,26 @@ void launch_topm(const TopmArgs &a, hipStream_t s)
     const int total = nqt * a.B;
     const int grid = ((total + 7) / 8) * 8;
     hipLaunchKernelGGL(tile_kernel<false>, dim3(grid), dim3(256), 0, s, a, nqt, total, 0, 0,
-                       (double *)nullptr);
+                       (double *)nullptr, (const int *)nullptr);
+}
+
+void launch_topm_flagged(const TopmArgs &a, const int *flags64, hipStream_t s)
+{
+    const int nq = a.pos_end - a.pos_begin;
+    if (nq <= 0 || a.B <= 0) return;
+    const int nqt = (nq + kQTile - 1) / kQTile;
+    const int total = nqt * a.B;
+    const int grid = ((total + 7) / 8) * 8;
+    hipLaunchKernelGGL(tile_kernel<false>, dim3(grid), dim3(256), 0, s, a, nqt, total, 0, 0,
+                       (double *)nullptr, flags64);
+}
+
+void launch_rescore(const RescoreArgs &a, hipStream_t s)
+{
+    const int npairs = (a.pos_end - a.pos_begin) * a.B;
+    if (npairs <= 0) return;
+    const int grid = (npairs + 7) / 8;
+    hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(256), 0, s, a, npairs);
 }
 
 void launch_pairwise(const double *X, int N, int Dp, int r0, int r1, double *out, hipStream_t s)
@@ -288,7 +360,8 @@ void launch_pairwise(const double *X, int N, int Dp, int r0, int r1, double *out
     const int nqt = (r1 - r0 + kQTile - 1) / kQTile;
     const int total = nqt * ngroups;
     const int grid = ((total + 7) / 8) * 8;
-    hipLaunchKernelGGL(tile_kernel<true>, dim3(grid), dim3(256), 0, s, a, nqt, total, N, group, out);
+    hipLaunchKernelGGL(tile_kernel<true>, dim3(grid), dim3(256), 0, s, a, nqt, total, N, group, out,
+                       (const int *)nullptr);
 }
 
 }  // namespace chb

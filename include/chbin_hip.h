@@ -113,12 +113,18 @@ int chb_fit_labels(chb_ctx *h, int64_t *labels_out);
 /* ---- measurement: HIP-event timing of every kernel launch on the context's stream */
 int chb_profile_enable(chb_ctx *h, int on);
 int chb_profile_reset(chb_ctx *h);
-/* kernel: "topm_base" | "topm_update" | "hull_qp" | "argmin" | "bucket" | "pairwise" */
+/* kernel: "prefilter" | "rescore" | "topm_fallback" | "topm_base" | "topm_update" | "hull_qp" |
+ * "argmin" | "bucket" | "pairwise" */
 int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *launches,
                     double *work_units);
 /* counters of the last chb_fit_cluster call: [0]=batches [1]=rounds [2]=hull distances evaluated
  * (incl. speculative re-evaluation) [3]=hull distances the sequential loop needs (sweeps*n_move*B) */
 int chb_fit_stats(chb_ctx *h, int64_t *out4);
+/* diagnostic counters: "prefilter_enabled" (1 when the bf16 shortlist stage is active; the
+ * environment variable CHB_PREFILTER=0 selects the brute-force selection kernel instead),
+ * "prefilter_overflow" (shortlists that overflowed and were recomputed by brute force since the
+ * last chb_fit_begin) */
+int chb_counter(chb_ctx *h, const char *name, int64_t *out);
 
 #ifdef __cplusplus
 }

@@ -325,3 +325,66 @@ def test_full_size_fixed_point_property(ctx, O):
         lab_j, md = O.sweep(X, B, got, np.array([j]), m)
         assert lab_j[j] == got[j]
         assert abs(md[0] - mind[j]) < QP_TOL
+
+
+# ------------------------------------------------------------------ two-stage selection
+
+def _brute_ctx():
+    """A second context with the bf16 shortlist stage disabled (brute-force selection)."""
+    from chbin_amd import _lib
+    old = os.environ.get("CHB_PREFILTER")
+    os.environ["CHB_PREFILTER"] = "0"
+    try:
+        c = _lib.Context(0)
+    finally:
+        if old is None:
+            del os.environ["CHB_PREFILTER"]
+        else:
+            os.environ["CHB_PREFILTER"] = old
+    return c
+
+
+@pytest.mark.parametrize("kind", ["offset", "tiny", "dups", "wide", "onehot"])
+def test_shortlist_stage_equals_brute_force(ctx, O, kind):
+    """The bf16 shortlist + exact rescoring must give bit-identical lists to the brute-force
+    kernel on data built to stress the error bounds and the overflow fallback."""
+    assert ctx.counter("prefilter_enabled") == 1
+    rng = np.random.default_rng(11)
+    N, D, B, m = 3000, 136, 6, 5
+    X, _, true = _synth(N, D, B, seed=4, sigma=3e-3, mix=0.5)
+    if kind == "offset":
+        X = X + 1000.0                                   # huge common offset: centring must cope
+    elif kind == "tiny":
+        X = X * 1e-150
+    elif kind == "dups":
+        X[100:400] = X[100]                              # 300 identical members: shortlist overflow
+        true[100:400] = 1
+    elif kind == "wide":
+        X = X * rng.lognormal(0, 3, size=(1, D))         # wildly different column scales
+    elif kind == "onehot":
+        X = np.zeros((N, D)); X[np.arange(N), rng.integers(0, D, N)] = 1.0   # massive exact ties
+    labels = true.copy()
+    labels[rng.random(N) < 0.1] = -1
+    queries = rng.choice(N, 700, replace=False)
+    ctx.set_samples(X)
+    got = ctx.topm_per_bin(labels, B, m, queries)
+    overflow = ctx.counter("prefilter_overflow")
+    b = _brute_ctx()
+    try:
+        assert b.counter("prefilter_enabled") == 0
+        b.set_samples(X)
+        want = b.topm_per_bin(labels, B, m, queries)
+    finally:
+        b.close()
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+    if kind in ("dups", "onehot"):
+        assert overflow > 0                              # the fallback really ran
+    # and against the oracle for a few queries
+    for qi in range(0, 700, 97):
+        q = queries[qi]
+        cur = labels.copy(); cur[q] = -1
+        row = O.cdist_row(X, int(q))
+        for c in range(B):
+            want_idx = O.find_nearest_from_cluster(c, cur, row, m)
+            assert np.array_equal(got[0][qi, c, :len(want_idx)], want_idx)
