@@ -104,6 +104,7 @@ struct chb_ctx {
     int Dz = 0;
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
     DevBuf<int> cand, cand_cnt, flags64, overflow;
+    DevBuf<float> cand_lb, cand_tau;
     // scratch for the indexed / explicit-point entry points
     DevBuf<int> xq, xhull, xcnt;
     DevBuf<double> xdist, xalpha, xpts;
@@ -183,6 +184,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     if (h->use_prefilter && h->shadow_ok) {
         HIPCHK(h->cand.ensure(K * B * (size_t)kCandCap));
         HIPCHK(h->cand_cnt.ensure(K * B));
+        HIPCHK(h->cand_lb.ensure(K * B * (size_t)kCandCap));
+        HIPCHK(h->cand_tau.ensure(K * B));
         HIPCHK(h->flags64.ensure(B * ((K + kQTile - 1) / kQTile)));
         HIPCHK(h->overflow.ensure(1));
     }
@@ -243,6 +246,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p;
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
         pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
+        pa.cand_lb = h->cand_lb.p; pa.cand_tau = h->cand_tau.p;
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
             launch_prefilter(pa, h->flags64.p, s);
@@ -251,6 +255,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = q_lo; ra.pos_end = q_hi;
         ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
         ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.out = h->L0();
+        ra.cand_lb = h->cand_lb.p; ra.cand_tau = h->cand_tau.p;
         {
             Timed t(h, "rescore", (double)(q_hi - q_lo) * h->B);
             launch_rescore(ra, s);
@@ -374,6 +379,7 @@ int chb_destroy(chb_ctx *h)
     DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
     h->Z.release(); h->znrm.release(); h->zrho.release(); h->colwork.release();
+    h->cand_lb.release(); h->cand_tau.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
     return CHB_OK;
@@ -840,6 +846,22 @@ int chb_counter(chb_ctx *h, const char *name, int64_t *out)
         }
         return CHB_OK;
     }
+    if (!strcmp(name, "shortlist_sum_last_batch") || !strcmp(name, "shortlist_max_last_batch")) {
+        if (h->cand_cnt.p && h->K > 0) {
+            std::vector<int> v((size_t)h->Kcap * h->B);
+            HIPCHK(hipMemcpyAsync(v.data(), h->cand_cnt.p, sizeof(int) * v.size(), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            int64_t sum = 0, mx = 0;
+            for (int c = 0; c < h->B; ++c)
+                for (int i = 0; i < h->K; ++i) {
+                    const int x = v[(size_t)c * h->Kcap + i];
+                    sum += x; if (x > mx) mx = x;
+                }
+            *out = name[10] == 's' ? sum : mx;
+        }
+        return CHB_OK;
+    }
+    if (!strcmp(name, "last_batch_k")) { *out = h->K; return CHB_OK; }
     if (!strcmp(name, "prefilter_enabled")) { *out = (h->use_prefilter && h->shadow_ok) ? 1 : 0; return CHB_OK; }
     return fail(CHB_EINVAL, "unknown counter");
 }

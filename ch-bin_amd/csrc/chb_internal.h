@@ -60,7 +60,9 @@ struct PrefilterArgs {
     const int *memb_id;
     int B, m, Kcap;
     int *cand;       // [B][Kcap][kCandCap] sample indices
+    float *cand_lb;  // [B][Kcap][kCandCap] lower bound of the candidate's distance
     int *cand_cnt;   // [B][Kcap]
+    float *cand_tau; // [B][Kcap] final tau: at least m members are provably within it
     int *overflow;   // [1] number of (bin, position) pairs whose shortlist overflowed
 };
 // flags64[bin][ceil(nq/64)] (pre-zeroed): set for (query tile of 64, bin) pairs whose shortlist overflowed
@@ -74,7 +76,10 @@ struct RescoreArgs {
     int pos_begin, pos_end;
     int B, m, Kcap;
     const int *cand;
+    const float *cand_lb;
     const int *cand_cnt;
+    const float *cand_tau;
+    Lists in;    // in.d == nullptr: start from empty lists
     Lists out;
 };
 void launch_rescore(const RescoreArgs &a, hipStream_t s);

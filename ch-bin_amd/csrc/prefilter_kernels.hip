@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
     const unsigned char *qbase = sQz + (size_t)(32 * w + col) * stride + h * 16;
     const size_t slot = (size_t)c * a.Kcap + qpos;
     int *cand = a.cand + slot * kCandCap;
+    float *cand_lb = a.cand_lb + slot * kCandCap;
 
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
@@ -286,13 +287,22 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
         const int pc = __shfl_xor(cnt, 32, 64);
         int off = ccount + (h ? pc : 0);
         ccount += cnt + pc;
-        if (qvalid) {
-            while (mask) {
-                const int r = __ffs(mask) - 1;
-                mask &= mask - 1u;
-                const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (off < kCandCap) cand[off] = sPid[buf * kPfP + prow];
-                ++off;
+        if (qvalid && mask) {
+            // the lower bound travels with the candidate: the rescoring pass drops every candidate
+            // whose LB exceeds the FINAL tau (early tiles were admitted against a looser one)
+            float t2v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t2v[r] = fmaf(-kGamma, np[r], u[r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (mask & (1u << r)) {
+                    const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (off < kCandCap) {
+                        cand[off] = sPid[buf * kPfP + prow];
+                        cand_lb[off] = sqrtf(fmaxf(t2v[r] + nj_lo, 0.f)) * (1.0f - 4.0f * kSlack) - rsum;
+                    }
+                    ++off;
+                }
             }
         }
 
@@ -303,6 +313,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
 
     if (qvalid && h == 0) {
         a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
+        a.cand_tau[slot] = tau < INFINITY ? tau * (1.0f + 4.0f * kSlack) : INFINITY;
         if (ccount > kCandCap) {
             atomicAdd(a.overflow, 1);
             flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
