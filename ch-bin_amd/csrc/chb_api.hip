@@ -290,7 +290,37 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;
         a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
         a.in = h->L0(); a.out = h->L1();
-        {
+        if (h->use_prefilter && h->shadow_ok && h->cand.p) {
+            // batch members that can displace an entry of the base list: bf16 shortlist against
+            // the exact m-th distance, exact rescoring seeded with the base list
+            const int nq64 = (hi - lo + kQTile - 1) / kQTile;
+            launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
+            PrefilterArgs pa{};
+            pa.sh = Shadow{h->Z.p, h->znrm.p, h->zrho.p, h->Dz};
+            pa.bq = h->bq.p; pa.pos_begin = lo; pa.pos_end = hi;
+            pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.memb_code = h->memb2_code.p;
+            pa.seed = h->L0();
+            pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
+            pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
+            pa.cand_lb = h->cand_lb.p; pa.cand_tau = h->cand_tau.p;
+            {
+                Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
+                launch_prefilter(pa, h->flags64.p, s);
+            }
+            RescoreArgs ra{};
+            ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = lo; ra.pos_end = hi;
+            ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
+            ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.cand_lb = nullptr; ra.cand_tau = nullptr;
+            ra.in = h->L0(); ra.out = h->L1();
+            {
+                Timed t(h, "rescore_update", (double)(hi - lo) * h->B);
+                launch_rescore(ra, s);
+            }
+            {
+                Timed t(h, "topm_fallback", 0.0);
+                launch_topm_flagged(a, h->flags64.p, s);
+            }
+        } else {
             Timed t(h, "topm_update", (double)(hi - lo) * h->hint_batch_entries);
             launch_topm(a, s);
         }

@@ -58,6 +58,8 @@ struct PrefilterArgs {
     int pos_begin, pos_end;
     const int *bin_ptr;
     const int *memb_id;
+    const int *memb_code;  // non-null selects the update mode: batch members, fixed tau from `seed`
+    Lists seed;
     int B, m, Kcap;
     int *cand;       // [B][Kcap][kCandCap] sample indices
     float *cand_lb;  // [B][Kcap][kCandCap] lower bound of the candidate's distance

@@ -111,7 +111,11 @@ __device__ __forceinline__ void list_insert(float (&l)[ML], float v)
     }
 }
 
-template <int ML>
+// UPD = false: base members of the bin, tau learned on the fly (top-m of the upper bounds).
+// UPD = true : the batch's own members (eligibility code per member, see aux_kernels.hip) against a
+//              FIXED tau = the exact m-th distance of the already known list `seed`; members that
+//              cannot displace a list entry are dropped without ever touching fp64.
+template <int ML, bool UPD>
 __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
                                                         int stride, int *flags64, int nqt64)
 {
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
     float *sPn = reinterpret_cast<float *>(sPz + (size_t)2 * kPfP * stride);  // [2][kPfP]
     float *sPr = sPn + 2 * kPfP;                             // [2][kPfP]
     int *sPid = reinterpret_cast<int *>(sPr + 2 * kPfP);     // [2][kPfP]
+    int *sPcode = sPid + 2 * kPfP;                           // [2][kPfP]
 
     const int per = (total + 7) >> 3;
     const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -160,12 +165,19 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
     for (int i = 0; i < ML; ++i) ub[i] = INFINITY;
     float tau = INFINITY;   // m-th smallest UB over both lane halves of this query
     int ccount = 0;
+    if (UPD && qvalid) {
+        const size_t sl = (size_t)c * a.Kcap + qpos;
+        if (a.seed.cnt[sl] >= m) {
+            const double e = a.seed.d[sl * m + m - 1];   // exact m-th distance so far
+            tau = round_up_f32(e) * (1.0f + kSlack);
+        }
+    }
 
     const int ntile = (nmem + kPfP - 1) / kPfP;
     const int nchunk = kPfP * cpr;      // chunks per member tile (<= 4 per thread for Dz <= 256)
     uint4 st[4];
     float st_n = INFINITY, st_r = 0.f;
-    int st_id = -1;
+    int st_id = -1, st_code = 0;
     auto fetch = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -183,8 +195,9 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
                 st_id = a.memb_id[mb + e];
                 st_n = a.sh.nrm[st_id];
                 st_r = a.sh.rho[st_id];
+                st_code = UPD ? a.memb_code[mb + e] : 0;
             } else {
-                st_id = -1; st_n = INFINITY; st_r = 0.f;
+                st_id = -1; st_n = INFINITY; st_r = 0.f; st_code = 0;
             }
         }
     };
@@ -201,6 +214,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
             sPn[buf * kPfP + tid] = st_n;
             sPr[buf * kPfP + tid] = st_r;
             sPid[buf * kPfP + tid] = st_id;
+            sPcode[buf * kPfP + tid] = st_code;
         }
     };
 
@@ -239,6 +253,18 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
         }
         rt = fmaxf(rt, __shfl_xor(rt, 32, 64));
         const float rsum = (rq + rt) * (1.0f + kSlack);
+        if (UPD) {
+            // a batch member counts for this query only on the right side of the visiting order
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int code = sPcode[buf * kPfP + (r & 3) + 8 * (r >> 2) + 4 * h];
+                bool ok = true;
+                if (code > 0) ok = qpos > code - 1;
+                else if (code <= -(1 << 30)) ok = qpos != -(1 << 30) - code;
+                else if (code < 0) ok = qpos < -code - 1;
+                if (!ok) np[r] = INFINITY;
+            }
+        }
 
         float u[16];
 #pragma unroll
@@ -251,6 +277,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
             C1 = lo > 0.f ? lo * lo * (1.0f - 4.0f * kSlack) - nj_hi : -FLT_MAX;
         }
         bool ins = false;
+        if (!UPD) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float t1 = fmaf(kGamma, np[r], u[r]);
@@ -269,6 +296,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
 #pragma unroll
             for (int i = 0; i < ML; ++i)
                 if (i == m - 1) tau = mg[i];
+        }
         }
 
         // (2) shortlist: LB' = sqrt(s - E) - rho_j - rho_tile <= tau
@@ -299,7 +327,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
                     const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (off < kCandCap) {
                         cand[off] = sPid[buf * kPfP + prow];
-                        cand_lb[off] = sqrtf(fmaxf(t2v[r] + nj_lo, 0.f)) * (1.0f - 4.0f * kSlack) - rsum;
+                        if (!UPD) cand_lb[off] = sqrtf(fmaxf(t2v[r] + nj_lo, 0.f)) * (1.0f - 4.0f * kSlack) - rsum;
                     }
                     ++off;
                 }
@@ -313,7 +341,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
 
     if (qvalid && h == 0) {
         a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
-        a.cand_tau[slot] = tau < INFINITY ? tau * (1.0f + 4.0f * kSlack) : INFINITY;
+        if (!UPD) a.cand_tau[slot] = tau < INFINITY ? tau * (1.0f + 4.0f * kSlack) : INFINITY;
         if (ccount > kCandCap) {
             atomicAdd(a.overflow, 1);
             flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
@@ -343,7 +371,21 @@ void launch_build_shadow(const double *X, int N, int D, int Dp, const double *co
 size_t prefilter_lds_bytes(int Dz)
 {
     const int stride = Dz * 2 + 16;
-    return (size_t)(kPfQ + 2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4);
+    return (size_t)(kPfQ + 2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4 + 4);
+}
+
+template <int ML, bool UPD>
+static void launch_pf(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
+                      int *flags64, int nqt64, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)prefilter_kernel<ML, UPD>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((prefilter_kernel<ML, UPD>), dim3(grid), dim3(256), lds, s, a, nqt, total, stride,
+                       flags64, nqt64);
 }
 
 void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s)
@@ -356,16 +398,14 @@ void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s)
     const int stride = a.sh.Dz * 2 + 16;
     const size_t lds = prefilter_lds_bytes(a.sh.Dz);
     const int nqt64 = (nq + kQTile - 1) / kQTile;
-    static bool attr_done[3] = {false, false, false};
-    if (a.m <= 5) {
-        if (!attr_done[0]) { (void)hipFuncSetAttribute((const void *)prefilter_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[0] = true; }
-        hipLaunchKernelGGL(prefilter_kernel<5>, dim3(grid), dim3(256), lds, s, a, nqt, total, stride, flags64, nqt64);
+    if (a.memb_code != nullptr) {
+        launch_pf<1, true>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
+    } else if (a.m <= 5) {
+        launch_pf<5, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
     } else if (a.m <= 8) {
-        if (!attr_done[1]) { (void)hipFuncSetAttribute((const void *)prefilter_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
-        hipLaunchKernelGGL(prefilter_kernel<8>, dim3(grid), dim3(256), lds, s, a, nqt, total, stride, flags64, nqt64);
+        launch_pf<8, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
     } else {
-        if (!attr_done[2]) { (void)hipFuncSetAttribute((const void *)prefilter_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[2] = true; }
-        hipLaunchKernelGGL(prefilter_kernel<16>, dim3(grid), dim3(256), lds, s, a, nqt, total, stride, flags64, nqt64);
+        launch_pf<16, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
     }
 }
 
