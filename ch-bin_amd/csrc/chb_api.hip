@@ -103,8 +103,9 @@ struct chb_ctx {
     DevBuf<double> colwork;
     int Dz = 0;
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
+    bool pf_base = true, pf_update = true;   // developer switches (CHB_PF_BASE / CHB_PF_UPDATE)
     DevBuf<int> cand, cand_cnt, flags64, overflow;
-    DevBuf<float> cand_lb, cand_tau;
+    DevBuf<int> active, n_active;
     // scratch for the indexed / explicit-point entry points
     DevBuf<int> xq, xhull, xcnt;
     DevBuf<double> xdist, xalpha, xpts;
@@ -184,8 +185,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     if (h->use_prefilter && h->shadow_ok) {
         HIPCHK(h->cand.ensure(K * B * (size_t)kCandCap));
         HIPCHK(h->cand_cnt.ensure(K * B));
-        HIPCHK(h->cand_lb.ensure(K * B * (size_t)kCandCap));
-        HIPCHK(h->cand_tau.ensure(K * B));
+        HIPCHK(h->active.ensure(K * B));
+        HIPCHK(h->n_active.ensure(1));
         HIPCHK(h->flags64.ensure(B * ((K + kQTile - 1) / kQTile)));
         HIPCHK(h->overflow.ensure(1));
     }
@@ -234,7 +235,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
     a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
     a.in = Lists{nullptr, nullptr, nullptr};
     a.out = h->L0();
-    if (h->use_prefilter && h->shadow_ok && h->cand.p) {
+    if (h->use_prefilter && h->pf_base && h->shadow_ok && h->cand.p) {
         // two-stage exact selection: bf16 matrix-core shortlist, exact fp64 on the shortlist,
         // brute force only for (query tile, bin) pairs whose shortlist overflowed
         const int nq64 = (q_hi - q_lo + kQTile - 1) / kQTile;
@@ -246,7 +247,6 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p;
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
         pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
-        pa.cand_lb = h->cand_lb.p; pa.cand_tau = h->cand_tau.p;
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
             launch_prefilter(pa, h->flags64.p, s);
@@ -255,7 +255,6 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = q_lo; ra.pos_end = q_hi;
         ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
         ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.out = h->L0();
-        ra.cand_lb = h->cand_lb.p; ra.cand_tau = h->cand_tau.p;
         {
             Timed t(h, "rescore", (double)(q_hi - q_lo) * h->B);
             launch_rescore(ra, s);
@@ -290,7 +289,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;
         a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
         a.in = h->L0(); a.out = h->L1();
-        if (h->use_prefilter && h->shadow_ok && h->cand.p) {
+        if (h->use_prefilter && h->pf_update && h->shadow_ok && h->cand.p) {
             // batch members that can displace an entry of the base list: bf16 shortlist against
             // the exact m-th distance, exact rescoring seeded with the base list
             const int nq64 = (hi - lo + kQTile - 1) / kQTile;
@@ -302,7 +301,8 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             pa.seed = h->L0();
             pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
             pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
-            pa.cand_lb = h->cand_lb.p; pa.cand_tau = h->cand_tau.p;
+            pa.active = h->active.p; pa.n_active = h->n_active.p;
+            launch_fill_i32(h->n_active.p, 0, 1, s);
             {
                 Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
                 launch_prefilter(pa, h->flags64.p, s);
@@ -310,8 +310,16 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             RescoreArgs ra{};
             ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = lo; ra.pos_end = hi;
             ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
-            ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.cand_lb = nullptr; ra.cand_tau = nullptr;
+            ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p;
+            ra.active = h->active.p; ra.n_active = h->n_active.p;
             ra.in = h->L0(); ra.out = h->L1();
+            // pairs without any candidate keep the base list
+            {
+                const size_t nl = (size_t)h->Kcap * h->B;
+                HIPCHK(hipMemcpyAsync(h->l1d.p, h->l0d.p, sizeof(double) * nl * h->m, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(h->l1i.p, h->l0i.p, sizeof(int) * nl * h->m, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(h->l1c.p, h->l0c.p, sizeof(int) * nl, hipMemcpyDeviceToDevice, s));
+            }
             {
                 Timed t(h, "rescore_update", (double)(hi - lo) * h->B);
                 launch_rescore(ra, s);
@@ -389,6 +397,8 @@ int chb_create(int device_id, chb_ctx **out)
     chb_ctx *h = new chb_ctx();
     h->dev = device_id;
     if (const char *e = getenv("CHB_PREFILTER")) h->use_prefilter = atoi(e) != 0;
+    if (const char *e = getenv("CHB_PF_BASE")) h->pf_base = atoi(e) != 0;
+    if (const char *e = getenv("CHB_PF_UPDATE")) h->pf_update = atoi(e) != 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
@@ -409,7 +419,7 @@ int chb_destroy(chb_ctx *h)
     DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
     h->Z.release(); h->znrm.release(); h->zrho.release(); h->colwork.release();
-    h->cand_lb.release(); h->cand_tau.release();
+    h->active.release(); h->n_active.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
     return CHB_OK;

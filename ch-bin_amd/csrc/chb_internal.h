@@ -38,7 +38,7 @@ void launch_topm(const TopmArgs &a, hipStream_t s);
 void launch_topm_flagged(const TopmArgs &a, const int *flags64, hipStream_t s);
 
 // ---- two-stage exact selection (prefilter_kernels.hip + rescore in topm_kernels.hip)
-constexpr int kCandCap = 96;   // shortlist capacity per (bin, batch position)
+constexpr int kCandCap = 64;   // shortlist capacity per (bin, batch position)
 
 // Per-sample data of the low-precision shadow copy: centred features rounded to bf16, the exact
 // squared norm of the rounded vector and the exact rounding distance rho = ||zhat - z||.
@@ -62,9 +62,9 @@ struct PrefilterArgs {
     Lists seed;
     int B, m, Kcap;
     int *cand;       // [B][Kcap][kCandCap] sample indices
-    float *cand_lb;  // [B][Kcap][kCandCap] lower bound of the candidate's distance
     int *cand_cnt;   // [B][Kcap]
-    float *cand_tau; // [B][Kcap] final tau: at least m members are provably within it
+    int *active;     // update mode: compacted list of (position, bin) pairs with a non-empty shortlist
+    int *n_active;   // [1]
     int *overflow;   // [1] number of (bin, position) pairs whose shortlist overflowed
 };
 // flags64[bin][ceil(nq/64)] (pre-zeroed): set for (query tile of 64, bin) pairs whose shortlist overflowed
@@ -78,9 +78,9 @@ struct RescoreArgs {
     int pos_begin, pos_end;
     int B, m, Kcap;
     const int *cand;
-    const float *cand_lb;
     const int *cand_cnt;
-    const float *cand_tau;
+    const int *active;    // non-null: only these pairs (index = (pos - pos_begin) * B + bin) ...
+    const int *n_active;  // ... *n_active of them; everything else in `out` must already hold `in`
     Lists in;    // in.d == nullptr: start from empty lists
     Lists out;
 };

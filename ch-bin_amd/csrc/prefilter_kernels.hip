@@ -218,130 +218,123 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
         }
     };
 
-    if (ntile > 0) { fetch(0); stash(0); }
-    __syncthreads();
-
     const unsigned char *qbase = sQz + (size_t)(32 * w + col) * stride + h * 16;
     const size_t slot = (size_t)c * a.Kcap + qpos;
     int *cand = a.cand + slot * kCandCap;
-    float *cand_lb = a.cand_lb + slot * kCandCap;
 
-    for (int t = 0; t < ntile; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntile) fetch(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
+    // Two sweeps over the bin's members.  Sweep 0 (base mode only) learns tau = m-th smallest upper
+    // bound; sweep 1 shortlists against that FINAL tau, so the list holds only the members whose
+    // error interval reaches below it (about m + a handful) instead of everything that passed a
+    // still-loose running threshold.  The matrix-core work is cheap enough to do twice.
+    for (int sweep = UPD ? 1 : 0; sweep < 2; ++sweep) {
+        __syncthreads();
+        if (ntile > 0) { fetch(0); stash(0); }
+        __syncthreads();
+        for (int t = 0; t < ntile; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < ntile) fetch(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
 
-        f32x16 acc;
+            f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + h * 16;
-        for (int s = 0; s < ksteps; ++s) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + s * 32);
-            const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(qbase + s * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
-        }
-
-        // rows held by this lane: (r&3) + 8*(r>>2) + 4*h
-        float np[16];
-        float rt = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4 *>(&sPn[buf * kPfP + 8 * g + 4 * h]);
-            const float4 rr = *reinterpret_cast<const float4 *>(&sPr[buf * kPfP + 8 * g + 4 * h]);
-            np[4 * g + 0] = v.x; np[4 * g + 1] = v.y; np[4 * g + 2] = v.z; np[4 * g + 3] = v.w;
-            rt = fmaxf(rt, fmaxf(fmaxf(rr.x, rr.y), fmaxf(rr.z, rr.w)));
-        }
-        rt = fmaxf(rt, __shfl_xor(rt, 32, 64));
-        const float rsum = (rq + rt) * (1.0f + kSlack);
-        if (UPD) {
-            // a batch member counts for this query only on the right side of the visiting order
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int code = sPcode[buf * kPfP + (r & 3) + 8 * (r >> 2) + 4 * h];
-                bool ok = true;
-                if (code > 0) ok = qpos > code - 1;
-                else if (code <= -(1 << 30)) ok = qpos != -(1 << 30) - code;
-                else if (code < 0) ok = qpos < -code - 1;
-                if (!ok) np[r] = INFINITY;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + h * 16;
+            for (int s = 0; s < ksteps; ++s) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + s * 32);
+                const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(qbase + s * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
             }
-        }
 
-        float u[16];
+            // rows held by this lane: (r&3) + 8*(r>>2) + 4*h
+            float np[16];
+            float rt = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = fmaf(-2.0f, acc[r], np[r]);
-
-        // (1) tighten tau with this tile: members whose UB' = sqrt(s + E) + rho_j + rho_tile < tau
-        float C1 = FLT_MAX;
-        if (tau < INFINITY) {
-            const float lo = tau - rsum;
-            C1 = lo > 0.f ? lo * lo * (1.0f - 4.0f * kSlack) - nj_hi : -FLT_MAX;
-        }
-        bool ins = false;
-        if (!UPD) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float t1 = fmaf(kGamma, np[r], u[r]);
-            if (t1 < C1) {
-                const float ubv = sqrtf(fmaxf(t1 + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
-                list_insert<ML>(ub, ubv);
-                ins = true;
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = *reinterpret_cast<const float4 *>(&sPn[buf * kPfP + 8 * g + 4 * h]);
+                const float4 rr = *reinterpret_cast<const float4 *>(&sPr[buf * kPfP + 8 * g + 4 * h]);
+                np[4 * g + 0] = v.x; np[4 * g + 1] = v.y; np[4 * g + 2] = v.z; np[4 * g + 3] = v.w;
+                rt = fmaxf(rt, fmaxf(fmaxf(rr.x, rr.y), fmaxf(rr.z, rr.w)));
             }
-        }
-        if (__any(ins)) {
-            float mg[ML];
+            rt = fmaxf(rt, __shfl_xor(rt, 32, 64));
+            const float rsum = (rq + rt) * (1.0f + kSlack);
+            if (UPD) {
+                // a batch member counts for this query only on the right side of the visiting order
 #pragma unroll
-            for (int i = 0; i < ML; ++i) mg[i] = ub[i];
-#pragma unroll
-            for (int i = 0; i < ML; ++i) list_insert<ML>(mg, __shfl_xor(ub[i], 32, 64));
-#pragma unroll
-            for (int i = 0; i < ML; ++i)
-                if (i == m - 1) tau = mg[i];
-        }
-        }
-
-        // (2) shortlist: LB' = sqrt(s - E) - rho_j - rho_tile <= tau
-        float C2 = FLT_MAX;
-        if (tau < INFINITY) {
-            const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
-            C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
-        }
-        unsigned mask = 0u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float t2 = fmaf(-kGamma, np[r], u[r]);
-            if (t2 <= C2) mask |= 1u << r;
-        }
-        const int cnt = __popc(mask);
-        const int pc = __shfl_xor(cnt, 32, 64);
-        int off = ccount + (h ? pc : 0);
-        ccount += cnt + pc;
-        if (qvalid && mask) {
-            // the lower bound travels with the candidate: the rescoring pass drops every candidate
-            // whose LB exceeds the FINAL tau (early tiles were admitted against a looser one)
-            float t2v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t2v[r] = fmaf(-kGamma, np[r], u[r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (mask & (1u << r)) {
-                    const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (off < kCandCap) {
-                        cand[off] = sPid[buf * kPfP + prow];
-                        if (!UPD) cand_lb[off] = sqrtf(fmaxf(t2v[r] + nj_lo, 0.f)) * (1.0f - 4.0f * kSlack) - rsum;
-                    }
-                    ++off;
+                for (int r = 0; r < 16; ++r) {
+                    const int code = sPcode[buf * kPfP + (r & 3) + 8 * (r >> 2) + 4 * h];
+                    bool ok = true;
+                    if (code > 0) ok = qpos > code - 1;
+                    else if (code <= -(1 << 30)) ok = qpos != -(1 << 30) - code;
+                    else if (code < 0) ok = qpos < -code - 1;
+                    if (!ok) np[r] = INFINITY;
                 }
             }
-        }
 
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntile) stash(buf ^ 1);
-        __syncthreads();
+            if (sweep == 0) {
+                // tighten tau: members whose UB' = sqrt(s + E) + rho_j + rho_tile < tau
+                float C1 = FLT_MAX;
+                if (tau < INFINITY) {
+                    const float lo = tau - rsum;
+                    C1 = lo > 0.f ? lo * lo * (1.0f - 4.0f * kSlack) - nj_hi : -FLT_MAX;
+                }
+                bool ins = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t1 = fmaf(kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
+                    if (t1 < C1) {
+                        const float ubv = sqrtf(fmaxf(t1 + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
+                        list_insert<ML>(ub, ubv);
+                        ins = true;
+                    }
+                }
+                if (__any(ins)) {
+                    float mg[ML];
+#pragma unroll
+                    for (int i = 0; i < ML; ++i) mg[i] = ub[i];
+#pragma unroll
+                    for (int i = 0; i < ML; ++i) list_insert<ML>(mg, __shfl_xor(ub[i], 32, 64));
+#pragma unroll
+                    for (int i = 0; i < ML; ++i)
+                        if (i == m - 1) tau = mg[i];
+                }
+            } else {
+                // shortlist: LB' = sqrt(s - E) - rho_j - rho_tile <= tau
+                float C2 = FLT_MAX;
+                if (tau < INFINITY) {
+                    const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+                    C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
+                }
+                unsigned mask = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t2 = fmaf(-kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
+                    if (t2 <= C2) mask |= 1u << r;
+                }
+                const int cnt = __popc(mask);
+                const int pc = __shfl_xor(cnt, 32, 64);
+                int off = ccount + (h ? pc : 0);
+                ccount += cnt + pc;
+                if (qvalid) {
+                    while (mask) {
+                        const int r = __ffs(mask) - 1;
+                        mask &= mask - 1u;
+                        const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (off < kCandCap) cand[off] = sPid[buf * kPfP + prow];
+                        ++off;
+                    }
+                }
+            }
+
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < ntile) stash(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     if (qvalid && h == 0) {
         a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
-        if (!UPD) a.cand_tau[slot] = tau < INFINITY ? tau * (1.0f + 4.0f * kSlack) : INFINITY;
+        if (UPD && ccount > 0 && a.active != nullptr)
+            a.active[atomicAdd(a.n_active, 1)] = (qpos - a.pos_begin) * a.B + c;
         if (ccount > kCandCap) {
             atomicAdd(a.overflow, 1);
             flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;

@@ -267,25 +267,33 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
 }
 
 // Stage 2 of the two-stage selection: exact distances on the shortlist of one (position, bin)
-// pair per half-wavefront, one candidate per lane.  Each lane must add its row's squared
-// differences strictly in feature order (cdist rounding), so lanes cannot split a row; instead
-// the wavefront fetches 16-feature chunks of its 64 candidate rows with coalesced 128-byte
-// segments (8 lanes per row) into a private LDS slab, and every lane then walks its own row there
-// (row stride 18 doubles: conflict-free ds_read_b128).  No barriers: the slab is per wavefront.
-// Then the same (distance, index) top-m list as the brute-force kernel, optionally seeded with an
-// existing list (`in`).
+// pair per 16-lane group (4 pairs per wavefront), one candidate per lane.  Each lane must add its
+// row's squared differences strictly in feature order (cdist rounding), so lanes cannot split a
+// row; instead the wavefront fetches 16-feature chunks of its 64 candidate rows with coalesced
+// 128-byte segments (8 lanes per row) into a private LDS slab, and every lane then walks its own
+// row there (row stride 18 doubles: conflict-free ds_read_b128).  No barriers: the slab is per
+// wavefront; the next chunk's loads are in flight during the arithmetic.  Then the same
+// (distance, index) top-m list as the brute-force kernel, optionally seeded with a list (`in`).
 constexpr int kRsChunk = 16;
 constexpr int kRsStride = 18;
 
 __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a, int npairs)
 {
-    __shared__ __attribute__((aligned(16))) double slab[4][66][kRsStride];
-    __shared__ int surv[4][2][kCandCap];
+    __shared__ __attribute__((aligned(16))) double slab[4][68][kRsStride];
 
-    const int lane = threadIdx.x & 63, hl = lane & 31, hbase = lane & 32, w = threadIdx.x >> 6;
-    const int half = lane >> 5;
-    const int pair = ((int)blockIdx.x * 4 + w) * 2 + half;
-    const bool pvalid = pair < npairs;
+    const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48, w = threadIdx.x >> 6;
+    const int grp = lane >> 4;
+    int gidx = ((int)blockIdx.x * 4 + w) * 4 + grp;
+    int pair = gidx;
+    bool pvalid;
+    if (a.active != nullptr) {
+        const int na = *a.n_active;
+        pvalid = gidx < na;
+        pair = pvalid ? a.active[gidx] : 0;
+        if (__builtin_amdgcn_readfirstlane(((int)blockIdx.x * 4 + w) * 4) >= na) return;
+    } else {
+        pvalid = gidx < npairs;
+    }
     int pos = a.pos_begin, c = 0, cnt = 0;
     if (pvalid) {
         pos = a.pos_begin + pair / a.B;
@@ -300,50 +308,26 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a, int npairs)
     int li = INT_MAX, lc = 0;
     if (pvalid && a.in.d != nullptr) {
         lc = a.in.cnt[slot];
-        if (hl < lc) { ld = a.in.d[slot * m + hl]; li = a.in.idx[slot * m + hl]; }
+        if (gl < lc) { ld = a.in.d[slot * m + gl]; li = a.in.idx[slot * m + gl]; }
         if (lc >= m) tau = tau_from(a.in.d[slot * m + m - 1]);
     }
 
-    // keep only candidates whose lower bound is within the final tau of the shortlist stage
-    // (early tiles were admitted against a looser running tau); compact them per half-wavefront
-    int nsurv = 0;
-    {
-        const float tfin = (pvalid && a.cand_tau) ? a.cand_tau[slot] : __builtin_huge_valf();
-        int cmax0 = cnt;
-        cmax0 = max(cmax0, __shfl_xor(cmax0, 32, 64));
-        cmax0 = __builtin_amdgcn_readfirstlane(cmax0);
-        for (int base = 0; base < cmax0; base += 32) {
-            const int ci = base + hl;
-            bool keep = ci < cnt;
-            int id = 0;
-            if (keep) {
-                id = a.cand[slot * kCandCap + ci];
-                if (a.cand_lb) keep = a.cand_lb[slot * kCandCap + ci] <= tfin;
-            }
-            const unsigned long long bal = __ballot(keep);
-            const unsigned int mine = (unsigned int)(bal >> hbase);
-            const int before = __popc(mine & ((1u << hl) - 1u));
-            if (keep) surv[w][half][nsurv + before] = id;
-            nsurv += __popc(mine);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    int cmax = nsurv;
+    int cmax = cnt;
+    cmax = max(cmax, __shfl_xor(cmax, 16, 64));
     cmax = max(cmax, __shfl_xor(cmax, 32, 64));
     cmax = __builtin_amdgcn_readfirstlane(cmax);
     const int srow = lane >> 3, spc = lane & 7;   // staging role: row srow + 8 i, 16-byte piece spc
     const int nchunks = (a.Dp + kRsChunk - 1) / kRsChunk;
-    for (int base = 0; base < cmax; base += 32) {
-        const int ci = base + hl;
-        const bool have = ci < nsurv;
-        const int id = have ? surv[w][half][ci] : qid;
+    // lanes with srow 0..3 also stage the query row of 16-lane group srow
+    const int qsel = __shfl(qid, (srow & 3) * 16, 64);
+    const double *qp = a.X + (size_t)qsel * a.Dp + 2 * spc;
+    for (int base = 0; base < cmax; base += 16) {
+        const int ci = base + gl;
+        const bool have = ci < cnt;
+        const int id = have ? a.cand[slot * kCandCap + ci] : qid;
         const double *rp[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) rp[i] = a.X + (size_t)__shfl(id, srow + 8 * i, 64) * a.Dp + 2 * spc;
-        // lanes with srow 0 / 1 also stage the query row of the lower / upper half-wavefront
-        const int q0 = __shfl(qid, 0, 64), q1 = __shfl(qid, 32, 64);
-        const double *qp = a.X + (size_t)(srow == 0 ? q0 : q1) * a.Dp + 2 * spc;
         double sacc = 0.0;
         double2 v[8], qv;
         auto fetch = [&](int ch) {
@@ -353,19 +337,19 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a, int npairs)
             for (int i = 0; i < 8; ++i)
                 v[i] = kin ? *reinterpret_cast<const double2 *>(rp[i] + k0) : double2{0.0, 0.0};
             qv = double2{0.0, 0.0};
-            if (srow < 2 && kin) qv = *reinterpret_cast<const double2 *>(qp + k0);
+            if (srow < 4 && kin) qv = *reinterpret_cast<const double2 *>(qp + k0);
         };
         fetch(0);
         for (int ch = 0; ch < nchunks; ++ch) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 *reinterpret_cast<double2 *>(&slab[w][srow + 8 * i][2 * spc]) = v[i];
-            if (srow < 2) *reinterpret_cast<double2 *>(&slab[w][64 + srow][2 * spc]) = qv;
+            if (srow < 4) *reinterpret_cast<double2 *>(&slab[w][64 + srow][2 * spc]) = qv;
             __builtin_amdgcn_wave_barrier();
             if (ch + 1 < nchunks) fetch(ch + 1);   // next chunk's loads fly during the arithmetic
             __builtin_amdgcn_sched_barrier(0);
             const double *mine = &slab[w][lane][0];
-            const double *qrow = &slab[w][64 + half][0];
+            const double *qrow = &slab[w][64 + grp][0];
 #pragma unroll
             for (int k = 0; k < kRsChunk; k += 2) {
                 const double2 pv = *reinterpret_cast<const double2 *>(mine + k);
@@ -380,14 +364,14 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a, int npairs)
         }
         double s1[1] = {have ? sacc : kInf};
         const int id1[1] = {have ? id : INT_MAX};
-        select_into<32, 1>(s1, id1, ld, li, lc, tau, m, hl, hbase);
+        select_into<16, 1>(s1, id1, ld, li, lc, tau, m, gl, gbase);
     }
     if (pvalid) {
-        if (hl < m) {
-            a.out.d[slot * m + hl] = hl < lc ? ld : kInf;
-            a.out.idx[slot * m + hl] = hl < lc ? li : -1;
+        if (gl < m) {
+            a.out.d[slot * m + gl] = gl < lc ? ld : kInf;
+            a.out.idx[slot * m + gl] = gl < lc ? li : -1;
         }
-        if (hl == 0) a.out.cnt[slot] = lc;
+        if (gl == 0) a.out.cnt[slot] = lc;
     }
 }
 
@@ -419,7 +403,7 @@ void launch_rescore(const RescoreArgs &a, hipStream_t s)
 {
     const int npairs = (a.pos_end - a.pos_begin) * a.B;
     if (npairs <= 0) return;
-    const int grid = (npairs + 7) / 8;
+    const int grid = (npairs + 15) / 16;
     hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(256), 0, s, a, npairs);
 }
 
