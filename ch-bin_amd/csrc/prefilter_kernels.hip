@@ -25,6 +25,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace chb {
 namespace {
@@ -115,13 +116,16 @@ __device__ __forceinline__ void list_insert(float (&l)[ML], float v)
 // UPD = true : the batch's own members (eligibility code per member, see aux_kernels.hip) against a
 //              FIXED tau = the exact m-th distance of the already known list `seed`; members that
 //              cannot displace a list entry are dropped without ever touching fp64.
-template <int ML, bool UPD>
+// QREG = true : the query fragments (B operand) live in registers for the whole kernel (Dz <= 160);
+//               LDS then only holds the double-buffered member tile, so 6-8 workgroups fit a CU.
+template <int ML, bool UPD, bool QREG>
 __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
                                                         int stride, int *flags64, int nqt64)
 {
+    constexpr int KSMAX = 10;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sQz = smem;                               // [kPfQ][stride]
-    unsigned char *sPz = sQz + (size_t)kPfQ * stride;        // [2][kPfP][stride]
+    unsigned char *sQz = smem;                               // [kPfQ][stride] (absent when QREG)
+    unsigned char *sPz = sQz + (QREG ? 0 : (size_t)kPfQ * stride);   // [2][kPfP][stride]
     float *sPn = reinterpret_cast<float *>(sPz + (size_t)2 * kPfP * stride);  // [2][kPfP]
     float *sPr = sPn + 2 * kPfP;                             // [2][kPfP]
     int *sPid = reinterpret_cast<int *>(sPr + 2 * kPfP);     // [2][kPfP]
@@ -151,13 +155,22 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
     const float nj_hi = nj * (1.0f + kGamma) * (1.0f + kSlack);
     const float nj_lo = nj * (1.0f - kGamma) * (1.0f - kSlack);
 
-    // stage the 128 query rows
-    for (int ch = tid; ch < kPfQ * cpr; ch += 256) {
-        const int r = ch / cpr, cc = ch - r * cpr;
-        int sp = pos0 + r;
-        if (sp >= a.pos_end) sp = a.pos_end - 1;
-        const uint4 v = *reinterpret_cast<const uint4 *>(a.sh.Z + (size_t)a.bq[sp] * Dz + cc * 8);
-        *reinterpret_cast<uint4 *>(sQz + (size_t)r * stride + cc * 16) = v;
+    bf16x8 qreg[KSMAX];
+    if (QREG) {
+        // lane (col, h) owns B[k = 16 s + 8 h + j][col]: 16 bytes of its query row per k-step
+#pragma unroll
+        for (int sx = 0; sx < KSMAX; ++sx)
+            if (sx < ksteps)
+                qreg[sx] = *reinterpret_cast<const bf16x8 *>(a.sh.Z + (size_t)qid * Dz + sx * 16 + h * 8);
+    } else {
+        // stage the 128 query rows
+        for (int ch = tid; ch < kPfQ * cpr; ch += 256) {
+            const int r = ch / cpr, cc = ch - r * cpr;
+            int sp = pos0 + r;
+            if (sp >= a.pos_end) sp = a.pos_end - 1;
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.sh.Z + (size_t)a.bq[sp] * Dz + cc * 8);
+            *reinterpret_cast<uint4 *>(sQz + (size_t)r * stride + cc * 16) = v;
+        }
     }
 
     float ub[ML];
@@ -175,22 +188,36 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
 
     const int ntile = (nmem + kPfP - 1) / kPfP;
     const int nchunk = kPfP * cpr;      // chunks per member tile (<= 4 per thread for Dz <= 256)
-    uint4 st[4];
+    // staging registers: up to 4 16-byte chunks per thread (Dz <= 256), kept in named scalars so
+    // that nothing is spilled to scratch
+    uint4 st0 = {0, 0, 0, 0}, st1 = st0, st2 = st0, st3 = st0;
     float st_n = INFINITY, st_r = 0.f;
     int st_id = -1, st_code = 0;
-    auto fetch = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = tid + 256 * i;
-            if (ch < nchunk) {
-                const int r = ch / cpr, cc = ch - r * cpr;
-                const int e = t * kPfP + r;
-                const int id = e < nmem ? a.memb_id[mb + e] : 0;
-                st[i] = *reinterpret_cast<const uint4 *>(a.sh.Z + (size_t)id * Dz + cc * 8);
-            }
-        }
+#define CHB_PF_FETCH_ONE(I, ST)                                                                   \
+    {                                                                                              \
+        const int ch = tid + 256 * (I);                                                            \
+        if (ch < nchunk) {                                                                         \
+            const int r = ch / cpr, cc = ch - r * cpr;                                             \
+            const int e = tt * kPfP + r;                                                           \
+            const int id = e < nmem ? a.memb_id[mb + e] : 0;                                       \
+            ST = *reinterpret_cast<const uint4 *>(a.sh.Z + (size_t)id * Dz + cc * 8);             \
+        }                                                                                          \
+    }
+#define CHB_PF_STASH_ONE(I, ST)                                                                   \
+    {                                                                                              \
+        const int ch = tid + 256 * (I);                                                            \
+        if (ch < nchunk) {                                                                         \
+            const int r = ch / cpr, cc = ch - r * cpr;                                             \
+            *reinterpret_cast<uint4 *>(sPz + ((size_t)bb * kPfP + r) * stride + cc * 16) = ST;     \
+        }                                                                                          \
+    }
+    auto fetch = [&](int tt) {
+        CHB_PF_FETCH_ONE(0, st0)
+        CHB_PF_FETCH_ONE(1, st1)
+        CHB_PF_FETCH_ONE(2, st2)
+        CHB_PF_FETCH_ONE(3, st3)
         if (tid < kPfP) {
-            const int e = t * kPfP + tid;
+            const int e = tt * kPfP + tid;
             if (e < nmem) {
                 st_id = a.memb_id[mb + e];
                 st_n = a.sh.nrm[st_id];
@@ -201,22 +228,20 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
             }
         }
     };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = tid + 256 * i;
-            if (ch < nchunk) {
-                const int r = ch / cpr, cc = ch - r * cpr;
-                *reinterpret_cast<uint4 *>(sPz + ((size_t)buf * kPfP + r) * stride + cc * 16) = st[i];
-            }
-        }
+    auto stash = [&](int bb) {
+        CHB_PF_STASH_ONE(0, st0)
+        CHB_PF_STASH_ONE(1, st1)
+        CHB_PF_STASH_ONE(2, st2)
+        CHB_PF_STASH_ONE(3, st3)
         if (tid < kPfP) {
-            sPn[buf * kPfP + tid] = st_n;
-            sPr[buf * kPfP + tid] = st_r;
-            sPid[buf * kPfP + tid] = st_id;
-            sPcode[buf * kPfP + tid] = st_code;
+            sPn[bb * kPfP + tid] = st_n;
+            sPr[bb * kPfP + tid] = st_r;
+            sPid[bb * kPfP + tid] = st_id;
+            sPcode[bb * kPfP + tid] = st_code;
         }
     };
+#undef CHB_PF_FETCH_ONE
+#undef CHB_PF_STASH_ONE
 
     const unsigned char *qbase = sQz + (size_t)(32 * w + col) * stride + h * 16;
     const size_t slot = (size_t)c * a.Kcap + qpos;
@@ -239,10 +264,19 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + h * 16;
-            for (int s = 0; s < ksteps; ++s) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + s * 32);
-                const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(qbase + s * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+            if (QREG) {
+#pragma unroll
+                for (int sx = 0; sx < KSMAX; ++sx)
+                    if (sx < ksteps) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + sx * 32);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qreg[sx], acc, 0, 0, 0);
+                    }
+            } else {
+                for (int sx = 0; sx < ksteps; ++sx) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + sx * 32);
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(qbase + sx * 32);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+                }
             }
 
             // rows held by this lane: (r&3) + 8*(r>>2) + 4*h
@@ -361,24 +395,40 @@ void launch_build_shadow(const double *X, int N, int D, int Dp, const double *co
     hipLaunchKernelGGL(build_shadow_kernel, dim3(N), dim3(64), 0, s, X, N, D, Dp, colmean, Z, Dz, nrm, rho);
 }
 
+static bool use_qreg(int Dz)
+{
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("CHB_PF_QREG"); env = e ? atoi(e) : 1; }
+    return env != 0 && Dz <= 160;   // queries in registers up to 10 k-steps
+}
+
 size_t prefilter_lds_bytes(int Dz)
 {
     const int stride = Dz * 2 + 16;
-    return (size_t)(kPfQ + 2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4 + 4);
+    const int qrows = use_qreg(Dz) ? 0 : kPfQ;
+    return (size_t)(qrows + 2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4 + 4);
+}
+
+template <int ML, bool UPD, bool QREG>
+static void launch_pf2(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
+                       int *flags64, int nqt64, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)prefilter_kernel<ML, UPD, QREG>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((prefilter_kernel<ML, UPD, QREG>), dim3(grid), dim3(256), lds, s, a, nqt, total,
+                       stride, flags64, nqt64);
 }
 
 template <int ML, bool UPD>
 static void launch_pf(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
                       int *flags64, int nqt64, hipStream_t s)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)prefilter_kernel<ML, UPD>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((prefilter_kernel<ML, UPD>), dim3(grid), dim3(256), lds, s, a, nqt, total, stride,
-                       flags64, nqt64);
+    if (use_qreg(a.sh.Dz)) launch_pf2<ML, UPD, true>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
+    else launch_pf2<ML, UPD, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
 }
 
 void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s)
