@@ -230,22 +230,29 @@ __global__ __launch_bounds__(64 * WAVES) void hull_qp_kernel(QpArgs a, int nprob
             }
         }
         const bool live = valid && rv < n;
-        const double *vptr = a.X + (size_t)id * a.Dp + kq;
-        const double *qptr = a.X + (size_t)qid * a.Dp + kq;
+        // The Gram sum over features is order-free, so feature k is assigned to MFMA step / k-slot
+        // as k = 16 t + 4 kq + s: every lane then reads 32 contiguous bytes per 4 steps and the 4
+        // lanes of a row cover one full 128-byte line.
+        const double *vptr = a.X + (size_t)id * a.Dp + 4 * kq;
+        const double *qptr = a.X + (size_t)qid * a.Dp + 4 * kq;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < a.Dp; k0 += 32) {
-            double v[8], x[8];
+            double2 v[4], x[4];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int kk = k0 + 4 * s;
-                const bool in = live && kk < a.Dp;
-                v[s] = in ? vptr[kk] : 0.0;
-                x[s] = in ? qptr[kk] : 0.0;
+            for (int t = 0; t < 2; ++t) {
+                const int kk = k0 + 16 * t + 4 * kq;
+                const bool in = live && kk < a.Dp;   // Dp % 8 == 0 and kk % 4 == 0: all 4 in range
+                v[2 * t] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t) : double2{0.0, 0.0};
+                v[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
+                x[2 * t] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t) : double2{0.0, 0.0};
+                x[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
             }
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const double y = v[s] - x[s];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                const double y0 = v[s].x - x[s].x;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, acc, 0, 0, 0);
+                const double y1 = v[s].y - x[s].y;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, acc, 0, 0, 0);
             }
         }
         // lane holds D[kq + 4r][row]; keep the lower triangles of the diagonal blocks
