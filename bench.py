@@ -194,7 +194,7 @@ def main():
                                    f"AlgoNumNeighbors={m}, one full fit_cluster sweep from the seed "
                                    "state per step (exact sequential label semantics)",
                        "n_contigs": N, "dim": D, "bins": B, "neighbors": m, "movable": int(n_move),
-                       "qp_per_step": int(qp_per_step), "batch": args.batch or 4096,
+                       "qp_per_step": int(qp_per_step), "batch": args.batch or 8192,
                        "parallelism": f"contig-sharded x{world}" if use_dist else "single GPU"},
             "roofline": roofline,
             "kernels": kern,

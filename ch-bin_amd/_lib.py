@@ -49,6 +49,7 @@ SIGNATURES = {
                                   C.c_int, _i64p, C.POINTER(C.c_int), _i64p, C.c_void_p]),
     "chb_fit_begin": (C.c_int, [C.c_void_p, C.c_int64, _i64p, C.c_int]),
     "chb_batch_begin": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_int64, C.c_int64]),
+    "chb_batch_guess": (C.c_int, [C.c_void_p, _i64p]),
     "chb_batch_round": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _i64p, C.c_void_p]),
     "chb_batch_commit": (C.c_int, [C.c_void_p, _i64p]),
     "chb_fit_labels": (C.c_int, [C.c_void_p, _i64p]),
@@ -203,6 +204,9 @@ class Context:
     def batch_begin(self, perm_slice, q_lo, q_hi):
         p = np.ascontiguousarray(perm_slice, dtype=np.int64)
         check(self._lib.chb_batch_begin(self._h, p, p.shape[0], int(q_lo), int(q_hi)))
+
+    def batch_guess(self, guess):
+        check(self._lib.chb_batch_guess(self._h, guess))
 
     def batch_round(self, lab_prev, active, lab_new, min_dist=None):
         check(self._lib.chb_batch_round(self._h, np.ascontiguousarray(lab_prev, dtype=np.int64),

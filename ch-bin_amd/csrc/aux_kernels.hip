@@ -132,10 +132,10 @@ __global__ void argmin_kernel(const double *dist, const int *lab_old, const int 
 // First-round label guess for batch members that carry no label yet (sweep 1): the bin of the
 // single nearest outside member.  Only a guess -- the rounds converge to the exact sequential
 // labels from any starting point; a good guess just saves a round.
-__global__ void guess_kernel(const double *list_d, const int *list_cnt, const int *lab_old, int K,
-                             int B, int m, int Kcap, int *lab_prev)
+__global__ void guess_kernel(const double *list_d, const int *list_cnt, const int *lab_old, int p0,
+                             int K, int B, int m, int Kcap, int *lab_prev)
 {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pos = p0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= K) return;
     int g = lab_old[pos];
     if (g < 0) {
@@ -197,11 +197,11 @@ __global__ __launch_bounds__(256) void select_row_kernel(const int *labels, cons
 
 }  // namespace
 
-void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old, int K, int B,
-                  int m, int Kcap, int *lab_prev, hipStream_t s)
+void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old, int p0, int p1,
+                  int B, int m, int Kcap, int *lab_prev, hipStream_t s)
 {
-    if (K > 0)
-        hipLaunchKernelGGL(guess_kernel, dim3((K + 127) / 128), dim3(128), 0, s, list_d, list_cnt, lab_old, K, B, m, Kcap, lab_prev);
+    if (p1 > p0)
+        hipLaunchKernelGGL(guess_kernel, dim3((p1 - p0 + 127) / 128), dim3(128), 0, s, list_d, list_cnt, lab_old, p0, p1, B, m, Kcap, lab_prev);
 }
 
 void launch_select_row(const int *labels, const double *row, int N, int c, int m, int *out_idx,

@@ -543,6 +543,22 @@ int chb_batch_round(chb_ctx *h, const int64_t *lab_prev, int64_t active, int64_t
     return CHB_OK;
 }
 
+int chb_batch_guess(chb_ctx *h, int64_t *guess)
+{
+    if (!h || !guess) return fail(CHB_EINVAL, "null argument");
+    if (!h->batch_open) return fail(CHB_ESTATE, "no open batch");
+    HIPCHK(hipSetDevice(h->dev));
+    const int lo = h->q_lo, hi = h->q_hi;
+    if (hi <= lo) return CHB_OK;
+    launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, lo, hi, h->B, h->m, h->Kcap, h->lab_prev.p, h->stream);
+    HIPCHK(hipGetLastError());
+    std::vector<int> g((size_t)(hi - lo));
+    HIPCHK(hipMemcpyAsync(g.data(), h->lab_prev.p + lo, sizeof(int) * (hi - lo), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = lo; i < hi; ++i) guess[i] = g[(size_t)(i - lo)];
+    return CHB_OK;
+}
+
 int chb_batch_commit(chb_ctx *h, const int64_t *final_labels)
 {
     if (!h || !final_labels) return fail(CHB_EINVAL, "null argument");
@@ -581,7 +597,7 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
     const int64_t N = h->N;
     for (int64_t i = 0; i < (int64_t)max_iter * n_move; ++i)
         if (perms[i] < 0 || perms[i] >= N) return fail(CHB_EINVAL, "perm entry out of range");
-    int Kmax = batch > 0 ? batch : 4096;
+    int Kmax = batch > 0 ? batch : 8192;
     if (Kmax > n_move) Kmax = (int)std::max<int64_t>(n_move, 1);
     rc = ensure_batch_buffers(h, Kmax);
     if (rc) return rc;
@@ -619,7 +635,7 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
             if (rc) return rc;
             // starting labels of the rounds: last sweep's label, or for still-unlabelled contigs
             // (sweep 1) the bin of the nearest outside member
-            launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, K, h->B, h->m, h->Kcap, h->lab_prev.p, s);
+            launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, 0, K, h->B, h->m, h->Kcap, h->lab_prev.p, s);
             int active = 0;
             for (;;) {
                 int f = K;

@@ -118,8 +118,8 @@ void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code,
                          hipStream_t s);
 // round-0 label guess: lab_old where >= 0, else bin of the nearest outside member
-void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old, int K, int B,
-                  int m, int Kcap, int *lab_prev, hipStream_t s);
+void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old, int p0, int p1,
+                  int B, int m, int Kcap, int *lab_prev, hipStream_t s);
 // select up to m smallest (row[p], p) among labels[p] == c; one workgroup
 void launch_select_row(const int *labels, const double *row, int N, int c, int m, int *out_idx,
                        int *out_cnt, hipStream_t s);

@@ -28,7 +28,7 @@ def batch_schedule(n_move, batch, members0, first_sweep):
     """Batch sizes for one sweep.  Any partition gives the same labels; in sweep 1 a batch is not
     allowed to outnumber the members labelled so far (keeps speculation rounds few)."""
     out, t0 = [], 0
-    kmax = max(1, min(int(batch) if batch and batch > 0 else 4096, max(n_move, 1)))
+    kmax = max(1, min(int(batch) if batch and batch > 0 else 8192, max(n_move, 1)))
     while t0 < n_move:
         members = members0 + t0 if first_sweep else 1 << 62
         K = min(kmax, n_move - t0)
@@ -39,7 +39,7 @@ def batch_schedule(n_move, batch, members0, first_sweep):
     return out
 
 
-def _sweeps(n, B, initial, perms, max_iter, batch, open_batch, evaluate, commit):
+def _sweeps(n, B, initial, perms, max_iter, batch, open_batch, evaluate, commit, guess=None):
     """Shared control flow (mirrors csrc/chb_api.hip:chb_fit_cluster)."""
     initial = np.ascontiguousarray(initial, dtype=np.int64)
     perms = np.ascontiguousarray(perms, dtype=np.int64).reshape(max_iter, -1)
@@ -54,6 +54,8 @@ def _sweeps(n, B, initial, perms, max_iter, batch, open_batch, evaluate, commit)
             sl = perms[it, t0:t0 + K]
             open_batch(sl)
             lab_prev = labels[sl].copy()
+            if guess is not None:
+                lab_prev = guess(lab_prev)           # only a starting point: any start is exact
             active = 0
             while True:
                 lab_new = evaluate(lab_prev, active)
@@ -106,7 +108,14 @@ def run_sweeps(backends, X, B, initial, perms, m, max_iter, batch=0):
         for b in backends:
             b.batch_commit(final)
 
-    return _sweeps(len(X), B, initial, perms, max_iter, batch, open_batch, evaluate, commit)
+    def guess(lab_old):
+        g = lab_old.copy()
+        for b in backends:
+            if hasattr(b, "batch_guess"):
+                b.batch_guess(g)                 # each backend fills its own slice
+        return g
+
+    return _sweeps(len(X), B, initial, perms, max_iter, batch, open_batch, evaluate, commit, guess)
 
 
 def fit_cluster_distributed(backend, X, B, initial, perms, m, max_iter, batch=0, group=None,
@@ -120,7 +129,7 @@ def fit_cluster_distributed(backend, X, B, initial, perms, m, max_iter, batch=0,
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     X = np.ascontiguousarray(X, dtype=np.float64)
-    backend.set_samples(X)
+    getattr(backend, "set_samples_cached", backend.set_samples)(X)   # resident copy is reused
     backend.fit_begin(int(B), initial, int(m))
     state = {}
 
@@ -134,23 +143,33 @@ def fit_cluster_distributed(backend, X, B, initial, perms, m, max_iter, batch=0,
         lo, hi = slice_bounds(K, world, rank)
         out = lab_prev.copy()
         backend.batch_round(lab_prev, active, out, None)
-        contrib = np.zeros(K, dtype=np.int64)
-        lo = max(lo, active)
-        if hi > lo:
-            contrib[lo:hi] = out[lo:hi] + 1          # shift so that "not mine" == 0
-        t = torch.from_numpy(contrib)
-        if device is not None:
-            t = t.to(device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        merged = t.cpu().numpy() - 1
+        merged = _merge(out, max(lo, active), hi)
         merged[:active] = lab_prev[:active]
         return merged
 
     def commit(final):
         backend.batch_commit(final)
 
+    def _merge(arr, lo, hi):
+        contrib = np.zeros(len(arr), dtype=np.int64)
+        if hi > lo:
+            contrib[lo:hi] = arr[lo:hi] + 1          # shift so that "not mine" == 0
+        t = torch.from_numpy(contrib)
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy() - 1
+
+    def guess(lab_old):
+        if not hasattr(backend, "batch_guess"):
+            return lab_old
+        g = lab_old.copy()
+        backend.batch_guess(g)
+        lo, hi = slice_bounds(state["K"], world, rank)
+        return _merge(g, lo, hi)
+
     labels, its, changed = _sweeps(len(X), B, initial, perms, max_iter, batch, open_batch, evaluate,
-                                   commit)
+                                   commit, guess)
     # algorithm.py:63-69 convergence statistics are identical on every rank by construction;
     # one tiny all_reduce(MAX) asserts the replicas did not diverge.
     chk = torch.tensor([int(labels.sum()), int(its)], dtype=torch.int64)

@@ -102,6 +102,10 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
 int chb_fit_begin(chb_ctx *h, int64_t B, const int64_t *initial_bins, int m);
 /* open a batch: perm_slice[K] are the contigs visited, in order */
 int chb_batch_begin(chb_ctx *h, const int64_t *perm_slice, int64_t K, int64_t q_lo, int64_t q_hi);
+/* optional: starting labels for the rounds of this batch, positions [q_lo,q_hi) of guess[K] --
+ * the contig's current label, or for a still unlabelled contig the bin of its nearest member
+ * outside the batch.  Any start gives the same final labels; a good one saves rounds. */
+int chb_batch_guess(chb_ctx *h, int64_t *guess);
 /* one speculative round: lab_prev[K] in; for positions [max(active,q_lo), q_hi) writes
  * lab_new[pos] and min_dist[pos] (arrays of length K, other entries untouched) */
 int chb_batch_round(chb_ctx *h, const int64_t *lab_prev, int64_t active, int64_t *lab_new,

@@ -388,3 +388,27 @@ def test_shortlist_stage_equals_brute_force(ctx, O, kind):
         for c in range(B):
             want_idx = O.find_nearest_from_cluster(c, cur, row, m)
             assert np.array_equal(got[0][qi, c, :len(want_idx)], want_idx)
+
+
+# ------------------------------------------------------------------ clustering-stage driver (8f-1)
+
+def test_cli_perform_clustering_matches_oracle(ctx, O, tmp_path, golden_dir, monkeypatch):
+    """BASELINE configs[0] plumbing: the reference's own contig names / coverages
+    (five-genomes-abundance.abund) + synthetic k-mer profiles -> features.csv -> HIP fit ->
+    binning-assignment.csv, identical to the same driver with the oracle's fit injected."""
+    import sys
+    import pandas as pd
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_cli_cpu import make_features_csv, oracle_fit
+    from chbin_amd import cli_clustering
+    feats = tmp_path / "features.csv"
+    make_features_csv(feats, golden_dir)
+    np.random.seed(0)
+    out_gpu = cli_clustering.perform_clustering(None, feats, tmp_path / "gpu", num_neighbors=5,
+                                                max_iterations=6)
+    monkeypatch.setattr(cli_clustering, "fit_cluster", oracle_fit)
+    np.random.seed(0)
+    out_cpu = cli_clustering.perform_clustering(None, feats, tmp_path / "cpu", num_neighbors=5,
+                                                max_iterations=6)
+    assert open(out_gpu).read() == open(out_cpu).read()
+    assert len(pd.read_csv(out_gpu)) == 120
