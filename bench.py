@@ -34,13 +34,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100_000)
+    ap.add_argument("--contigs", type=int, default=100_000)
     ap.add_argument("--dim", type=int, default=136)
     ap.add_argument("--bins", type=int, default=64)
     ap.add_argument("--neighbors", type=int, default=5)      # config/default.ini:16
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=300)
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (dev: gloo)")
+    ap.add_argument("--same-gpu", action="store_true", help="dev only: all ranks on cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -52,6 +54,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_gpu:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -60,12 +64,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    xdev = dev if args.backend == "nccl" else None      # where exchanged tensors live
 
-    N, D, B, m = args.n, args.dim, args.bins, args.neighbors
+    N, D, B, m = args.contigs, args.dim, args.bins, args.neighbors
     S = 1 if D <= 136 else (5 if D == 140 else 10)
     X, initial, true = synth.make_synthetic(N, D, B, S=S, seed=0)
     perms = synth.draw_permutations(initial, 10, seed=0)     # np.random.seed(0): ch_bin.py:22
@@ -75,10 +83,25 @@ def main():
     ctx = _lib.Context(local_rank)
     ctx.set_samples(X)                                        # resident in HBM before timing
 
+    # N > 1: contigs of every batch sharded across the ranks inside the C++ loop, label slices
+    # exchanged with RCCL all-gathers; if the native communicator cannot be created the Python
+    # driver (torch.distributed all_reduce between rounds) is used instead.
+    native = False
+    if use_dist:
+        try:
+            cdist_mod.init_native_comm(ctx, device=xdev)
+            native = True
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"native RCCL communicator unavailable ({e}); using the Python driver", file=sys.stderr)
+        flag = torch.tensor([1 if native else 0], device=xdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native = bool(flag.item())
+
     def one_step():
-        if use_dist:
+        if use_dist and not native:
             return cdist_mod.fit_cluster_distributed(ctx, X, B, initial, perms[:1], m, 1,
-                                                     batch=args.batch, device=dev)[0]
+                                                     batch=args.batch, device=xdev)[0]
         return ctx.fit_cluster(B, initial, perms[:1], m, 1, batch=args.batch)[0]
 
     def sync():
@@ -98,7 +121,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / max(args.steps, 1) * 1e3
@@ -195,7 +218,7 @@ def main():
                                    "state per step (exact sequential label semantics)",
                        "n_contigs": N, "dim": D, "bins": B, "neighbors": m, "movable": int(n_move),
                        "qp_per_step": int(qp_per_step), "batch": args.batch or 8192,
-                       "parallelism": f"contig-sharded x{world}" if use_dist else "single GPU"},
+                       "parallelism": (f"contig-sharded x{world}, " + ("RCCL all-gather in the C++ loop" if native else "torch.distributed all_reduce")) if use_dist else "single GPU"},
             "roofline": roofline,
             "kernels": kern,
             "cpu_baseline": cpu,

@@ -53,6 +53,9 @@ SIGNATURES = {
     "chb_batch_round": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _i64p, C.c_void_p]),
     "chb_batch_commit": (C.c_int, [C.c_void_p, _i64p]),
     "chb_fit_labels": (C.c_int, [C.c_void_p, _i64p]),
+    "chb_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "chb_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "chb_comm_destroy": (C.c_int, [C.c_void_p]),
     "chb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "chb_profile_reset": (C.c_int, [C.c_void_p]),
     "chb_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
@@ -220,6 +223,20 @@ class Context:
         out = np.empty(self.N, dtype=np.int64)
         check(self._lib.chb_fit_labels(self._h, out))
         return out
+
+    # multi-GPU (RCCL inside chb_fit_cluster)
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        check(load().chb_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        check(self._lib.chb_comm_init(self._h, C.c_char_p(unique_id), int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_destroy(self):
+        check(self._lib.chb_comm_destroy(self._h))
 
     # measurement
     def profile_enable(self, on=True):

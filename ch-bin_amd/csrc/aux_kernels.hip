@@ -129,6 +129,12 @@ __global__ void argmin_kernel(const double *dist, const int *lab_old, const int 
     if (bc != lab_prev[pos]) atomicMin(first_change, pos);
 }
 
+__global__ void first_change_kernel(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change)
+{
+    const int pos = p0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < K && lab_new[pos] != lab_prev[pos]) atomicMin(first_change, pos);
+}
+
 // First-round label guess for batch members that carry no label yet (sweep 1): the bin of the
 // single nearest outside member.  Only a guess -- the rounds converge to the exact sequential
 // labels from any starting point; a good guess just saves a round.
@@ -202,6 +208,13 @@ void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old,
 {
     if (p1 > p0)
         hipLaunchKernelGGL(guess_kernel, dim3((p1 - p0 + 127) / 128), dim3(128), 0, s, list_d, list_cnt, lab_old, p0, p1, B, m, Kcap, lab_prev);
+}
+
+void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,
+                         hipStream_t s)
+{
+    if (K > p0)
+        hipLaunchKernelGGL(first_change_kernel, dim3((K - p0 + 255) / 256), dim3(256), 0, s, lab_new, lab_prev, p0, K, first_change);
 }
 
 void launch_select_row(const int *labels, const double *row, int N, int c, int m, int *out_idx,

@@ -18,6 +18,9 @@
 #include "chb_internal.h"
 #include "../../include/chbin_hip.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -38,6 +41,51 @@ int fail(int code, const std::string &msg)
     g_err = msg;
     return code;
 }
+
+// RCCL is resolved at run time (dlopen) so that the library neither forces a second copy of RCCL
+// into a process that already has one (PyTorch bundles its own) nor needs it for single-GPU use.
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+RcclApi *rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.ok ? &api : nullptr;
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);   // a copy already in the process
+        if (api.lib) break;
+    }
+    if (!api.lib)
+        for (const char *n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+    if (!api.lib) return nullptr;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+    return api.ok ? &api : nullptr;
+}
+
+#define NCCLCHK(expr)                                                                      \
+    do {                                                                                   \
+        ncclResult_t r_ = (expr);                                                          \
+        if (r_ != ncclSuccess)                                                             \
+            return fail(CHB_EHIP, std::string(#expr) + ": " + rccl()->GetErrorString(r_)); \
+    } while (0)
 
 #define HIPCHK(expr)                                                                       \
     do {                                                                                   \
@@ -114,6 +162,10 @@ struct chb_ctx {
     std::map<std::string, ProfEntry> prof_acc;
     std::vector<Pending> pending;
     int64_t stats[4] = {0, 0, 0, 0};
+    // multi-GPU: one context per process per GPU, RCCL communicator over all ranks
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    bool force_gather = false;   // CHB_FORCE_GATHER=1: run the exchange path even with one rank (tests)
     // work-unit hints for the profile (pairs = queries x members streamed)
     double hint_base_members = 0.0, hint_batch_entries = 0.0;
 
@@ -160,12 +212,13 @@ void drain_profile(chb_ctx *h)
 int ensure_batch_buffers(chb_ctx *h, int Kcap)
 {
     const size_t B = h->B, m = h->m, K = Kcap;
+    const size_t Kpad = K + (size_t)h->world;   // allgather of ceil(K/world)-sized slices
     HIPCHK(h->bq.ensure(K));
     HIPCHK(h->lab_old.ensure(K));
-    HIPCHK(h->lab_prev.ensure(K));
-    HIPCHK(h->lab_new.ensure(K));
+    HIPCHK(h->lab_prev.ensure(Kpad));
+    HIPCHK(h->lab_new.ensure(Kpad));
     HIPCHK(h->first_change.ensure(1));
-    HIPCHK(h->mind.ensure(K));
+    HIPCHK(h->mind.ensure(Kpad));
     HIPCHK(h->dist.ensure(K * B));
     HIPCHK(h->l0d.ensure(K * B * m));
     HIPCHK(h->l1d.ensure(K * B * m));
@@ -397,6 +450,7 @@ int chb_create(int device_id, chb_ctx **out)
     chb_ctx *h = new chb_ctx();
     h->dev = device_id;
     if (const char *e = getenv("CHB_PREFILTER")) h->use_prefilter = atoi(e) != 0;
+    if (const char *e = getenv("CHB_FORCE_GATHER")) h->force_gather = atoi(e) != 0;
     if (const char *e = getenv("CHB_PF_BASE")) h->pf_base = atoi(e) != 0;
     if (const char *e = getenv("CHB_PF_UPDATE")) h->pf_update = atoi(e) != 0;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -411,6 +465,7 @@ int chb_destroy(chb_ctx *h)
     (void)hipSetDevice(h->dev);
     (void)hipStreamSynchronize(h->stream);
     drain_profile(h);
+    if (h->comm && rccl()) { (void)rccl()->CommDestroy(h->comm); h->comm = nullptr; }
     DevBuf<int> *ib[] = {&h->labels, &h->inb, &h->bq, &h->lab_old, &h->lab_prev, &h->lab_new,
                          &h->first_change, &h->l0i, &h->l1i, &h->l0c, &h->l1c, &h->cnt, &h->bin_ptr,
                          &h->cursor, &h->memb_id, &h->cnt2, &h->bin_ptr2, &h->cursor2, &h->memb2_id,
@@ -597,7 +652,10 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
     const int64_t N = h->N;
     for (int64_t i = 0; i < (int64_t)max_iter * n_move; ++i)
         if (perms[i] < 0 || perms[i] >= N) return fail(CHB_EINVAL, "perm entry out of range");
-    int Kmax = batch > 0 ? batch : 8192;
+    if (h->world > 1 && !h->comm) return fail(CHB_ESTATE, "world > 1 but chb_comm_init was not called");
+    // default batch: 8192 positions per GPU (more ranks -> proportionally larger batches, so that
+    // every rank still launches full grids)
+    int Kmax = batch > 0 ? batch : 8192 * std::min(h->world, 8);
     if (Kmax > n_move) Kmax = (int)std::max<int64_t>(n_move, 1);
     rc = ensure_batch_buffers(h, Kmax);
     if (rc) return rc;
@@ -631,16 +689,31 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
             HIPCHK(hipMemcpyAsync(h->bq.p, h->perm.p + t0, sizeof(int) * K, hipMemcpyDeviceToDevice, s));
             h->hint_base_members = (double)((it == 0) ? assigned0 + t0 : labelled - K);
             h->hint_batch_entries = (double)((it == 0) ? K : 2 * K);
-            rc = batch_begin_dev(h, K, 0, K);
+            // multi-GPU: rank r evaluates positions [r*C, (r+1)*C) of the batch; the label slices
+            // are exchanged with one in-place RCCL all-gather per round (KB-sized)
+            const int world = h->world;
+            const bool xchg = h->comm != nullptr && (world > 1 || h->force_gather);
+            const int C = (K + world - 1) / world;
+            const int q_lo = std::min(K, h->rank * C), q_hi = std::min(K, q_lo + C);
+            rc = batch_begin_dev(h, K, q_lo, q_hi);
             if (rc) return rc;
             // starting labels of the rounds: last sweep's label, or for still-unlabelled contigs
             // (sweep 1) the bin of the nearest outside member
-            launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, 0, K, h->B, h->m, h->Kcap, h->lab_prev.p, s);
+            launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, q_lo, q_hi, h->B, h->m, h->Kcap, h->lab_prev.p, s);
+            if (xchg)
+                NCCLCHK(rccl()->AllGather(h->lab_prev.p + h->rank * C, h->lab_prev.p, (size_t)C, ncclInt32, h->comm, s));
             int active = 0;
             for (;;) {
                 int f = K;
-                rc = batch_round_dev(h, active, &f);
+                rc = batch_round_dev(h, active, xchg ? nullptr : &f);
                 if (rc) return rc;
+                if (xchg) {
+                    NCCLCHK(rccl()->AllGather(h->lab_new.p + h->rank * C, h->lab_new.p, (size_t)C, ncclInt32, h->comm, s));
+                    launch_fill_i32(h->first_change.p, K, 1, s);
+                    launch_first_change(h->lab_new.p, h->lab_prev.p, active, K, h->first_change.p, s);
+                    HIPCHK(hipMemcpyAsync(&f, h->first_change.p, sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                }
                 // positions [active, K) now carry this round's labels
                 HIPCHK(hipMemcpyAsync(h->lab_prev.p + active, h->lab_new.p + active,
                                       sizeof(int) * (K - active), hipMemcpyDeviceToDevice, s));
@@ -648,6 +721,8 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
                 active = f + 1;
                 if (active >= K) break;
             }
+            if (min_dist_out && xchg)
+                NCCLCHK(rccl()->AllGather(h->mind.p + h->rank * C, h->mind.p, (size_t)C, ncclFloat64, h->comm, s));
             if (min_dist_out) {
                 HIPCHK(hipMemcpyAsync(mind_host.data(), h->mind.p, sizeof(double) * K, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
@@ -856,6 +931,43 @@ int chb_find_nearest_from_row(chb_ctx *h, int64_t c, const int64_t *labels, cons
     if (e != hipSuccess) return fail(CHB_EHIP, hipGetErrorString(e));
     for (int i = 0; i < m; ++i) out_idx[i] = out[(size_t)i];
     *out_cnt = out[(size_t)m];
+    return CHB_OK;
+}
+
+int chb_comm_unique_id(char *out128)
+{
+    if (!out128) return fail(CHB_EINVAL, "null argument");
+    if (!rccl()) return fail(CHB_EUNSUPPORTED, "librccl could not be loaded");
+    ncclUniqueId id;
+    NCCLCHK(rccl()->GetUniqueId(&id));
+    memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return CHB_OK;
+}
+
+int chb_comm_init(chb_ctx *h, const char *id128, int rank, int world)
+{
+    if (!h || !id128) return fail(CHB_EINVAL, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(CHB_EINVAL, "bad rank/world");
+    if (!rccl()) return fail(CHB_EUNSUPPORTED, "librccl could not be loaded");
+    HIPCHK(hipSetDevice(h->dev));
+    if (h->comm) { (void)rccl()->CommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    NCCLCHK(rccl()->CommInitRank(&h->comm, world, id, rank));
+    h->rank = rank; h->world = world;
+    h->Kcap = 0;
+    return CHB_OK;
+}
+
+int chb_comm_destroy(chb_ctx *h)
+{
+    if (!h) return CHB_OK;
+    if (h->comm && rccl()) {
+        (void)hipSetDevice(h->dev);
+        (void)hipStreamSynchronize(h->stream);
+        (void)rccl()->CommDestroy(h->comm);
+    }
+    h->comm = nullptr; h->rank = 0; h->world = 1;
     return CHB_OK;
 }
 

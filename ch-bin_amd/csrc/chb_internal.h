@@ -117,6 +117,9 @@ void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cn
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code,
                          hipStream_t s);
+// first position in [p0,K) whose label changed (atomicMin into *first_change)
+void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,
+                         hipStream_t s);
 // round-0 label guess: lab_old where >= 0, else bin of the nearest outside member
 void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old, int p0, int p1,
                   int B, int m, int Kcap, int *lab_prev, hipStream_t s);

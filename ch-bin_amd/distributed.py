@@ -180,3 +180,22 @@ def fit_cluster_distributed(backend, X, B, initial, perms, m, max_iter, batch=0,
     if not torch.equal(chk_max.cpu(), chk):
         raise RuntimeError("label replicas diverged across ranks")
     return labels, its, changed
+
+
+def init_native_comm(ctx, group=None, device=None):
+    """Create the RCCL communicator that lets `ctx.fit_cluster` shard batches across all ranks in
+    C++ (csrc/chb_api.hip).  torch.distributed is only used to hand rank 0's 128-byte unique id to
+    the other ranks.  Afterwards every rank calls ctx.fit_cluster(...) with identical arguments."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    buf = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = torch.frombuffer(bytearray(type(ctx).comm_unique_id()), dtype=torch.uint8).clone()
+    if device is not None:
+        buf = buf.to(device)
+    dist.broadcast(buf, src=0, group=group)
+    ctx.comm_init(bytes(buf.cpu().numpy().tobytes()), rank, world)
+    return rank, world

@@ -114,6 +114,15 @@ int chb_batch_round(chb_ctx *h, const int64_t *lab_prev, int64_t active, int64_t
 int chb_batch_commit(chb_ctx *h, const int64_t *final_labels);
 int chb_fit_labels(chb_ctx *h, int64_t *labels_out);
 
+/* ---- multi-GPU inside chb_fit_cluster: one process (and one context) per GPU.  Rank 0 obtains a
+ * 128-byte RCCL unique id, the host side broadcasts it (torch.distributed / MPI / files), every
+ * rank calls chb_comm_init.  chb_fit_cluster then shards each speculative batch's positions over
+ * the ranks and exchanges the label slices with RCCL all-gathers over xGMI; every rank must make
+ * the same call with the same arguments and receives the same, complete result. */
+int chb_comm_unique_id(char *out128);
+int chb_comm_init(chb_ctx *h, const char *id128, int rank, int world);
+int chb_comm_destroy(chb_ctx *h);
+
 /* ---- measurement: HIP-event timing of every kernel launch on the context's stream */
 int chb_profile_enable(chb_ctx *h, int on);
 int chb_profile_reset(chb_ctx *h);

@@ -412,3 +412,33 @@ def test_cli_perform_clustering_matches_oracle(ctx, O, tmp_path, golden_dir, mon
                                                 max_iterations=6)
     assert open(out_gpu).read() == open(out_cpu).read()
     assert len(pd.read_csv(out_gpu)) == 120
+
+
+def test_native_comm_exchange_path_world1(O):
+    """The RCCL exchange path of chb_fit_cluster (communicator of one rank, all-gathers forced on):
+    same labels and winning distances as the plain path."""
+    from chbin_amd import _lib
+    X, initial, _ = _synth(900, 136, 8, seed=31, sigma=6e-3, mix=0.6, n_seed=8)
+    perms = _perms(initial, 4)
+    want, its_o, _ = O.fit_cluster(X, 8, initial, perms, 5, 4)
+    old = os.environ.get("CHB_FORCE_GATHER")
+    os.environ["CHB_FORCE_GATHER"] = "1"
+    try:
+        c = _lib.Context(0)
+    finally:
+        if old is None:
+            del os.environ["CHB_FORCE_GATHER"]
+        else:
+            os.environ["CHB_FORCE_GATHER"] = old
+    try:
+        c.comm_init(_lib.Context.comm_unique_id(), 0, 1)
+        c.set_samples(X)
+        got, its, _, mind = c.fit_cluster(8, initial, perms, 5, 4, batch=200, want_min_dist=True)
+        assert its == its_o and np.array_equal(got, want)
+        labels = initial.copy()
+        for k in range(its):
+            labels, md = O.sweep(X, 8, labels, perms[k], 5)
+        assert np.allclose(mind[perms[its - 1]], md, rtol=0, atol=QP_TOL)
+        c.comm_destroy()
+    finally:
+        c.close()
