@@ -146,8 +146,8 @@ struct chb_ctx {
     DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
     DevBuf<int> perm;
     // two-stage selection: bf16 shadow copy + shortlists
-    DevBuf<unsigned short> Z;
-    DevBuf<float> znrm, zrho;
+    DevBuf<unsigned short> Z, Zp;
+    DevBuf<float> znrm, zrho, znrm_p, zrho_p, rho_bin, rho_all;
     DevBuf<double> colwork;
     int Dz = 0;
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
@@ -242,6 +242,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->n_active.ensure(1));
         HIPCHK(h->flags64.ensure(B * ((K + kQTile - 1) / kQTile)));
         HIPCHK(h->overflow.ensure(1));
+        HIPCHK(h->rho_bin.ensure(B));
     }
     h->Kcap = Kcap;
     return CHB_OK;
@@ -296,6 +297,16 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
         PrefilterArgs pa{};
         pa.sh = Shadow{h->Z.p, h->znrm.p, h->zrho.p, h->Dz};
+        // member rows packed in CSR (bin) order: the kernel streams contiguous memory
+        {
+            Timed t(h, "bucket", 0.0);
+            launch_pack_shadow(pa.sh, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->Zp.p,
+                               h->znrm_p.p, h->zrho_p.p, s);
+        }
+        pa.shm = Shadow{h->Zp.p, h->znrm_p.p, h->zrho_p.p, h->Dz};
+        pa.packed = true;
+        launch_bin_rho_max(h->zrho_p.p, h->memb_id.p, h->bin_ptr.p, h->B, true, h->rho_bin.p, s);
+        pa.rho_bound = h->rho_bin.p;
         pa.bq = h->bq.p; pa.pos_begin = q_lo; pa.pos_end = q_hi;
         pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p;
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
@@ -349,6 +360,8 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
             PrefilterArgs pa{};
             pa.sh = Shadow{h->Z.p, h->znrm.p, h->zrho.p, h->Dz};
+            pa.shm = pa.sh; pa.packed = false;
+            pa.rho_bound = h->rho_all.p;
             pa.bq = h->bq.p; pa.pos_begin = lo; pa.pos_end = hi;
             pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.memb_code = h->memb2_code.p;
             pa.seed = h->L0();
@@ -474,6 +487,7 @@ int chb_destroy(chb_ctx *h)
     DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
     h->Z.release(); h->znrm.release(); h->zrho.release(); h->colwork.release();
+    h->Zp.release(); h->znrm_p.release(); h->zrho_p.release(); h->rho_bin.release(); h->rho_all.release();
     h->active.release(); h->n_active.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -501,10 +515,15 @@ static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D,
         HIPCHK(h->Z.ensure((size_t)N * Dz));
         HIPCHK(h->znrm.ensure((size_t)N));
         HIPCHK(h->zrho.ensure((size_t)N));
+        HIPCHK(h->Zp.ensure((size_t)N * Dz));
+        HIPCHK(h->znrm_p.ensure((size_t)N));
+        HIPCHK(h->zrho_p.ensure((size_t)N));
         HIPCHK(h->colwork.ensure((size_t)257 * D));
         launch_col_sums(h->X.p, (int)N, (int)D, Dp, h->colwork.p, h->stream);
         launch_build_shadow(h->X.p, (int)N, (int)D, Dp, h->colwork.p + (size_t)256 * D, h->Z.p, Dz,
                             h->znrm.p, h->zrho.p, h->stream);
+        HIPCHK(h->rho_all.ensure(1));
+        launch_rho_max_all(h->zrho.p, (int)N, h->rho_all.p, h->stream);
         HIPCHK(hipGetLastError());
         h->Dz = Dz;
         h->shadow_ok = true;

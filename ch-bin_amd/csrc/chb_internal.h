@@ -49,11 +49,19 @@ struct Shadow {
     int Dz;
 };
 void launch_col_sums(const double *X, int N, int D, int Dp, double *colsum, hipStream_t s);
+void launch_pack_shadow(const Shadow &src, const int *memb_id, const int *bin_ptr, int B, int n_max,
+                        unsigned short *Zp, float *nrm_p, float *rho_p, hipStream_t s);
+void launch_bin_rho_max(const float *rho, const int *memb_id, const int *bin_ptr, int B, bool packed,
+                        float *out, hipStream_t s);
+void launch_rho_max_all(const float *rho, int N, float *out, hipStream_t s);
 void launch_build_shadow(const double *X, int N, int D, int Dp, const double *colsum,
                          unsigned short *Z, int Dz, float *nrm, float *rho, hipStream_t s);
 
 struct PrefilterArgs {
-    Shadow sh;
+    Shadow sh;             // query side, indexed by sample id
+    Shadow shm;            // member side: indexed by sample id, or by CSR entry when `packed`
+    bool packed;
+    const float *rho_bound; // base mode: [B] largest rho among each bin's members; update mode: [1]
     const int *bq;
     int pos_begin, pos_end;
     const int *bin_ptr;

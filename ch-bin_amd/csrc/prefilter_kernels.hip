@@ -27,6 +27,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace chb {
 namespace {
 
@@ -99,6 +101,59 @@ __global__ __launch_bounds__(64) void build_shadow_kernel(const double *X, int N
         nrm[p] = round_up_f32(n2 * (1.0 + 1e-12));
         rho[p] = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
     }
+}
+
+// Copies the shadow rows of the CSR-ordered members into contiguous storage so that the shortlist
+// kernel streams plain sequential memory (no dependent index -> row load chain in its pipeline).
+__global__ __launch_bounds__(256) void pack_shadow_kernel(const unsigned short *Z, const float *nrm,
+                                                          const float *rho, int Dz, const int *memb_id,
+                                                          const int *bin_ptr, int B,
+                                                          unsigned short *Zp, float *nrm_p, float *rho_p)
+{
+    const int total = bin_ptr[B];
+    const int cpr = Dz >> 3;
+    const long long nch = (long long)total * cpr;
+    for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nch;
+         ch += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(ch / cpr), cc = (int)(ch - (long long)e * cpr);
+        const int id = memb_id[e];
+        *reinterpret_cast<uint4 *>(Zp + (size_t)e * Dz + cc * 8) =
+            *reinterpret_cast<const uint4 *>(Z + (size_t)id * Dz + cc * 8);
+        if (cc == 0) { nrm_p[e] = nrm[id]; rho_p[e] = rho[id]; }
+    }
+}
+
+// rho_bound[c] = largest rounding distance among the members of bin c (one block per bin)
+__global__ __launch_bounds__(256) void bin_rho_max_kernel(const float *rho, const int *memb_id,
+                                                          const int *bin_ptr, bool packed, float *out)
+{
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float v = 0.f;
+    for (int e = bin_ptr[c] + threadIdx.x; e < bin_ptr[c + 1]; e += 256)
+        v = fmaxf(v, rho[packed ? e : memb_id[e]]);
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
+}
+
+// out[0] = largest rho over all samples
+__global__ __launch_bounds__(256) void rho_max_all_kernel(const float *rho, int N, float *out)
+{
+    __shared__ float red[256];
+    float v = 0.f;
+    for (int p = threadIdx.x; p < N; p += 256) v = fmaxf(v, rho[p]);
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 template <int ML>
@@ -188,60 +243,60 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
 
     const int ntile = (nmem + kPfP - 1) / kPfP;
     const int nchunk = kPfP * cpr;      // chunks per member tile (<= 4 per thread for Dz <= 256)
-    // staging registers: up to 4 16-byte chunks per thread (Dz <= 256), kept in named scalars so
-    // that nothing is spilled to scratch
-    uint4 st0 = {0, 0, 0, 0}, st1 = st0, st2 = st0, st3 = st0;
-    float st_n = INFINITY, st_r = 0.f;
-    int st_id = -1, st_code = 0;
-#define CHB_PF_FETCH_ONE(I, ST)                                                                   \
+    // staging registers: up to 4 16-byte chunks per thread (Dz <= 256).  Two sets, so that the tile
+    // after next is already in flight while the current one is being consumed (one global-memory
+    // latency per tile would otherwise be exposed: a tile is only ~0.4 us of work per wavefront).
+    uint4 cA0 = {0, 0, 0, 0}, cA1 = cA0, cA2 = cA0, cA3 = cA0, cB0 = cA0, cB1 = cA0, cB2 = cA0, cB3 = cA0;
+    float nA = INFINITY, nB = INFINITY;
+    int idA = -1, codeA = 0, idB = -1, codeB = 0;
+    // (named scalars + macros: a struct passed by reference to a lambda ends up in scratch)
+#define CHB_PF_FETCH_ONE(I, ST, TT)                                                               \
     {                                                                                              \
         const int ch = tid + 256 * (I);                                                            \
         if (ch < nchunk) {                                                                         \
             const int r = ch / cpr, cc = ch - r * cpr;                                             \
-            const int e = tt * kPfP + r;                                                           \
-            const int id = e < nmem ? a.memb_id[mb + e] : 0;                                       \
-            ST = *reinterpret_cast<const uint4 *>(a.sh.Z + (size_t)id * Dz + cc * 8);             \
+            const int e = (TT) * kPfP + r;                                                         \
+            const int id = e < nmem ? (a.packed ? mb + e : a.memb_id[mb + e]) : 0;                 \
+            ST = *reinterpret_cast<const uint4 *>(a.shm.Z + (size_t)id * Dz + cc * 8);            \
         }                                                                                          \
     }
-#define CHB_PF_STASH_ONE(I, ST)                                                                   \
+#define CHB_PF_STASH_ONE(I, ST, BB)                                                               \
     {                                                                                              \
         const int ch = tid + 256 * (I);                                                            \
         if (ch < nchunk) {                                                                         \
             const int r = ch / cpr, cc = ch - r * cpr;                                             \
-            *reinterpret_cast<uint4 *>(sPz + ((size_t)bb * kPfP + r) * stride + cc * 16) = ST;     \
+            *reinterpret_cast<uint4 *>(sPz + ((size_t)(BB) * kPfP + r) * stride + cc * 16) = ST;   \
         }                                                                                          \
     }
-    auto fetch = [&](int tt) {
-        CHB_PF_FETCH_ONE(0, st0)
-        CHB_PF_FETCH_ONE(1, st1)
-        CHB_PF_FETCH_ONE(2, st2)
-        CHB_PF_FETCH_ONE(3, st3)
-        if (tid < kPfP) {
-            const int e = tt * kPfP + tid;
-            if (e < nmem) {
-                st_id = a.memb_id[mb + e];
-                st_n = a.sh.nrm[st_id];
-                st_r = a.sh.rho[st_id];
-                st_code = UPD ? a.memb_code[mb + e] : 0;
-            } else {
-                st_id = -1; st_n = INFINITY; st_r = 0.f; st_code = 0;
-            }
-        }
-    };
-    auto stash = [&](int bb) {
-        CHB_PF_STASH_ONE(0, st0)
-        CHB_PF_STASH_ONE(1, st1)
-        CHB_PF_STASH_ONE(2, st2)
-        CHB_PF_STASH_ONE(3, st3)
-        if (tid < kPfP) {
-            sPn[bb * kPfP + tid] = st_n;
-            sPr[bb * kPfP + tid] = st_r;
-            sPid[bb * kPfP + tid] = st_id;
-            sPcode[bb * kPfP + tid] = st_code;
-        }
-    };
-#undef CHB_PF_FETCH_ONE
-#undef CHB_PF_STASH_ONE
+#define CHB_PF_FETCH(TT, X)                                                                       \
+    {                                                                                              \
+        CHB_PF_FETCH_ONE(0, c##X##0, TT)                                                           \
+        CHB_PF_FETCH_ONE(1, c##X##1, TT)                                                           \
+        CHB_PF_FETCH_ONE(2, c##X##2, TT)                                                           \
+        CHB_PF_FETCH_ONE(3, c##X##3, TT)                                                           \
+        if (tid < kPfP) {                                                                          \
+            const int e = (TT) * kPfP + tid;                                                       \
+            if (e < nmem) {                                                                        \
+                id##X = a.memb_id[mb + e];                                                         \
+                n##X = a.shm.nrm[a.packed ? mb + e : id##X];                                       \
+                code##X = UPD ? a.memb_code[mb + e] : 0;                                           \
+            } else {                                                                               \
+                id##X = -1; n##X = INFINITY; code##X = 0;                                          \
+            }                                                                                      \
+        }                                                                                          \
+    }
+#define CHB_PF_STASH(BB, X)                                                                       \
+    {                                                                                              \
+        CHB_PF_STASH_ONE(0, c##X##0, BB)                                                           \
+        CHB_PF_STASH_ONE(1, c##X##1, BB)                                                           \
+        CHB_PF_STASH_ONE(2, c##X##2, BB)                                                           \
+        CHB_PF_STASH_ONE(3, c##X##3, BB)                                                           \
+        if (tid < kPfP) {                                                                          \
+            sPn[(BB) * kPfP + tid] = n##X;                                                         \
+            sPid[(BB) * kPfP + tid] = id##X;                                                       \
+            sPcode[(BB) * kPfP + tid] = code##X;                                                   \
+        }                                                                                          \
+    }
 
     const unsigned char *qbase = sQz + (size_t)(32 * w + col) * stride + h * 16;
     const size_t slot = (size_t)c * a.Kcap + qpos;
@@ -251,116 +306,128 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
     // bound; sweep 1 shortlists against that FINAL tau, so the list holds only the members whose
     // error interval reaches below it (about m + a handful) instead of everything that passed a
     // still-loose running threshold.  The matrix-core work is cheap enough to do twice.
+    // rho_j + (largest rho of any member this kernel can meet): constant per (query, bin)
+    const float rsum = (rq + a.rho_bound[UPD ? 0 : c]) * (1.0f + kSlack);
+    float thr = INFINITY;   // sweep 0: m-th smallest t1 so far
+    float C2 = FLT_MAX;     // sweep 1: admission bound on t2
+    if (UPD && tau < INFINITY) {
+        const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+        C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
+    }
     for (int sweep = UPD ? 1 : 0; sweep < 2; ++sweep) {
-        __syncthreads();
-        if (ntile > 0) { fetch(0); stash(0); }
-        __syncthreads();
-        for (int t = 0; t < ntile; ++t) {
-            const int buf = t & 1;
-            if (t + 1 < ntile) fetch(t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-
-            f32x16 acc;
+        if (!UPD && sweep == 1 && thr < INFINITY) {
+            // tau = m-th smallest upper bound; at least m members are provably within it
+            tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
+            const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+            C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
+        }
+        auto consume = [&](int buf) {
+        f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + h * 16;
-            if (QREG) {
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + h * 16;
+        if (QREG) {
 #pragma unroll
-                for (int sx = 0; sx < KSMAX; ++sx)
-                    if (sx < ksteps) {
-                        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + sx * 32);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qreg[sx], acc, 0, 0, 0);
-                    }
-            } else {
-                for (int sx = 0; sx < ksteps; ++sx) {
+            for (int sx = 0; sx < KSMAX; ++sx)
+                if (sx < ksteps) {
                     const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + sx * 32);
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(qbase + sx * 32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qreg[sx], acc, 0, 0, 0);
                 }
+        } else {
+            for (int sx = 0; sx < ksteps; ++sx) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + sx * 32);
+                const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(qbase + sx * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
             }
+        }
 
-            // rows held by this lane: (r&3) + 8*(r>>2) + 4*h
-            float np[16];
-            float rt = 0.f;
+        // rows held by this lane: (r&3) + 8*(r>>2) + 4*h
+        float np[16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = *reinterpret_cast<const float4 *>(&sPn[buf * kPfP + 8 * g + 4 * h]);
-                const float4 rr = *reinterpret_cast<const float4 *>(&sPr[buf * kPfP + 8 * g + 4 * h]);
-                np[4 * g + 0] = v.x; np[4 * g + 1] = v.y; np[4 * g + 2] = v.z; np[4 * g + 3] = v.w;
-                rt = fmaxf(rt, fmaxf(fmaxf(rr.x, rr.y), fmaxf(rr.z, rr.w)));
-            }
-            rt = fmaxf(rt, __shfl_xor(rt, 32, 64));
-            const float rsum = (rq + rt) * (1.0f + kSlack);
-            if (UPD) {
-                // a batch member counts for this query only on the right side of the visiting order
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(&sPn[buf * kPfP + 8 * g + 4 * h]);
+            np[4 * g + 0] = v.x; np[4 * g + 1] = v.y; np[4 * g + 2] = v.z; np[4 * g + 3] = v.w;
+        }
+        if (UPD) {
+            // a batch member counts for this query only on the right side of the visiting order
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int code = sPcode[buf * kPfP + (r & 3) + 8 * (r >> 2) + 4 * h];
-                    bool ok = true;
-                    if (code > 0) ok = qpos > code - 1;
-                    else if (code <= -(1 << 30)) ok = qpos != -(1 << 30) - code;
-                    else if (code < 0) ok = qpos < -code - 1;
-                    if (!ok) np[r] = INFINITY;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int code = sPcode[buf * kPfP + (r & 3) + 8 * (r >> 2) + 4 * h];
+                bool ok = true;
+                if (code > 0) ok = qpos > code - 1;
+                else if (code <= -(1 << 30)) ok = qpos != -(1 << 30) - code;
+                else if (code < 0) ok = qpos < -code - 1;
+                if (!ok) np[r] = INFINITY;
             }
+        }
 
-            if (sweep == 0) {
-                // tighten tau: members whose UB' = sqrt(s + E) + rho_j + rho_tile < tau
-                float C1 = FLT_MAX;
-                if (tau < INFINITY) {
-                    const float lo = tau - rsum;
-                    C1 = lo > 0.f ? lo * lo * (1.0f - 4.0f * kSlack) - nj_hi : -FLT_MAX;
-                }
-                bool ins = false;
+        if (sweep == 0) {
+            // Learn tau.  UB'(p) = sqrt(t1_p + n_j(1+g)) + rho_j + rho_bin is monotone in
+            // t1_p = n_p(1+g) - 2<zh_j, zh_p>, so the m smallest t1 are kept (no sqrt per insert);
+            // `thr` = m-th smallest t1 over both lane halves of this query.
+            bool ins = false;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float t1 = fmaf(kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
-                    if (t1 < C1) {
-                        const float ubv = sqrtf(fmaxf(t1 + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
-                        list_insert<ML>(ub, ubv);
-                        ins = true;
-                    }
-                }
-                if (__any(ins)) {
-                    float mg[ML];
-#pragma unroll
-                    for (int i = 0; i < ML; ++i) mg[i] = ub[i];
-#pragma unroll
-                    for (int i = 0; i < ML; ++i) list_insert<ML>(mg, __shfl_xor(ub[i], 32, 64));
-#pragma unroll
-                    for (int i = 0; i < ML; ++i)
-                        if (i == m - 1) tau = mg[i];
-                }
-            } else {
-                // shortlist: LB' = sqrt(s - E) - rho_j - rho_tile <= tau
-                float C2 = FLT_MAX;
-                if (tau < INFINITY) {
-                    const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
-                    C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
-                }
-                unsigned mask = 0u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float t2 = fmaf(-kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
-                    if (t2 <= C2) mask |= 1u << r;
-                }
-                const int cnt = __popc(mask);
-                const int pc = __shfl_xor(cnt, 32, 64);
-                int off = ccount + (h ? pc : 0);
-                ccount += cnt + pc;
-                if (qvalid) {
-                    while (mask) {
-                        const int r = __ffs(mask) - 1;
-                        mask &= mask - 1u;
-                        const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (off < kCandCap) cand[off] = sPid[buf * kPfP + prow];
-                        ++off;
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const float t1 = fmaf(kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
+                if (t1 < thr) {
+                    list_insert<ML>(ub, t1);
+                    ins = true;
                 }
             }
+            if (__any(ins)) {
+                float mg[ML];
+#pragma unroll
+                for (int i = 0; i < ML; ++i) mg[i] = ub[i];
+#pragma unroll
+                for (int i = 0; i < ML; ++i) list_insert<ML>(mg, __shfl_xor(ub[i], 32, 64));
+#pragma unroll
+                for (int i = 0; i < ML; ++i)
+                    if (i == m - 1) thr = mg[i];
+            }
+        } else {
+            // shortlist: LB' = sqrt(s - E) - rho_j - rho_bin <= tau  <=>  t2 <= C2 (constant)
+            unsigned mask = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t2 = fmaf(-kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
+                if (t2 <= C2) mask |= 1u << r;
+            }
+            const int cnt = __popc(mask);
+            const int pc = __shfl_xor(cnt, 32, 64);
+            int off = ccount + (h ? pc : 0);
+            ccount += cnt + pc;
+            if (qvalid) {
+                while (mask) {
+                    const int r = __ffs(mask) - 1;
+                    mask &= mask - 1u;
+                    const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (off < kCandCap) cand[off] = sPid[buf * kPfP + prow];
+                    ++off;
+                }
+            }
+        }
 
+        };
+        __syncthreads();
+        if (ntile > 0) CHB_PF_FETCH(0, A)
+        if (ntile > 1) CHB_PF_FETCH(1, B)
+        if (ntile > 0) CHB_PF_STASH(0, A)
+        __syncthreads();
+        for (int t = 0; t < ntile; t += 2) {
+            // even tile t sits in buffer 0, tile t+1 is in flight in SB
+            if (t + 2 < ntile) CHB_PF_FETCH(t + 2, A)
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < ntile) stash(buf ^ 1);
+            consume(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < ntile) CHB_PF_STASH(1, B)
+            __syncthreads();
+            if (t + 1 >= ntile) break;
+            // odd tile t+1 sits in buffer 1, tile t+2 is in flight in SA
+            if (t + 3 < ntile) CHB_PF_FETCH(t + 3, B)
+            __builtin_amdgcn_sched_barrier(0);
+            consume(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntile) CHB_PF_STASH(0, A)
             __syncthreads();
         }
     }
@@ -395,11 +462,37 @@ void launch_build_shadow(const double *X, int N, int D, int Dp, const double *co
     hipLaunchKernelGGL(build_shadow_kernel, dim3(N), dim3(64), 0, s, X, N, D, Dp, colmean, Z, Dz, nrm, rho);
 }
 
+#undef CHB_PF_FETCH_ONE
+#undef CHB_PF_STASH_ONE
+#undef CHB_PF_FETCH
+#undef CHB_PF_STASH
+
 static bool use_qreg(int Dz)
 {
     static int env = -1;
     if (env < 0) { const char *e = getenv("CHB_PF_QREG"); env = e ? atoi(e) : 1; }
     return env != 0 && Dz <= 160;   // queries in registers up to 10 k-steps
+}
+
+void launch_pack_shadow(const Shadow &src, const int *memb_id, const int *bin_ptr, int B, int n_max,
+                        unsigned short *Zp, float *nrm_p, float *rho_p, hipStream_t s)
+{
+    if (n_max <= 0) return;
+    long long nch = (long long)n_max * (src.Dz >> 3);
+    int grid = (int)std::min<long long>((nch + 255) / 256, 8192);
+    hipLaunchKernelGGL(pack_shadow_kernel, dim3(grid), dim3(256), 0, s, src.Z, src.nrm, src.rho, src.Dz,
+                       memb_id, bin_ptr, B, Zp, nrm_p, rho_p);
+}
+
+void launch_bin_rho_max(const float *rho, const int *memb_id, const int *bin_ptr, int B, bool packed,
+                        float *out, hipStream_t s)
+{
+    if (B > 0) hipLaunchKernelGGL(bin_rho_max_kernel, dim3(B), dim3(256), 0, s, rho, memb_id, bin_ptr, packed, out);
+}
+
+void launch_rho_max_all(const float *rho, int N, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(rho_max_all_kernel, dim3(1), dim3(256), 0, s, rho, N, out);
 }
 
 size_t prefilter_lds_bytes(int Dz)
