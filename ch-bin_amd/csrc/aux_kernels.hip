@@ -60,13 +60,26 @@ __global__ void scan_kernel(const int *cnt, int B, int *bin_ptr, int *cursor)
     }
 }
 
-__global__ void fill_base_kernel(const int *labels, const int *inb, int N, int B, int *cursor,
-                                 int *memb_id)
+// Block-aggregated fill: one global atomic per (block, bin) instead of one per sample.
+__global__ __launch_bounds__(256) void fill_base_kernel(const int *labels, const int *inb, int N, int B,
+                                                        int *cursor, int *memb_id)
 {
+    extern __shared__ int sh[];      // [B] local counts, then [B] block base offsets
+    int *cnt = sh, *base = sh + B;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N) return;
-    const int l = labels[p];
-    if (l >= 0 && l < B && inb[p] < 0) memb_id[atomicAdd(&cursor[l], 1)] = p;
+    int l = -1, my = 0;
+    if (p < N) {
+        l = labels[p];
+        if (!(l >= 0 && l < B && inb[p] < 0)) l = -1;
+    }
+    if (l >= 0) my = atomicAdd(&cnt[l], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x)
+        base[b] = cnt[b] ? atomicAdd(&cursor[b], cnt[b]) : 0;
+    __syncthreads();
+    if (l >= 0) memb_id[base[l] + my] = p;
 }
 
 // ---- the batch's own members.  Position i appears (a) in bin lab_prev[i] for every LATER query
@@ -248,7 +261,7 @@ void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cn
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, cnt, B, bin_ptr, cursor);
-    hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 0, s, labels, inb, N, B, cursor, memb_id);
+    hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * sizeof(int), s, labels, inb, N, B, cursor, memb_id);
 }
 
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
