@@ -176,8 +176,30 @@ def main():
                          "avg_launch_ms": p["ms"] / p["launches"], "launches": p["launches"],
                          "total_ms": p["ms"], "qp_per_s_kernel": p["work"] / (p["ms"] * 1e-3),
                          "bytes_per_qp": bytes_qp})
+        # HBM-side traffic per launch from the committed PMC profile (separate rocprofv3 --pmc passes,
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null when unavailable
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01c_traffic.json")))["kernels"]
+            tmap = {"prefilter": "prefilter_kernel<5, false, true>", "hull_qp": "hull_qp_kernel",
+                    "rescore": "rescore_kernel", "rescore_update": "rescore_kernel",
+                    "prefilter_update": "prefilter_kernel<1, true, true>"}
+            if (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist:
+                for k in kern:
+                    src = tmap.get(k["kernel"])
+                    if src in tr:
+                        k["traffic"] = tr[src]["traffic_bytes_per_launch"]
+                        k["traffic_source"] = "profiles/r01c_traffic.json (" + src + ")"
+        except Exception:  # noqa: BLE001
+            pass
         kern.sort(key=lambda k: -k["total_ms"])
         roofline = dict(kern[0]) if kern else None
+        # whole-path view in SURVEY 8(d)'s no-reuse gather model: every hull distance the sweep needs
+        # x bytes_QP over the sweep's wall time (selection traffic is on top of that and is not part
+        # of bytes_QP because no distance row is ever materialised)
+        bytes_qp = 8.0 * (m * D + D / B + 1)
+        path_roofline = {"bound": "hbm", "achieved": value * bytes_qp / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": value * bytes_qp / 1e9 / HBM_PEAK_GBS,
+                         "bytes_per_qp": bytes_qp}
 
         # ---- end-to-end bin-assign wall clock (all sweeps until no label changes, max 10)
         e2e = None
@@ -220,6 +242,7 @@ def main():
                        "qp_per_step": int(qp_per_step), "batch": args.batch or 8192,
                        "parallelism": (f"contig-sharded x{world}, " + ("RCCL all-gather in the C++ loop" if native else "torch.distributed all_reduce")) if use_dist else "single GPU"},
             "roofline": roofline,
+            "path_roofline": path_roofline,
             "kernels": kern,
             "cpu_baseline": cpu,
             "end_to_end_bin_assign": e2e,
