@@ -29,6 +29,13 @@
 
 #include <algorithm>
 
+#ifndef CHB_PF_DEEP
+#define CHB_PF_DEEP 0
+#endif
+#ifndef CHB_PF_WAVES
+#define CHB_PF_WAVES 3
+#endif
+
 namespace chb {
 namespace {
 
@@ -174,7 +181,7 @@ __device__ __forceinline__ void list_insert(float (&l)[ML], float v)
 // QREG = true : the query fragments (B operand) live in registers for the whole kernel (Dz <= 160);
 //               LDS then only holds the double-buffered member tile, so 6-8 workgroups fit a CU.
 template <int ML, bool UPD, bool QREG>
-__global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
+__global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
                                                         int stride, int *flags64, int nqt64)
 {
     constexpr int KSMAX = 10;
@@ -246,9 +253,14 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
     // staging registers: up to 4 16-byte chunks per thread (Dz <= 256).  Two sets, so that the tile
     // after next is already in flight while the current one is being consumed (one global-memory
     // latency per tile would otherwise be exposed: a tile is only ~0.4 us of work per wavefront).
-    uint4 cA0 = {0, 0, 0, 0}, cA1 = cA0, cA2 = cA0, cA3 = cA0, cB0 = cA0, cB1 = cA0, cB2 = cA0, cB3 = cA0;
-    float nA = INFINITY, nB = INFINITY;
-    int idA = -1, codeA = 0, idB = -1, codeB = 0;
+    uint4 cA0 = {0, 0, 0, 0}, cA1 = cA0, cA2 = cA0, cA3 = cA0;
+    float nA = INFINITY;
+    int idA = -1, codeA = 0;
+#if CHB_PF_DEEP
+    uint4 cB0 = cA0, cB1 = cA0, cB2 = cA0, cB3 = cA0;
+    float nB = INFINITY;
+    int idB = -1, codeB = 0;
+#endif
     // (named scalars + macros: a struct passed by reference to a lambda ends up in scratch)
 #define CHB_PF_FETCH_ONE(I, ST, TT)                                                               \
     {                                                                                              \
@@ -409,6 +421,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
 
         };
         __syncthreads();
+#if CHB_PF_DEEP
         if (ntile > 0) CHB_PF_FETCH(0, A)
         if (ntile > 1) CHB_PF_FETCH(1, B)
         if (ntile > 0) CHB_PF_STASH(0, A)
@@ -430,6 +443,18 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a, int nqt
             if (t + 2 < ntile) CHB_PF_STASH(0, A)
             __syncthreads();
         }
+#else
+        if (ntile > 0) { CHB_PF_FETCH(0, A) CHB_PF_STASH(0, A) }
+        __syncthreads();
+        for (int t = 0; t < ntile; ++t) {
+            if (t + 1 < ntile) CHB_PF_FETCH(t + 1, A)
+            __builtin_amdgcn_sched_barrier(0);
+            consume(t & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < ntile) CHB_PF_STASH((t + 1) & 1, A)
+            __syncthreads();
+        }
+#endif
     }
 
     if (qvalid && h == 0) {

@@ -192,7 +192,7 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 // dimension happens inside the MFMA accumulator: no cross-lane reduction at all.  Each lane streams
 // ONE vertex row (every 4th feature), 8 loads in flight per operand.
 template <int M, int WAVES, bool INDEXED>
-__global__ __launch_bounds__(64 * WAVES) void hull_qp_kernel(QpArgs a, int nprob, const int *xq,
+__global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(QpArgs a, int nprob, const int *xq,
                                                               const int *xhull, const int *xn,
                                                               int xm, double *xdist, double *xalpha)
 {

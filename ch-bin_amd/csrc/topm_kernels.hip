@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
 constexpr int kRsChunk = 16;
 constexpr int kRsStride = 18;
 
-__global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a, int npairs)
+__global__ __launch_bounds__(256, 4) void rescore_kernel(RescoreArgs a, int npairs)
 {
     __shared__ __attribute__((aligned(16))) double slab[4][68][kRsStride];
 
