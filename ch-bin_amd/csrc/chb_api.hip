@@ -515,7 +515,7 @@ static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D,
         HIPCHK(h->Z.ensure((size_t)N * Dz));
         HIPCHK(h->znrm.ensure((size_t)N));
         HIPCHK(h->zrho.ensure((size_t)N));
-        HIPCHK(h->Zp.ensure((size_t)N * Dz));
+        HIPCHK(h->Zp.ensure((size_t)(N + 64) * Dz));   // + slack: the DMA path reads whole 32-row tiles
         HIPCHK(h->znrm_p.ensure((size_t)N));
         HIPCHK(h->zrho_p.ensure((size_t)N));
         HIPCHK(h->colwork.ensure((size_t)257 * D));

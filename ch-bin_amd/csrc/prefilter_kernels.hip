@@ -180,7 +180,11 @@ __device__ __forceinline__ void list_insert(float (&l)[ML], float v)
 //              cannot displace a list entry are dropped without ever touching fp64.
 // QREG = true : the query fragments (B operand) live in registers for the whole kernel (Dz <= 160);
 //               LDS then only holds the double-buffered member tile, so 6-8 workgroups fit a CU.
-template <int ML, bool UPD, bool QREG>
+// DMA  = true : member tiles go global -> LDS directly (global_load_lds_dwordx4, no staging
+//               registers, no ds_write); needs packed rows and 18 chunks per row (Dz = 144).  The LDS
+//               image is unpadded and XOR-swizzled through the SOURCE address (chunk c of row r sits
+//               at c ^ ((r >> 4) & 1)), which makes the ds_read_b128 fragment reads conflict-free.
+template <int ML, bool UPD, bool QREG, bool DMA>
 __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
                                                         int stride, int *flags64, int nqt64)
 {
@@ -250,6 +254,17 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
 
     const int ntile = (nmem + kPfP - 1) / kPfP;
     const int nchunk = kPfP * cpr;      // chunks per member tile (<= 4 per thread for Dz <= 256)
+    // LDS-DMA roles: wave w issues the 1-KiB pieces w, w+4, w+8, w+12 of a tile; lane l of piece i
+    // fills LDS chunk p = 64 i + l and fetches the global chunk that the swizzle maps there
+    int dma_off[4] = {0, 0, 0, 0};
+    if (DMA) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pch = (w + 4 * j) * 64 + lane;
+            const int r = pch / cpr, cs = pch - r * cpr;
+            dma_off[j] = (r * cpr + (cs ^ ((r >> 4) & 1))) * 16;
+        }
+    }
     // staging registers: up to 4 16-byte chunks per thread (Dz <= 256).  Two sets, so that the tile
     // after next is already in flight while the current one is being consumed (one global-memory
     // latency per tile would otherwise be exposed: a tile is only ~0.4 us of work per wavefront).
@@ -263,7 +278,15 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
 #endif
     // (named scalars + macros: a struct passed by reference to a lambda ends up in scratch)
 #define CHB_PF_FETCH_ONE(I, ST, TT)                                                               \
-    {                                                                                              \
+    if (DMA) {                                                                                     \
+        if (w + 4 * (I) < (cpr >> 1))                                                              \
+            __builtin_amdgcn_global_load_lds(                                                      \
+                reinterpret_cast<const unsigned char *>(a.shm.Z) +                                 \
+                    ((size_t)(mb + (TT) * kPfP) * Dz) * 2 + dma_off[I],                            \
+                (__attribute__((address_space(3))) void *)(sPz + (size_t)((TT) & 1) * kPfP * stride + \
+                                                          (w + 4 * (I)) * 1024),                  \
+                16, 0, 0);                                                                         \
+    } else {                                                                                       \
         const int ch = tid + 256 * (I);                                                            \
         if (ch < nchunk) {                                                                         \
             const int r = ch / cpr, cc = ch - r * cpr;                                             \
@@ -273,7 +296,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         }                                                                                          \
     }
 #define CHB_PF_STASH_ONE(I, ST, BB)                                                               \
-    {                                                                                              \
+    if (!DMA) {                                                                                    \
         const int ch = tid + 256 * (I);                                                            \
         if (ch < nchunk) {                                                                         \
             const int r = ch / cpr, cc = ch - r * cpr;                                             \
@@ -337,12 +360,14 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + h * 16;
+        const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + (DMA ? 0 : h * 16);
+        const int swz = (col >> 4) & 1;
         if (QREG) {
 #pragma unroll
             for (int sx = 0; sx < KSMAX; ++sx)
                 if (sx < ksteps) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + sx * 32);
+                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(
+                        pbase + (DMA ? ((2 * sx + h) ^ swz) * 16 : sx * 32));
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qreg[sx], acc, 0, 0, 0);
                 }
         } else {
@@ -527,18 +552,35 @@ size_t prefilter_lds_bytes(int Dz)
     return (size_t)(qrows + 2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4 + 4);
 }
 
-template <int ML, bool UPD, bool QREG>
-static void launch_pf2(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
+template <int ML, bool UPD, bool QREG, bool DMA>
+static void launch_pf3(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
                        int *flags64, int nqt64, hipStream_t s)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)prefilter_kernel<ML, UPD, QREG>,
+        (void)hipFuncSetAttribute((const void *)prefilter_kernel<ML, UPD, QREG, DMA>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((prefilter_kernel<ML, UPD, QREG>), dim3(grid), dim3(256), lds, s, a, nqt, total,
-                       stride, flags64, nqt64);
+    hipLaunchKernelGGL((prefilter_kernel<ML, UPD, QREG, DMA>), dim3(grid), dim3(256), lds, s, a, nqt,
+                       total, stride, flags64, nqt64);
+}
+
+static bool use_dma(const PrefilterArgs &a)
+{
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("CHB_PF_DMA"); env = e ? atoi(e) : 1; }
+    return env != 0 && a.packed && a.memb_code == nullptr && ((a.sh.Dz >> 3) & 15) == 2;
+}
+
+template <int ML, bool UPD, bool QREG>
+static void launch_pf2(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
+                       int *flags64, int nqt64, hipStream_t s)
+{
+    if (!UPD && QREG && use_dma(a))
+        launch_pf3<ML, UPD, QREG, true>(a, grid, lds, nqt, total, a.sh.Dz * 2, flags64, nqt64, s);
+    else
+        launch_pf3<ML, UPD, QREG, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
 }
 
 template <int ML, bool UPD>
