@@ -442,3 +442,16 @@ def test_native_comm_exchange_path_world1(O):
         c.comm_destroy()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("N,D,B,m", [(400, 300, 3, 5), (300, 8, 1, 4), (900, 146, 40, 5), (64, 16, 2, 16)])
+def test_fit_cluster_odd_shapes(ctx, O, N, D, B, m):
+    """D > 256 (no bf16 shadow: brute-force selection), a single bin, many bins with few members
+    each, D = 146 (10 coverage columns: 10 MFMA k-steps), m = 16 with bins smaller than m."""
+    S = 10 if D == 146 else 1
+    X, initial, _ = _synth(N, D, B, S=S, seed=D + B, sigma=6e-3, mix=0.5, n_seed=3)
+    perms = _perms(initial, 4)
+    want, its_o, ch_o = O.fit_cluster(X, B, initial, perms, m, 4)
+    ctx.set_samples(X)
+    got, its, ch = ctx.fit_cluster(B, initial, perms, m, 4, batch=150)
+    assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
