@@ -146,9 +146,9 @@ struct chb_ctx {
     DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
     DevBuf<int> perm;
     // two-stage selection: bf16 shadow copy + shortlists
-    DevBuf<unsigned short> Z, Zp;
-    DevBuf<float> znrm, zrho, znrm_p, zrho_p, rho_bin, rho_all;
-    DevBuf<double> colwork;
+    DevBuf<unsigned short> Zs, Zp, Zp2;
+    DevBuf<float> znrm_s, zrho_s, znrm_p, zrho_p, znrm_p2, zrho_p2, rho_bin, rho_bin2, sn_bin, sn_bin2;
+    DevBuf<double> centers;
     int Dz = 0;
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
     bool pf_base = true, pf_update = true;   // developer switches (CHB_PF_BASE / CHB_PF_UPDATE)
@@ -243,6 +243,12 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->flags64.ensure(B * ((K + kQTile - 1) / kQTile)));
         HIPCHK(h->overflow.ensure(1));
         HIPCHK(h->rho_bin.ensure(B));
+        HIPCHK(h->rho_bin2.ensure(B));
+        HIPCHK(h->sn_bin.ensure(B));
+        HIPCHK(h->sn_bin2.ensure(B));
+        HIPCHK(h->Zp2.ensure((2 * K + 64) * (size_t)h->Dz));
+        HIPCHK(h->znrm_p2.ensure(2 * K));
+        HIPCHK(h->zrho_p2.ensure(2 * K));
     }
     h->Kcap = Kcap;
     return CHB_OK;
@@ -265,6 +271,22 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     HIPCHK(h->inb.ensure((size_t)h->N));
     HIPCHK(hipMemcpyAsync(h->labels.p, lab.data(), sizeof(int) * h->N, hipMemcpyHostToDevice, h->stream));
     launch_fill_i32(h->inb.p, -1, (int)h->N, h->stream);
+    HIPCHK(h->cnt.ensure((size_t)B));
+    HIPCHK(h->bin_ptr.ensure((size_t)B + 1));
+    HIPCHK(h->cursor.ensure((size_t)B));
+    HIPCHK(h->memb_id.ensure((size_t)h->N));
+    if (h->use_prefilter && h->shadow_ok) {
+        // Bin centres for the shortlist stage: the mean of each bin's initially labelled members
+        // (the seeds), fixed for the whole fit -- any fixed point keeps the bounds valid, one near
+        // the bin keeps them tight.  Then every labelled sample's shadow row against its own bin.
+        HIPCHK(h->centers.ensure((size_t)B * h->Dp));
+        launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p,
+                           h->memb_id.p, h->stream);
+        launch_bin_centers(h->X.p, h->D, h->Dp, h->memb_id.p, h->bin_ptr.p, h->B, h->centers.p, h->stream);
+        launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
+                             h->Zs.p, h->Dz, h->znrm_s.p, h->zrho_s.p, h->stream);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->fit_open = true; h->batch_open = false; h->Kcap = 0;
     h->overflow_total_valid = false;
@@ -296,17 +318,17 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
         if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
         PrefilterArgs pa{};
-        pa.sh = Shadow{h->Z.p, h->znrm.p, h->zrho.p, h->Dz};
-        // member rows packed in CSR (bin) order: the kernel streams contiguous memory
+        pa.X = h->X.p; pa.D = h->D; pa.Dp = h->Dp;
+        // the members' shadow rows (relative to their bin's centre) gathered into CSR order
         {
             Timed t(h, "bucket", 0.0);
-            launch_pack_shadow(pa.sh, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->Zp.p,
-                               h->znrm_p.p, h->zrho_p.p, s);
+            launch_pack_rows(Shadow{h->Zs.p, h->znrm_s.p, h->zrho_s.p, h->Dz}, h->memb_id.p, h->bin_ptr.p,
+                             h->B, (int)h->N, h->Zp.p, h->znrm_p.p, h->zrho_p.p, s);
+            launch_bin_bounds(h->zrho_p.p, h->znrm_p.p, h->bin_ptr.p, h->B, h->rho_bin.p, h->sn_bin.p, s);
         }
+        pa.centers = h->centers.p;
         pa.shm = Shadow{h->Zp.p, h->znrm_p.p, h->zrho_p.p, h->Dz};
-        pa.packed = true;
-        launch_bin_rho_max(h->zrho_p.p, h->memb_id.p, h->bin_ptr.p, h->B, true, h->rho_bin.p, s);
-        pa.rho_bound = h->rho_bin.p;
+        pa.rho_bound = h->rho_bin.p; pa.sn_bound = h->sn_bin.p;
         pa.bq = h->bq.p; pa.pos_begin = q_lo; pa.pos_end = q_hi;
         pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p;
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
@@ -359,9 +381,13 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             const int nq64 = (hi - lo + kQTile - 1) / kQTile;
             launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
             PrefilterArgs pa{};
-            pa.sh = Shadow{h->Z.p, h->znrm.p, h->zrho.p, h->Dz};
-            pa.shm = pa.sh; pa.packed = false;
-            pa.rho_bound = h->rho_all.p;
+            pa.X = h->X.p; pa.D = h->D; pa.Dp = h->Dp;
+            pa.centers = h->centers.p;   // same centres as the base lists of this batch
+            launch_pack_centered(h->X.p, h->D, h->Dp, h->memb2_id.p, h->bin_ptr2.p, h->B, 2 * h->K,
+                                 h->centers.p, h->Zp2.p, h->Dz, h->znrm_p2.p, h->zrho_p2.p, s);
+            launch_bin_bounds(h->zrho_p2.p, h->znrm_p2.p, h->bin_ptr2.p, h->B, h->rho_bin2.p, h->sn_bin2.p, s);
+            pa.shm = Shadow{h->Zp2.p, h->znrm_p2.p, h->zrho_p2.p, h->Dz};
+            pa.rho_bound = h->rho_bin2.p; pa.sn_bound = h->sn_bin2.p;
             pa.bq = h->bq.p; pa.pos_begin = lo; pa.pos_end = hi;
             pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.memb_code = h->memb2_code.p;
             pa.seed = h->L0();
@@ -426,6 +452,9 @@ int batch_commit_dev(chb_ctx *h, const int *final_dev)
     hipStream_t s = h->stream;
     launch_scatter_labels(h->labels.p, h->bq.p, final_dev, h->K, s);
     launch_mark_batch(h->inb.p, h->bq.p, h->K, 0, s);
+    if (h->use_prefilter && h->shadow_ok && h->centers.p)   // their bin (hence their centre) changed
+        launch_sample_shadow(h->X.p, h->D, h->Dp, h->bq.p, h->K, h->labels.p, h->B, h->centers.p, h->Zs.p,
+                             h->Dz, h->znrm_s.p, h->zrho_s.p, s);
     HIPCHK(hipGetLastError());
     h->batch_open = false;
     return CHB_OK;
@@ -486,8 +515,9 @@ int chb_destroy(chb_ctx *h)
     for (auto *b : ib) b->release();
     DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
-    h->Z.release(); h->znrm.release(); h->zrho.release(); h->colwork.release();
-    h->Zp.release(); h->znrm_p.release(); h->zrho_p.release(); h->rho_bin.release(); h->rho_all.release();
+    h->Zp.release(); h->znrm_p.release(); h->zrho_p.release(); h->rho_bin.release();
+    h->Zs.release(); h->znrm_s.release(); h->zrho_s.release(); h->sn_bin.release(); h->sn_bin2.release();
+    h->Zp2.release(); h->znrm_p2.release(); h->zrho_p2.release(); h->rho_bin2.release(); h->centers.release();
     h->active.release(); h->n_active.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -508,23 +538,16 @@ static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D,
                             h->stream));
     h->N = N; h->D = (int)D; h->Dp = Dp;
     h->fit_open = false; h->batch_open = false;
-    // bf16 shadow copy for the shortlist stage (prefilter_kernels.hip)
+    // the shortlist stage (prefilter_kernels.hip) keeps its query fragments in registers: Dz <= 160
     h->shadow_ok = false;
     const int Dz = (int)((D + 15) / 16) * 16;
-    if (h->use_prefilter && Dz <= 256) {
-        HIPCHK(h->Z.ensure((size_t)N * Dz));
-        HIPCHK(h->znrm.ensure((size_t)N));
-        HIPCHK(h->zrho.ensure((size_t)N));
+    if (h->use_prefilter && Dz <= 160) {
         HIPCHK(h->Zp.ensure((size_t)(N + 64) * Dz));   // + slack: the DMA path reads whole 32-row tiles
         HIPCHK(h->znrm_p.ensure((size_t)N));
         HIPCHK(h->zrho_p.ensure((size_t)N));
-        HIPCHK(h->colwork.ensure((size_t)257 * D));
-        launch_col_sums(h->X.p, (int)N, (int)D, Dp, h->colwork.p, h->stream);
-        launch_build_shadow(h->X.p, (int)N, (int)D, Dp, h->colwork.p + (size_t)256 * D, h->Z.p, Dz,
-                            h->znrm.p, h->zrho.p, h->stream);
-        HIPCHK(h->rho_all.ensure(1));
-        launch_rho_max_all(h->zrho.p, (int)N, h->rho_all.p, h->stream);
-        HIPCHK(hipGetLastError());
+        HIPCHK(h->Zs.ensure((size_t)N * Dz));
+        HIPCHK(h->znrm_s.ensure((size_t)N));
+        HIPCHK(h->zrho_s.ensure((size_t)N));
         h->Dz = Dz;
         h->shadow_ok = true;
     }

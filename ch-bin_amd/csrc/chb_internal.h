@@ -38,30 +38,36 @@ void launch_topm(const TopmArgs &a, hipStream_t s);
 void launch_topm_flagged(const TopmArgs &a, const int *flags64, hipStream_t s);
 
 // ---- two-stage exact selection (prefilter_kernels.hip + rescore in topm_kernels.hip)
-constexpr int kCandCap = 64;   // shortlist capacity per (bin, batch position)
+constexpr int kCandCap = 128;   // shortlist capacity per (bin, batch position)
 
-// Per-sample data of the low-precision shadow copy: centred features rounded to bf16, the exact
-// squared norm of the rounded vector and the exact rounding distance rho = ||zhat - z||.
+// Low-precision shadow rows (one per CSR entry): features minus the bin's centre rounded to bf16,
+// the exact squared norm of the rounded vector and the exact rounding distance rho = ||zhat - z||.
 struct Shadow {
-    const unsigned short *Z;  // [N][Dz] bf16, Dz % 16 == 0, zero padded
-    const float *nrm;         // [N] ||zhat||^2 (rounded up)
-    const float *rho;         // [N] ||zhat - z|| (rounded up)
+    const unsigned short *Z;  // [rows][Dz] bf16, Dz % 16 == 0, zero padded
+    const float *nrm;         // [rows] ||zhat||^2 (rounded up)
+    const float *rho;         // [rows] ||zhat - z|| (rounded up)
     int Dz;
 };
-void launch_col_sums(const double *X, int N, int D, int Dp, double *colsum, hipStream_t s);
-void launch_pack_shadow(const Shadow &src, const int *memb_id, const int *bin_ptr, int B, int n_max,
-                        unsigned short *Zp, float *nrm_p, float *rho_p, hipStream_t s);
-void launch_bin_rho_max(const float *rho, const int *memb_id, const int *bin_ptr, int B, bool packed,
-                        float *out, hipStream_t s);
-void launch_rho_max_all(const float *rho, int N, float *out, hipStream_t s);
-void launch_build_shadow(const double *X, int N, int D, int Dp, const double *colsum,
-                         unsigned short *Z, int Dz, float *nrm, float *rho, hipStream_t s);
+void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
+                        double *centers, hipStream_t s);
+void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
+                          int rows_hint, const double *centers, unsigned short *Zp, int Dz, float *nrm_p,
+                          float *rho_p, hipStream_t s);
+void launch_bin_bounds(const float *rho_p, const float *nrm_p, const int *bin_ptr, int B, float *rho_out,
+                       float *sn_out, hipStream_t s);
+void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, const int *labels,
+                          int B, const double *centers, unsigned short *Zs, int Dz, float *nrm_s,
+                          float *rho_s, hipStream_t s);
+void launch_pack_rows(const Shadow &src, const int *memb_id, const int *bin_ptr, int B, int n_max,
+                      unsigned short *Zp, float *nrm_p, float *rho_p, hipStream_t s);
 
 struct PrefilterArgs {
-    Shadow sh;             // query side, indexed by sample id
-    Shadow shm;            // member side: indexed by sample id, or by CSR entry when `packed`
-    bool packed;
-    const float *rho_bound; // base mode: [B] largest rho among each bin's members; update mode: [1]
+    const double *X;        // [N][Dp] features (queries are centred and rounded inside the kernel)
+    int D, Dp;
+    const double *centers;  // [B][Dp] centre of every bin (any fixed point is valid; member mean used)
+    Shadow shm;             // member rows relative to their bin's centre, packed in CSR order
+    const float *rho_bound; // [B] largest rho among each bin's packed members
+    const float *sn_bound;  // [B] largest ||zh|| among each bin's packed members
     const int *bq;
     int pos_begin, pos_end;
     const int *bin_ptr;

@@ -8,8 +8,13 @@
 // cdist-rounded distance on the shortlist only.  The final result is bit-identical to the
 // brute-force path (and is checked against it in tests/).
 //
-// Guarantee.  Let z = x - mu (any fixed centre mu), zh = bf16(z) and rho_p = ||zh_p - z_p||_2,
-// measured exactly per sample when the shadow copy is built.  By the triangle inequality
+// Guarantee.  For the members of bin c and the queries examined against bin c let z = x - mu_c
+// (mu_c = any fixed centre; the mean of the bin's current members is used, so member vectors are
+// small and the bf16 rounding error is RELATIVE to the within-bin spread, whatever the absolute
+// scale of the features -- coverage columns of magnitude 0.2 next to k-mer frequencies of 0.007
+// included), zh = bf16(z) and rho = ||zh - z||_2, measured exactly when the shadow row is built
+// (members: once per batch in pack_centered_kernel; queries: in the kernel prologue).  By the
+// triangle inequality
 //     | ||x_j - x_p|| - ||zh_j - zh_p|| |  <=  rho_j + rho_p .
 // ||zh_j - zh_p||^2 = n_j + n_p - 2 <zh_j, zh_p> with n = ||zh||^2 exact and the dot product from
 // v_mfma_f32_32x32x16_bf16 (bf16 products are exact in fp32; accumulation error <= g (n_j + n_p)
@@ -47,29 +52,6 @@ constexpr float kSlack = 1e-6f;
 constexpr int kPfQ = 128;  // batch positions per workgroup (32 per wavefront)
 constexpr int kPfP = 32;   // members per tile
 
-__global__ void col_partial_kernel(const double *X, int N, int D, int Dp, int rows_per_block,
-                                   double *partial)
-{
-    const int k = threadIdx.x;
-    const int r0 = blockIdx.x * rows_per_block;
-    int r1 = r0 + rows_per_block;
-    if (r1 > N) r1 = N;
-    for (int kk = k; kk < D; kk += blockDim.x) {
-        double s = 0.0;
-        for (int r = r0; r < r1; ++r) s += X[(size_t)r * Dp + kk];
-        partial[(size_t)blockIdx.x * D + kk] = s;
-    }
-}
-
-__global__ void col_final_kernel(const double *partial, int nblocks, int D, int N, double *colmean)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= D) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * D + k];
-    colmean[k] = s / (double)N;
-}
-
 __device__ __forceinline__ float round_up_f32(double v)
 {
     float f = (float)v;
@@ -77,27 +59,92 @@ __device__ __forceinline__ float round_up_f32(double v)
     return f;
 }
 
-// one wavefront per sample
-__global__ __launch_bounds__(64) void build_shadow_kernel(const double *X, int N, int D, int Dp,
-                                                          const double *mu, unsigned short *Z,
-                                                          int Dz, float *nrm, float *rho)
+__device__ __forceinline__ unsigned short bf16_rn(float zf)
 {
-    const int p = blockIdx.x;
-    const int lane = threadIdx.x;
+    unsigned int u = __float_as_uint(zf);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;   // round-to-nearest-even
+    return (unsigned short)u;
+}
+
+// centers[c][k] = mean over the members of bin c (0 for an empty bin); one block per bin, a thread
+// per feature, members in CSR order
+__global__ __launch_bounds__(256) void bin_center_kernel(const double *X, int D, int Dp,
+                                                         const int *memb_id, const int *bin_ptr,
+                                                         double *centers)
+{
+    const int c = blockIdx.x;
+    const int b = bin_ptr[c], e = bin_ptr[c + 1];
+    for (int k = threadIdx.x; k < Dp; k += 256) {
+        double s = 0.0;
+        if (k < D)
+            for (int i = b; i < e; ++i) s += X[(size_t)memb_id[i] * Dp + k];
+        centers[(size_t)c * Dp + k] = e > b ? s / (double)(e - b) : 0.0;
+    }
+}
+
+// Shadow rows of the CSR-ordered members, relative to their bin's centre, stored contiguously in
+// CSR order (the shortlist kernel streams plain sequential memory).  One wavefront per member.
+__global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int D, int Dp,
+                                                            const int *memb_id, const int *bin_ptr,
+                                                            const double *centers, unsigned short *Zp,
+                                                            int Dz, float *nrm_p, float *rho_p)
+{
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double *mu = centers + (size_t)c * Dp;
+    for (int e = bin_ptr[c] + blockIdx.y * 4 + w; e < bin_ptr[c + 1]; e += gridDim.y * 4) {
+        const double *x = X + (size_t)memb_id[e] * Dp;
+        double n2 = 0.0, e2 = 0.0;
+        for (int k = lane; k < Dz; k += 64) {
+            unsigned short hb = 0;
+            if (k < D) {
+                const double z = x[k] - mu[k];
+                hb = bf16_rn((float)z);
+                const double zh = (double)__uint_as_float(((unsigned int)hb) << 16);
+                n2 += zh * zh;
+                e2 += (zh - z) * (zh - z);
+            }
+            Zp[(size_t)e * Dz + k] = hb;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            n2 += __shfl_xor(n2, off, 64);
+            e2 += __shfl_xor(e2, off, 64);
+        }
+        if (lane == 0) {
+            nrm_p[e] = round_up_f32(n2 * (1.0 + 1e-12));
+            rho_p[e] = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
+        }
+    }
+}
+
+// Per-sample shadow rows relative to the centre of the sample's CURRENT bin (labels[p] >= 0).
+// ids == nullptr: all samples 0..n-1; otherwise the n listed samples (the batch just committed).
+// One wavefront per sample.
+__global__ __launch_bounds__(256) void sample_shadow_kernel(const double *X, int D, int Dp, const int *ids,
+                                                            int n, const int *labels, int B,
+                                                            const double *centers, unsigned short *Zs,
+                                                            int Dz, float *nrm_s, float *rho_s)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int p = ids ? ids[i] : i;
+    const int c = labels[p];
+    if (c < 0 || c >= B) return;
+    const double *mu = centers + (size_t)c * Dp;
+    const double *x = X + (size_t)p * Dp;
     double n2 = 0.0, e2 = 0.0;
     for (int k = lane; k < Dz; k += 64) {
         unsigned short hb = 0;
         if (k < D) {
-            const double z = X[(size_t)p * Dp + k] - mu[k];
-            const float zf = (float)z;
-            unsigned int u = __float_as_uint(zf);
-            u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;   // round-to-nearest-even to bf16
-            hb = (unsigned short)u;
+            const double z = x[k] - mu[k];
+            hb = bf16_rn((float)z);
             const double zh = (double)__uint_as_float(((unsigned int)hb) << 16);
             n2 += zh * zh;
             e2 += (zh - z) * (zh - z);
         }
-        Z[(size_t)p * Dz + k] = hb;
+        Zs[(size_t)p * Dz + k] = hb;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -105,17 +152,16 @@ __global__ __launch_bounds__(64) void build_shadow_kernel(const double *X, int N
         e2 += __shfl_xor(e2, off, 64);
     }
     if (lane == 0) {
-        nrm[p] = round_up_f32(n2 * (1.0 + 1e-12));
-        rho[p] = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
+        nrm_s[p] = round_up_f32(n2 * (1.0 + 1e-12));
+        rho_s[p] = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
     }
 }
 
-// Copies the shadow rows of the CSR-ordered members into contiguous storage so that the shortlist
-// kernel streams plain sequential memory (no dependent index -> row load chain in its pipeline).
-__global__ __launch_bounds__(256) void pack_shadow_kernel(const unsigned short *Z, const float *nrm,
-                                                          const float *rho, int Dz, const int *memb_id,
-                                                          const int *bin_ptr, int B,
-                                                          unsigned short *Zp, float *nrm_p, float *rho_p)
+// Gathers the per-sample shadow rows of the CSR-ordered members into contiguous storage.
+__global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs, const float *nrm_s,
+                                                        const float *rho_s, int Dz, const int *memb_id,
+                                                        const int *bin_ptr, int B, unsigned short *Zp,
+                                                        float *nrm_p, float *rho_p)
 {
     const int total = bin_ptr[B];
     const int cpr = Dz >> 3;
@@ -125,42 +171,36 @@ __global__ __launch_bounds__(256) void pack_shadow_kernel(const unsigned short *
         const int e = (int)(ch / cpr), cc = (int)(ch - (long long)e * cpr);
         const int id = memb_id[e];
         *reinterpret_cast<uint4 *>(Zp + (size_t)e * Dz + cc * 8) =
-            *reinterpret_cast<const uint4 *>(Z + (size_t)id * Dz + cc * 8);
-        if (cc == 0) { nrm_p[e] = nrm[id]; rho_p[e] = rho[id]; }
+            *reinterpret_cast<const uint4 *>(Zs + (size_t)id * Dz + cc * 8);
+        if (cc == 0) { nrm_p[e] = nrm_s[id]; rho_p[e] = rho_s[id]; }
     }
 }
 
-// rho_bound[c] = largest rounding distance among the members of bin c (one block per bin)
-__global__ __launch_bounds__(256) void bin_rho_max_kernel(const float *rho, const int *memb_id,
-                                                          const int *bin_ptr, bool packed, float *out)
+// rho_bound[c] = largest rounding distance, sn_bound[c] = largest ||zh|| among the (packed) members
+// of bin c; one block per bin
+__global__ __launch_bounds__(256) void bin_bounds_kernel(const float *rho_p, const float *nrm_p,
+                                                         const int *bin_ptr, float *rho_out, float *sn_out)
 {
-    __shared__ float red[256];
+    __shared__ float red[256], red2[256];
     const int c = blockIdx.x;
-    float v = 0.f;
-    for (int e = bin_ptr[c] + threadIdx.x; e < bin_ptr[c + 1]; e += 256)
-        v = fmaxf(v, rho[packed ? e : memb_id[e]]);
-    red[threadIdx.x] = v;
+    float v = 0.f, u = 0.f;
+    for (int e = bin_ptr[c] + threadIdx.x; e < bin_ptr[c + 1]; e += 256) {
+        v = fmaxf(v, rho_p[e]);
+        u = fmaxf(u, nrm_p[e]);
+    }
+    red[threadIdx.x] = v; red2[threadIdx.x] = u;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+        if ((int)threadIdx.x < off) {
+            red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+            red2[threadIdx.x] = fmaxf(red2[threadIdx.x], red2[threadIdx.x + off]);
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[c] = red[0];
-}
-
-// out[0] = largest rho over all samples
-__global__ __launch_bounds__(256) void rho_max_all_kernel(const float *rho, int N, float *out)
-{
-    __shared__ float red[256];
-    float v = 0.f;
-    for (int p = threadIdx.x; p < N; p += 256) v = fmaxf(v, rho[p]);
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        rho_out[c] = red[0];
+        sn_out[c] = sqrtf(red2[0]) * (1.0f + 1e-6f);
     }
-    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 template <int ML>
@@ -178,20 +218,20 @@ __device__ __forceinline__ void list_insert(float (&l)[ML], float v)
 // UPD = true : the batch's own members (eligibility code per member, see aux_kernels.hip) against a
 //              FIXED tau = the exact m-th distance of the already known list `seed`; members that
 //              cannot displace a list entry are dropped without ever touching fp64.
-// QREG = true : the query fragments (B operand) live in registers for the whole kernel (Dz <= 160);
-//               LDS then only holds the double-buffered member tile, so 6-8 workgroups fit a CU.
+// The query fragments (B operand) are built in the prologue (x_j - mu_c -> bf16, with the exact
+// ||zh||^2 and rho of THIS query against THIS bin's centre) and live in registers for the whole
+// kernel (Dz <= 160); LDS only holds the double-buffered member tile.
 // DMA  = true : member tiles go global -> LDS directly (global_load_lds_dwordx4, no staging
 //               registers, no ds_write); needs packed rows and 18 chunks per row (Dz = 144).  The LDS
 //               image is unpadded and XOR-swizzled through the SOURCE address (chunk c of row r sits
 //               at c ^ ((r >> 4) & 1)), which makes the ds_read_b128 fragment reads conflict-free.
-template <int ML, bool UPD, bool QREG, bool DMA>
+template <int ML, bool UPD, bool DMA>
 __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
                                                         int stride, int *flags64, int nqt64)
 {
     constexpr int KSMAX = 10;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sQz = smem;                               // [kPfQ][stride] (absent when QREG)
-    unsigned char *sPz = sQz + (QREG ? 0 : (size_t)kPfQ * stride);   // [2][kPfP][stride]
+    unsigned char *sPz = smem;                               // [2][kPfP][stride]
     float *sPn = reinterpret_cast<float *>(sPz + (size_t)2 * kPfP * stride);  // [2][kPfP]
     float *sPr = sPn + 2 * kPfP;                             // [2][kPfP]
     int *sPid = reinterpret_cast<int *>(sPr + 2 * kPfP);     // [2][kPfP]
@@ -207,7 +247,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
     const int mb = a.bin_ptr[c];
     const int nmem = a.bin_ptr[c + 1] - mb;
     const int pos0 = a.pos_begin + qt * kPfQ;
-    const int Dz = a.sh.Dz;
+    const int Dz = a.shm.Dz;
     const int cpr = Dz >> 3;            // 16-byte chunks per row
     const int ksteps = Dz >> 4;
     const int m = a.m;
@@ -216,28 +256,52 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
     const int qpos = pos0 + 32 * w + col;
     const bool qvalid = qpos < a.pos_end;
     const int qid = a.bq[qvalid ? qpos : a.pos_end - 1];
-    const float nj = a.sh.nrm[qid];
-    const float rq = a.sh.rho[qid];
-    const float nj_hi = nj * (1.0f + kGamma) * (1.0f + kSlack);
-    const float nj_lo = nj * (1.0f - kGamma) * (1.0f - kSlack);
-
+    // Query fragment: lane (col, h) owns B[k = 16 s + 8 h + j][col] = bf16(x_j[k] - mu_c[k]).
+    using s16x8 = __attribute__((ext_vector_type(8))) short;
     bf16x8 qreg[KSMAX];
-    if (QREG) {
-        // lane (col, h) owns B[k = 16 s + 8 h + j][col]: 16 bytes of its query row per k-step
+    float nj, rq, njx_up, njx_dn;
+    {
+        const double *xq = a.X + (size_t)qid * a.Dp;
+        const double *mu = a.centers + (size_t)c * a.Dp;
+        double n2 = 0.0, e2 = 0.0, x2 = 0.0;
 #pragma unroll
-        for (int sx = 0; sx < KSMAX; ++sx)
-            if (sx < ksteps)
-                qreg[sx] = *reinterpret_cast<const bf16x8 *>(a.sh.Z + (size_t)qid * Dz + sx * 16 + h * 8);
-    } else {
-        // stage the 128 query rows
-        for (int ch = tid; ch < kPfQ * cpr; ch += 256) {
-            const int r = ch / cpr, cc = ch - r * cpr;
-            int sp = pos0 + r;
-            if (sp >= a.pos_end) sp = a.pos_end - 1;
-            const uint4 v = *reinterpret_cast<const uint4 *>(a.sh.Z + (size_t)a.bq[sp] * Dz + cc * 8);
-            *reinterpret_cast<uint4 *>(sQz + (size_t)r * stride + cc * 16) = v;
+        for (int sx = 0; sx < KSMAX; ++sx) {
+            s16x8 bits = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (sx < ksteps) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * sx + 8 * h + j;
+                    if (k < a.D) {
+                        const double z = xq[k] - mu[k];
+                        const unsigned short hb = bf16_rn((float)z);
+                        const double zh = (double)__uint_as_float(((unsigned int)hb) << 16);
+                        n2 += zh * zh;
+                        e2 += (zh - z) * (zh - z);
+                        x2 += z * z;
+                        bits[j] = (short)hb;
+                    }
+                }
+            }
+            qreg[sx] = __builtin_bit_cast(bf16x8, bits);
         }
+        n2 += __shfl_xor(n2, 32, 64);
+        e2 += __shfl_xor(e2, 32, 64);
+        x2 += __shfl_xor(x2, 32, 64);
+        nj = round_up_f32(n2 * (1.0 + 1e-12));
+        rq = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
+        njx_up = round_up_f32(x2 * (1.0 + 1e-12));
+        njx_dn = (float)(x2 * (1.0 - 1e-6));
     }
+    // Bounds.  With z_j EXACT on the query side:
+    //   ||z_j - zh_p||^2 = ||z_j||^2 + n_p - 2 <z_j, zh_p>,   <z_j, zh_p> = <zh_j, zh_p> + <z_j - zh_j, zh_p>,
+    //   |<z_j - zh_j, zh_p>| <= rho_j sqrt(n_p) <= rho_j * snb   (snb = largest ||zh_p|| in the bin),
+    // so the query's rounding error is damped by the (small) norm of the bin-centred member instead
+    // of entering the distance at full size -- what keeps far bins, whose members are all almost
+    // equally far, from flooding the shortlist.  The matrix-core accumulation error is bounded by
+    // g (n_j + n_p) as before; the member's own rounding enters as +-rho_p <= rho_bin on d.
+    const float Aq = (2.0f * rq * a.sn_bound[c] + kGamma * nj) * (1.0f + 4.0f * kSlack);
+    const float nj_hi = (njx_up + Aq) * (1.0f + kSlack);
+    const float nj_lo = (njx_dn - Aq) * (njx_dn > Aq ? (1.0f - kSlack) : (1.0f + kSlack));
 
     float ub[ML];
 #pragma unroll
@@ -291,7 +355,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         if (ch < nchunk) {                                                                         \
             const int r = ch / cpr, cc = ch - r * cpr;                                             \
             const int e = (TT) * kPfP + r;                                                         \
-            const int id = e < nmem ? (a.packed ? mb + e : a.memb_id[mb + e]) : 0;                 \
+            const int id = e < nmem ? mb + e : mb;                                                 \
             ST = *reinterpret_cast<const uint4 *>(a.shm.Z + (size_t)id * Dz + cc * 8);            \
         }                                                                                          \
     }
@@ -313,7 +377,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
             const int e = (TT) * kPfP + tid;                                                       \
             if (e < nmem) {                                                                        \
                 id##X = a.memb_id[mb + e];                                                         \
-                n##X = a.shm.nrm[a.packed ? mb + e : id##X];                                       \
+                n##X = a.shm.nrm[mb + e];                                                          \
                 code##X = UPD ? a.memb_code[mb + e] : 0;                                           \
             } else {                                                                               \
                 id##X = -1; n##X = INFINITY; code##X = 0;                                          \
@@ -333,7 +397,6 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         }                                                                                          \
     }
 
-    const unsigned char *qbase = sQz + (size_t)(32 * w + col) * stride + h * 16;
     const size_t slot = (size_t)c * a.Kcap + qpos;
     int *cand = a.cand + slot * kCandCap;
 
@@ -342,7 +405,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
     // error interval reaches below it (about m + a handful) instead of everything that passed a
     // still-loose running threshold.  The matrix-core work is cheap enough to do twice.
     // rho_j + (largest rho of any member this kernel can meet): constant per (query, bin)
-    const float rsum = (rq + a.rho_bound[UPD ? 0 : c]) * (1.0f + kSlack);
+    const float rsum = a.rho_bound[c] * (1.0f + kSlack);
     float thr = INFINITY;   // sweep 0: m-th smallest t1 so far
     float C2 = FLT_MAX;     // sweep 1: admission bound on t2
     if (UPD && tau < INFINITY) {
@@ -362,21 +425,13 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + (DMA ? 0 : h * 16);
         const int swz = (col >> 4) & 1;
-        if (QREG) {
 #pragma unroll
-            for (int sx = 0; sx < KSMAX; ++sx)
-                if (sx < ksteps) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(
-                        pbase + (DMA ? ((2 * sx + h) ^ swz) * 16 : sx * 32));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qreg[sx], acc, 0, 0, 0);
-                }
-        } else {
-            for (int sx = 0; sx < ksteps; ++sx) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + sx * 32);
-                const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(qbase + sx * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+        for (int sx = 0; sx < KSMAX; ++sx)
+            if (sx < ksteps) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(
+                    pbase + (DMA ? ((2 * sx + h) ^ swz) * 16 : sx * 32));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qreg[sx], acc, 0, 0, 0);
             }
-        }
 
         // rows held by this lane: (r&3) + 8*(r>>2) + 4*h
         float np[16];
@@ -495,100 +550,77 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
 
 }  // namespace
 
-void launch_col_sums(const double *X, int N, int D, int Dp, double *work, hipStream_t s)
+void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
+                        double *centers, hipStream_t s)
 {
-    // work: [nblocks*D partials][D means]
-    const int nblocks = 256;
-    const int rpb = (N + nblocks - 1) / nblocks;
-    double *partial = work;
-    double *mean = work + (size_t)nblocks * D;
-    hipLaunchKernelGGL(col_partial_kernel, dim3(nblocks), dim3(256), 0, s, X, N, D, Dp, rpb, partial);
-    hipLaunchKernelGGL(col_final_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partial, nblocks, D, N, mean);
+    if (B > 0) hipLaunchKernelGGL(bin_center_kernel, dim3(B), dim3(256), 0, s, X, D, Dp, memb_id, bin_ptr, centers);
 }
 
-void launch_build_shadow(const double *X, int N, int D, int Dp, const double *colmean,
-                         unsigned short *Z, int Dz, float *nrm, float *rho, hipStream_t s)
+void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
+                          int rows_hint, const double *centers, unsigned short *Zp, int Dz, float *nrm_p,
+                          float *rho_p, hipStream_t s)
 {
-    hipLaunchKernelGGL(build_shadow_kernel, dim3(N), dim3(64), 0, s, X, N, D, Dp, colmean, Z, Dz, nrm, rho);
+    if (B <= 0) return;
+    int gy = (rows_hint / std::max(B, 1) + 15) / 16;   // ~4 members per wavefront per bin
+    gy = std::max(1, std::min(gy, 64));
+    hipLaunchKernelGGL(pack_centered_kernel, dim3(B, gy), dim3(256), 0, s, X, D, Dp, memb_id, bin_ptr,
+                       centers, Zp, Dz, nrm_p, rho_p);
 }
 
-#undef CHB_PF_FETCH_ONE
-#undef CHB_PF_STASH_ONE
-#undef CHB_PF_FETCH
-#undef CHB_PF_STASH
-
-static bool use_qreg(int Dz)
+void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, const int *labels,
+                          int B, const double *centers, unsigned short *Zs, int Dz, float *nrm_s,
+                          float *rho_s, hipStream_t s)
 {
-    static int env = -1;
-    if (env < 0) { const char *e = getenv("CHB_PF_QREG"); env = e ? atoi(e) : 1; }
-    return env != 0 && Dz <= 160;   // queries in registers up to 10 k-steps
+    if (n > 0)
+        hipLaunchKernelGGL(sample_shadow_kernel, dim3((n + 3) / 4), dim3(256), 0, s, X, D, Dp, ids, n, labels,
+                           B, centers, Zs, Dz, nrm_s, rho_s);
 }
 
-void launch_pack_shadow(const Shadow &src, const int *memb_id, const int *bin_ptr, int B, int n_max,
-                        unsigned short *Zp, float *nrm_p, float *rho_p, hipStream_t s)
+void launch_pack_rows(const Shadow &src, const int *memb_id, const int *bin_ptr, int B, int n_max,
+                      unsigned short *Zp, float *nrm_p, float *rho_p, hipStream_t s)
 {
     if (n_max <= 0) return;
     long long nch = (long long)n_max * (src.Dz >> 3);
     int grid = (int)std::min<long long>((nch + 255) / 256, 8192);
-    hipLaunchKernelGGL(pack_shadow_kernel, dim3(grid), dim3(256), 0, s, src.Z, src.nrm, src.rho, src.Dz,
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(256), 0, s, src.Z, src.nrm, src.rho, src.Dz,
                        memb_id, bin_ptr, B, Zp, nrm_p, rho_p);
 }
 
-void launch_bin_rho_max(const float *rho, const int *memb_id, const int *bin_ptr, int B, bool packed,
-                        float *out, hipStream_t s)
+void launch_bin_bounds(const float *rho_p, const float *nrm_p, const int *bin_ptr, int B, float *rho_out,
+                       float *sn_out, hipStream_t s)
 {
-    if (B > 0) hipLaunchKernelGGL(bin_rho_max_kernel, dim3(B), dim3(256), 0, s, rho, memb_id, bin_ptr, packed, out);
-}
-
-void launch_rho_max_all(const float *rho, int N, float *out, hipStream_t s)
-{
-    hipLaunchKernelGGL(rho_max_all_kernel, dim3(1), dim3(256), 0, s, rho, N, out);
+    if (B > 0) hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, rho_p, nrm_p, bin_ptr, rho_out, sn_out);
 }
 
 size_t prefilter_lds_bytes(int Dz)
 {
     const int stride = Dz * 2 + 16;
-    const int qrows = use_qreg(Dz) ? 0 : kPfQ;
-    return (size_t)(qrows + 2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4 + 4);
+    return (size_t)(2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4 + 4);
 }
 
-template <int ML, bool UPD, bool QREG, bool DMA>
+template <int ML, bool UPD, bool DMA>
 static void launch_pf3(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
                        int *flags64, int nqt64, hipStream_t s)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)prefilter_kernel<ML, UPD, QREG, DMA>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((prefilter_kernel<ML, UPD, QREG, DMA>), dim3(grid), dim3(256), lds, s, a, nqt,
-                       total, stride, flags64, nqt64);
+    hipLaunchKernelGGL((prefilter_kernel<ML, UPD, DMA>), dim3(grid), dim3(256), lds, s, a, nqt, total,
+                       stride, flags64, nqt64);
 }
 
 static bool use_dma(const PrefilterArgs &a)
 {
     static int env = -1;
     if (env < 0) { const char *e = getenv("CHB_PF_DMA"); env = e ? atoi(e) : 1; }
-    return env != 0 && a.packed && a.memb_code == nullptr && ((a.sh.Dz >> 3) & 15) == 2;
-}
-
-template <int ML, bool UPD, bool QREG>
-static void launch_pf2(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
-                       int *flags64, int nqt64, hipStream_t s)
-{
-    if (!UPD && QREG && use_dma(a))
-        launch_pf3<ML, UPD, QREG, true>(a, grid, lds, nqt, total, a.sh.Dz * 2, flags64, nqt64, s);
-    else
-        launch_pf3<ML, UPD, QREG, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
+    return env != 0 && ((a.shm.Dz >> 3) & 15) == 2;
 }
 
 template <int ML, bool UPD>
 static void launch_pf(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
                       int *flags64, int nqt64, hipStream_t s)
 {
-    if (use_qreg(a.sh.Dz)) launch_pf2<ML, UPD, true>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
-    else launch_pf2<ML, UPD, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
+    if (use_dma(a))
+        launch_pf3<ML, UPD, true>(a, grid, lds, nqt, total, a.shm.Dz * 2, flags64, nqt64, s);
+    else
+        launch_pf3<ML, UPD, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
 }
 
 void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s)
@@ -598,8 +630,8 @@ void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s)
     const int nqt = (nq + kPfQ - 1) / kPfQ;
     const int total = nqt * a.B;
     const int grid = ((total + 7) / 8) * 8;
-    const int stride = a.sh.Dz * 2 + 16;
-    const size_t lds = prefilter_lds_bytes(a.sh.Dz);
+    const int stride = a.shm.Dz * 2 + 16;
+    const size_t lds = prefilter_lds_bytes(a.shm.Dz);
     const int nqt64 = (nq + kQTile - 1) / kQTile;
     if (a.memb_code != nullptr) {
         launch_pf<1, true>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
