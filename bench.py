@@ -127,7 +127,7 @@ def main():
     ms_per_step = dt / max(args.steps, 1) * 1e3
     value = qp_per_step * args.steps / dt
 
-    prof = {k: ctx.profile_get(k) for k in ("prefilter", "rescore", "prefilter_update", "rescore_update",
+    prof = {k: ctx.profile_get(k) for k in ("prefilter", "rescore", "prefilter_update", "rescore_update", "query_shadow",
                                             "topm_fallback", "topm_base", "topm_update", "hull_qp", "argmin",
                                             "bucket")}
     stats = ctx.fit_stats()
@@ -160,7 +160,8 @@ def main():
                          "total_ms": p["ms"], "pairs_per_s": p["work"] / (p["ms"] * 1e-3),
                          "note": "bf16 v_mfma_f32_32x32x16 shortlist; selection (VALU) and LDS "
                                  "staging, not the matrix core, set its time"})
-        for name in ("rescore", "prefilter_update", "rescore_update", "topm_fallback", "argmin", "bucket"):
+        for name in ("rescore", "prefilter_update", "rescore_update", "query_shadow", "topm_fallback", "argmin",
+                     "bucket"):
             p = prof[name]
             if p["launches"]:
                 kern.append({"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,

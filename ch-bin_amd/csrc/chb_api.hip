@@ -146,7 +146,8 @@ struct chb_ctx {
     DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
     DevBuf<int> perm;
     // two-stage selection: bf16 shadow copy + shortlists
-    DevBuf<unsigned short> Zs, Zp, Zp2;
+    DevBuf<unsigned short> Zs, Zp, Zp2, Zq;
+    DevBuf<float> qs;
     DevBuf<float> znrm_s, zrho_s, znrm_p, zrho_p, znrm_p2, zrho_p2, rho_bin, rho_bin2, sn_bin, sn_bin2;
     DevBuf<double> centers;
     int Dz = 0;
@@ -246,6 +247,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->rho_bin2.ensure(B));
         HIPCHK(h->sn_bin.ensure(B));
         HIPCHK(h->sn_bin2.ensure(B));
+        HIPCHK(h->Zq.ensure(K * B * (size_t)h->Dz));
+        HIPCHK(h->qs.ensure(K * B * 4));
         HIPCHK(h->Zp2.ensure((2 * K + 64) * (size_t)h->Dz));
         HIPCHK(h->znrm_p2.ensure(2 * K));
         HIPCHK(h->zrho_p2.ensure(2 * K));
@@ -318,7 +321,12 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
         if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
         PrefilterArgs pa{};
-        pa.X = h->X.p; pa.D = h->D; pa.Dp = h->Dp;
+        {
+            Timed t(h, "query_shadow", (double)(q_hi - q_lo) * h->B);
+            launch_query_shadow(h->X.p, h->D, h->Dp, h->bq.p, q_lo, q_hi, h->B, h->Kcap, h->centers.p, h->Zq.p,
+                                h->Dz, h->qs.p, s);
+        }
+        pa.Zq = h->Zq.p; pa.qs = reinterpret_cast<const float4 *>(h->qs.p);
         // the members' shadow rows (relative to their bin's centre) gathered into CSR order
         {
             Timed t(h, "bucket", 0.0);
@@ -326,7 +334,6 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
                              h->B, (int)h->N, h->Zp.p, h->znrm_p.p, h->zrho_p.p, s);
             launch_bin_bounds(h->zrho_p.p, h->znrm_p.p, h->bin_ptr.p, h->B, h->rho_bin.p, h->sn_bin.p, s);
         }
-        pa.centers = h->centers.p;
         pa.shm = Shadow{h->Zp.p, h->znrm_p.p, h->zrho_p.p, h->Dz};
         pa.rho_bound = h->rho_bin.p; pa.sn_bound = h->sn_bin.p;
         pa.bq = h->bq.p; pa.pos_begin = q_lo; pa.pos_end = q_hi;
@@ -381,8 +388,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             const int nq64 = (hi - lo + kQTile - 1) / kQTile;
             launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
             PrefilterArgs pa{};
-            pa.X = h->X.p; pa.D = h->D; pa.Dp = h->Dp;
-            pa.centers = h->centers.p;   // same centres as the base lists of this batch
+            pa.Zq = h->Zq.p; pa.qs = reinterpret_cast<const float4 *>(h->qs.p);   // built at batch start
             launch_pack_centered(h->X.p, h->D, h->Dp, h->memb2_id.p, h->bin_ptr2.p, h->B, 2 * h->K,
                                  h->centers.p, h->Zp2.p, h->Dz, h->znrm_p2.p, h->zrho_p2.p, s);
             launch_bin_bounds(h->zrho_p2.p, h->znrm_p2.p, h->bin_ptr2.p, h->B, h->rho_bin2.p, h->sn_bin2.p, s);
@@ -517,6 +523,7 @@ int chb_destroy(chb_ctx *h)
     for (auto *b : db) b->release();
     h->Zp.release(); h->znrm_p.release(); h->zrho_p.release(); h->rho_bin.release();
     h->Zs.release(); h->znrm_s.release(); h->zrho_s.release(); h->sn_bin.release(); h->sn_bin2.release();
+    h->Zq.release(); h->qs.release();
     h->Zp2.release(); h->znrm_p2.release(); h->zrho_p2.release(); h->rho_bin2.release(); h->centers.release();
     h->active.release(); h->n_active.release();
     (void)hipStreamDestroy(h->stream);

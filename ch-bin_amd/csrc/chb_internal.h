@@ -53,6 +53,9 @@ void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, cons
 void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
                           int rows_hint, const double *centers, unsigned short *Zp, int Dz, float *nrm_p,
                           float *rho_p, hipStream_t s);
+void launch_query_shadow(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
+                         int Kcap, const double *centers, unsigned short *Zq, int Dz, void *qs,
+                         hipStream_t s);
 void launch_bin_bounds(const float *rho_p, const float *nrm_p, const int *bin_ptr, int B, float *rho_out,
                        float *sn_out, hipStream_t s);
 void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, const int *labels,
@@ -62,9 +65,8 @@ void launch_pack_rows(const Shadow &src, const int *memb_id, const int *bin_ptr,
                       unsigned short *Zp, float *nrm_p, float *rho_p, hipStream_t s);
 
 struct PrefilterArgs {
-    const double *X;        // [N][Dp] features (queries are centred and rounded inside the kernel)
-    int D, Dp;
-    const double *centers;  // [B][Dp] centre of every bin (any fixed point is valid; member mean used)
+    const unsigned short *Zq; // [B][Kcap][Dz] query shadow rows bf16(x_j - mu_c) (query_shadow_kernel)
+    const float4 *qs;         // [B][Kcap] {||zh||^2, rho, ||z||^2 up, ||z||^2 down} of that row
     Shadow shm;             // member rows relative to their bin's centre, packed in CSR order
     const float *rho_bound; // [B] largest rho among each bin's packed members
     const float *sn_bound;  // [B] largest ||zh|| among each bin's packed members

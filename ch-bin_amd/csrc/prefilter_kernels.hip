@@ -176,6 +176,52 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs
     }
 }
 
+// Query-side shadow rows, one per (batch position, bin): bf16(x_j - mu_c) plus the four scalars
+// the bounds need {||zh||^2, rho, ||z||^2 rounded up, ||z||^2 rounded down}.  One wavefront per
+// row, lanes along the features (coalesced); computed once per batch and shared by the base and
+// the update shortlist launches.
+__global__ __launch_bounds__(256) void query_shadow_kernel(const double *X, int D, int Dp, const int *bq,
+                                                           int pos_begin, int pos_end, int B, int Kcap,
+                                                           const double *centers, unsigned short *Zq,
+                                                           int Dz, float4 *qs)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nrow = (long long)(pos_end - pos_begin) * B;
+    if (row >= nrow) return;
+    const int pos = pos_begin + (int)(row / B), c = (int)(row - (row / B) * B);
+    const double *x = X + (size_t)bq[pos] * Dp;
+    const double *mu = centers + (size_t)c * Dp;
+    const size_t slot = (size_t)c * Kcap + pos;
+    double n2 = 0.0, e2 = 0.0, x2 = 0.0;
+    for (int k = lane; k < Dz; k += 64) {
+        unsigned short hb = 0;
+        if (k < D) {
+            const double z = x[k] - mu[k];
+            hb = bf16_rn((float)z);
+            const double zh = (double)__uint_as_float(((unsigned int)hb) << 16);
+            n2 += zh * zh;
+            e2 += (zh - z) * (zh - z);
+            x2 += z * z;
+        }
+        Zq[slot * Dz + k] = hb;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        n2 += __shfl_xor(n2, off, 64);
+        e2 += __shfl_xor(e2, off, 64);
+        x2 += __shfl_xor(x2, off, 64);
+    }
+    if (lane == 0) {
+        float4 o;
+        o.x = round_up_f32(n2 * (1.0 + 1e-12));
+        o.y = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
+        o.z = round_up_f32(x2 * (1.0 + 1e-12));
+        o.w = (float)(x2 * (1.0 - 1e-6));
+        qs[slot] = o;
+    }
+}
+
 // rho_bound[c] = largest rounding distance, sn_bound[c] = largest ||zh|| among the (packed) members
 // of bin c; one block per bin
 __global__ __launch_bounds__(256) void bin_bounds_kernel(const float *rho_p, const float *nrm_p,
@@ -255,42 +301,20 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
     // my query
     const int qpos = pos0 + 32 * w + col;
     const bool qvalid = qpos < a.pos_end;
-    const int qid = a.bq[qvalid ? qpos : a.pos_end - 1];
-    // Query fragment: lane (col, h) owns B[k = 16 s + 8 h + j][col] = bf16(x_j[k] - mu_c[k]).
-    using s16x8 = __attribute__((ext_vector_type(8))) short;
+    // Query fragment: lane (col, h) owns B[k = 16 s + 8 h + j][col] of the precomputed shadow row
+    // bf16(x_j - mu_c) of (this position, this bin)  (query_shadow_kernel).
     bf16x8 qreg[KSMAX];
     float nj, rq, njx_up, njx_dn;
     {
-        const double *xq = a.X + (size_t)qid * a.Dp;
-        const double *mu = a.centers + (size_t)c * a.Dp;
-        double n2 = 0.0, e2 = 0.0, x2 = 0.0;
+        const size_t qslot = (size_t)c * a.Kcap + (qvalid ? qpos : a.pos_end - 1);
+        const unsigned short *zq = a.Zq + qslot * Dz + h * 8;
 #pragma unroll
         for (int sx = 0; sx < KSMAX; ++sx) {
-            s16x8 bits = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (sx < ksteps) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * sx + 8 * h + j;
-                    if (k < a.D) {
-                        const double z = xq[k] - mu[k];
-                        const unsigned short hb = bf16_rn((float)z);
-                        const double zh = (double)__uint_as_float(((unsigned int)hb) << 16);
-                        n2 += zh * zh;
-                        e2 += (zh - z) * (zh - z);
-                        x2 += z * z;
-                        bits[j] = (short)hb;
-                    }
-                }
-            }
-            qreg[sx] = __builtin_bit_cast(bf16x8, bits);
+            if (sx < ksteps) qreg[sx] = *reinterpret_cast<const bf16x8 *>(zq + sx * 16);
+            else qreg[sx] = qreg[0];
         }
-        n2 += __shfl_xor(n2, 32, 64);
-        e2 += __shfl_xor(e2, 32, 64);
-        x2 += __shfl_xor(x2, 32, 64);
-        nj = round_up_f32(n2 * (1.0 + 1e-12));
-        rq = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
-        njx_up = round_up_f32(x2 * (1.0 + 1e-12));
-        njx_dn = (float)(x2 * (1.0 - 1e-6));
+        const float4 q4 = a.qs[qslot];
+        nj = q4.x; rq = q4.y; njx_up = q4.z; njx_dn = q4.w;
     }
     // Bounds.  With z_j EXACT on the query side:
     //   ||z_j - zh_p||^2 = ||z_j||^2 + n_p - 2 <z_j, zh_p>,   <z_j, zh_p> = <zh_j, zh_p> + <z_j - zh_j, zh_p>,
@@ -584,6 +608,16 @@ void launch_pack_rows(const Shadow &src, const int *memb_id, const int *bin_ptr,
     int grid = (int)std::min<long long>((nch + 255) / 256, 8192);
     hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(256), 0, s, src.Z, src.nrm, src.rho, src.Dz,
                        memb_id, bin_ptr, B, Zp, nrm_p, rho_p);
+}
+
+void launch_query_shadow(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
+                         int Kcap, const double *centers, unsigned short *Zq, int Dz, void *qs,
+                         hipStream_t s)
+{
+    const long long nrow = (long long)(pos_end - pos_begin) * B;
+    if (nrow <= 0) return;
+    hipLaunchKernelGGL(query_shadow_kernel, dim3((unsigned)((nrow + 3) / 4)), dim3(256), 0, s, X, D, Dp, bq,
+                       pos_begin, pos_end, B, Kcap, centers, Zq, Dz, reinterpret_cast<float4 *>(qs));
 }
 
 void launch_bin_bounds(const float *rho_p, const float *nrm_p, const int *bin_ptr, int B, float *rho_out,
