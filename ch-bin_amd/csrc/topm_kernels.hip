@@ -277,20 +277,24 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
 constexpr int kRsChunk = 16;
 constexpr int kRsStride = 18;
 
-__global__ __launch_bounds__(256, 4) void rescore_kernel(RescoreArgs a, int npairs)
+// W lanes per (position, bin) pair: 8 when the list fits 8 lanes (m <= 8: the shortlists average
+// ~7 candidates, so 16-lane groups would idle half their lanes), else 16.
+template <int W, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rescore_kernel(RescoreArgs a, int npairs)
 {
-    __shared__ __attribute__((aligned(16))) double slab[4][68][kRsStride];
+    constexpr int G = 64 / W;   // pairs per wavefront
+    __shared__ __attribute__((aligned(16))) double slab[WAVES][64 + G][kRsStride];
 
-    const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48, w = threadIdx.x >> 6;
-    const int grp = lane >> 4;
-    int gidx = ((int)blockIdx.x * 4 + w) * 4 + grp;
+    const int lane = threadIdx.x & 63, gl = lane & (W - 1), gbase = lane & ~(W - 1), w = threadIdx.x >> 6;
+    const int grp = lane / W;
+    int gidx = ((int)blockIdx.x * WAVES + w) * G + grp;
     int pair = gidx;
     bool pvalid;
     if (a.active != nullptr) {
         const int na = *a.n_active;
         pvalid = gidx < na;
         pair = pvalid ? a.active[gidx] : 0;
-        if (__builtin_amdgcn_readfirstlane(((int)blockIdx.x * 4 + w) * 4) >= na) return;
+        if (__builtin_amdgcn_readfirstlane(((int)blockIdx.x * WAVES + w) * G) >= na) return;
     } else {
         pvalid = gidx < npairs;
     }
@@ -313,15 +317,15 @@ __global__ __launch_bounds__(256, 4) void rescore_kernel(RescoreArgs a, int npai
     }
 
     int cmax = cnt;
-    cmax = max(cmax, __shfl_xor(cmax, 16, 64));
-    cmax = max(cmax, __shfl_xor(cmax, 32, 64));
+#pragma unroll
+    for (int off = W; off < 64; off <<= 1) cmax = max(cmax, __shfl_xor(cmax, off, 64));
     cmax = __builtin_amdgcn_readfirstlane(cmax);
     const int srow = lane >> 3, spc = lane & 7;   // staging role: row srow + 8 i, 16-byte piece spc
     const int nchunks = (a.Dp + kRsChunk - 1) / kRsChunk;
-    // lanes with srow 0..3 also stage the query row of 16-lane group srow
-    const int qsel = __shfl(qid, (srow & 3) * 16, 64);
+    // lanes with srow < G also stage the query row of lane group srow
+    const int qsel = __shfl(qid, (srow & (G - 1)) * W, 64);
     const double *qp = a.X + (size_t)qsel * a.Dp + 2 * spc;
-    for (int base = 0; base < cmax; base += 16) {
+    for (int base = 0; base < cmax; base += W) {
         const int ci = base + gl;
         const bool have = ci < cnt;
         const int id = have ? a.cand[slot * kCandCap + ci] : qid;
@@ -337,14 +341,14 @@ __global__ __launch_bounds__(256, 4) void rescore_kernel(RescoreArgs a, int npai
             for (int i = 0; i < 8; ++i)
                 v[i] = kin ? *reinterpret_cast<const double2 *>(rp[i] + k0) : double2{0.0, 0.0};
             qv = double2{0.0, 0.0};
-            if (srow < 4 && kin) qv = *reinterpret_cast<const double2 *>(qp + k0);
+            if (srow < G && kin) qv = *reinterpret_cast<const double2 *>(qp + k0);
         };
         fetch(0);
         for (int ch = 0; ch < nchunks; ++ch) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 *reinterpret_cast<double2 *>(&slab[w][srow + 8 * i][2 * spc]) = v[i];
-            if (srow < 4) *reinterpret_cast<double2 *>(&slab[w][64 + srow][2 * spc]) = qv;
+            if (srow < G) *reinterpret_cast<double2 *>(&slab[w][64 + srow][2 * spc]) = qv;
             __builtin_amdgcn_wave_barrier();
             if (ch + 1 < nchunks) fetch(ch + 1);   // next chunk's loads fly during the arithmetic
             __builtin_amdgcn_sched_barrier(0);
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256, 4) void rescore_kernel(RescoreArgs a, int npai
         }
         double s1[1] = {have ? sacc : kInf};
         const int id1[1] = {have ? id : INT_MAX};
-        select_into<16, 1>(s1, id1, ld, li, lc, tau, m, gl, gbase);
+        select_into<W, 1>(s1, id1, ld, li, lc, tau, m, gl, gbase);
     }
     if (pvalid) {
         if (gl < m) {
@@ -403,8 +407,13 @@ void launch_rescore(const RescoreArgs &a, hipStream_t s)
 {
     const int npairs = (a.pos_end - a.pos_begin) * a.B;
     if (npairs <= 0) return;
-    const int grid = (npairs + 15) / 16;
-    hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(256), 0, s, a, npairs);
+    if (a.m <= 8) {
+        constexpr int WV = 2, PB = WV * 8;      // 8 pairs per wavefront
+        hipLaunchKernelGGL((rescore_kernel<8, WV>), dim3((npairs + PB - 1) / PB), dim3(64 * WV), 0, s, a, npairs);
+    } else {
+        constexpr int WV = 4, PB = WV * 4;
+        hipLaunchKernelGGL((rescore_kernel<16, WV>), dim3((npairs + PB - 1) / PB), dim3(64 * WV), 0, s, a, npairs);
+    }
 }
 
 void launch_pairwise(const double *X, int N, int Dp, int r0, int r1, double *out, hipStream_t s)
