@@ -185,34 +185,40 @@ __global__ __launch_bounds__(256) void query_shadow_kernel(const double *X, int 
                                                            const double *centers, unsigned short *Zq,
                                                            int Dz, float4 *qs)
 {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // 16 lanes per row (4 rows per wavefront); a lane owns feature pairs (2 l + 32 t, 2 l + 32 t + 1)
+    const int l16 = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const long long nrow = (long long)(pos_end - pos_begin) * B;
-    if (row >= nrow) return;
-    const int pos = pos_begin + (int)(row / B), c = (int)(row - (row / B) * B);
+    const bool rvalid = row < nrow;
+    const long long rr = rvalid ? row : 0;
+    const int pos = pos_begin + (int)(rr / B), c = (int)(rr - (rr / B) * B);
     const double *x = X + (size_t)bq[pos] * Dp;
     const double *mu = centers + (size_t)c * Dp;
     const size_t slot = (size_t)c * Kcap + pos;
     double n2 = 0.0, e2 = 0.0, x2 = 0.0;
-    for (int k = lane; k < Dz; k += 64) {
-        unsigned short hb = 0;
-        if (k < D) {
-            const double z = x[k] - mu[k];
-            hb = bf16_rn((float)z);
-            const double zh = (double)__uint_as_float(((unsigned int)hb) << 16);
-            n2 += zh * zh;
-            e2 += (zh - z) * (zh - z);
-            x2 += z * z;
+    for (int k = 2 * l16; k < Dz; k += 32) {
+        unsigned int packed = 0u;
+        if (k < Dp) {   // Dp is even and rows are zero padded to Dp: k + 1 < Dp as well
+            const double2 xv = *reinterpret_cast<const double2 *>(x + k);
+            const double2 mv = *reinterpret_cast<const double2 *>(mu + k);
+            const double z0 = xv.x - mv.x, z1 = xv.y - mv.y;   // padding columns give exactly 0
+            const unsigned short h0 = bf16_rn((float)z0), h1 = bf16_rn((float)z1);
+            const double zh0 = (double)__uint_as_float(((unsigned int)h0) << 16);
+            const double zh1 = (double)__uint_as_float(((unsigned int)h1) << 16);
+            n2 += zh0 * zh0 + zh1 * zh1;
+            e2 += (zh0 - z0) * (zh0 - z0) + (zh1 - z1) * (zh1 - z1);
+            x2 += z0 * z0 + z1 * z1;
+            packed = (unsigned int)h0 | ((unsigned int)h1 << 16);
         }
-        Zq[slot * Dz + k] = hb;
+        if (rvalid) *reinterpret_cast<unsigned int *>(Zq + slot * Dz + k) = packed;
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        n2 += __shfl_xor(n2, off, 64);
-        e2 += __shfl_xor(e2, off, 64);
-        x2 += __shfl_xor(x2, off, 64);
+    for (int off = 8; off >= 1; off >>= 1) {
+        n2 += __shfl_xor(n2, off, 16);
+        e2 += __shfl_xor(e2, off, 16);
+        x2 += __shfl_xor(x2, off, 16);
     }
-    if (lane == 0) {
+    if (rvalid && l16 == 0) {
         float4 o;
         o.x = round_up_f32(n2 * (1.0 + 1e-12));
         o.y = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
@@ -616,7 +622,7 @@ void launch_query_shadow(const double *X, int D, int Dp, const int *bq, int pos_
 {
     const long long nrow = (long long)(pos_end - pos_begin) * B;
     if (nrow <= 0) return;
-    hipLaunchKernelGGL(query_shadow_kernel, dim3((unsigned)((nrow + 3) / 4)), dim3(256), 0, s, X, D, Dp, bq,
+    hipLaunchKernelGGL(query_shadow_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, s, X, D, Dp, bq,
                        pos_begin, pos_end, B, Kcap, centers, Zq, Dz, reinterpret_cast<float4 *>(qs));
 }
 
