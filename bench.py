@@ -180,16 +180,17 @@ def main():
         # HBM-side traffic per launch from the committed PMC profile (separate rocprofv3 --pmc passes,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null when unavailable
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01c_traffic.json")))["kernels"]
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01d_traffic.json")))["kernels"]
             tmap = {"prefilter": "prefilter_kernel<5, false, true>", "hull_qp": "hull_qp_kernel",
-                    "rescore": "rescore_kernel", "rescore_update": "rescore_kernel",
-                    "prefilter_update": "prefilter_kernel<1, true, true>"}
+                    "rescore": "rescore_kernel<8, 2>", "rescore_update": "rescore_kernel<8, 2>",
+                    "prefilter_update": "prefilter_kernel<1, true, true>",
+                    "query_shadow": "query_shadow_kernel"}
             if (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist:
                 for k in kern:
                     src = tmap.get(k["kernel"])
                     if src in tr:
                         k["traffic"] = tr[src]["traffic_bytes_per_launch"]
-                        k["traffic_source"] = "profiles/r01c_traffic.json (" + src + ")"
+                        k["traffic_source"] = "profiles/r01d_traffic.json (" + src + ")"
         except Exception:  # noqa: BLE001
             pass
         kern.sort(key=lambda k: -k["total_ms"])
