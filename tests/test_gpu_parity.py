@@ -455,3 +455,36 @@ def test_fit_cluster_odd_shapes(ctx, O, N, D, B, m):
     ctx.set_samples(X)
     got, its, ch = ctx.fit_cluster(B, initial, perms, m, 4, batch=150)
     assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
+
+
+def test_hull_distance_kkt_properties(ctx, O):
+    """Solver-independent optimality check of the GPU hull weights: feasibility, stationarity on
+    the support, dual feasibility off it, and invariance under vertex permutation / translation."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=400, deadline=None, derandomize=True)
+    @given(st.integers(1, 16), st.integers(2, 140), st.integers(0, 2**31 - 1), st.floats(1e-4, 10.0))
+    def check(m, D, seed, scale):
+        rng = np.random.default_rng(seed)
+        P = scale * rng.random((m, D)) / D
+        x = scale * rng.random(D) / D
+        if seed % 3 == 0 and m > 1:
+            P[-1] = P[0]
+        d, alpha = ctx.hull_distance_points(x, P, want_alpha=True)
+        Y = P - x
+        Q = Y @ Y.T
+        g = Q @ alpha
+        val = float(alpha @ g)
+        tol = 1e-9 * max(np.diag(Q).max(), 1e-300)
+        assert np.all(alpha >= 0) and abs(alpha.sum() - 1) < 1e-12
+        assert abs(d * d - val) <= 10 * tol + 1e-12 * val
+        assert np.all(g >= val - 1e3 * tol)                      # no vertex improves (dual feasibility)
+        assert np.all(np.abs(g[alpha > 1e-9] - val) <= 1e3 * tol)  # stationarity on the support
+        # a query inside the hull returns sqrt(residual of size ~64 eps max Q_ii), not exactly 0
+        near0 = 2e-7 * np.sqrt(np.diag(Q).max())
+        perm = rng.permutation(m)
+        assert abs(ctx.hull_distance_points(x, P[perm]) - d) <= 1e-9 * scale + near0
+        shift = scale * rng.random(D)
+        assert abs(ctx.hull_distance_points(x + shift, P + shift) - d) <= 1e-8 * scale + near0
+
+    check()
