@@ -34,6 +34,7 @@ SIGNATURES = {
     "chb_device_count": (C.c_int, []),
     "chb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "chb_destroy": (C.c_int, [C.c_void_p]),
+    "chb_set_metric": (C.c_int, [C.c_void_p, C.c_int]),
     "chb_set_samples": (C.c_int, [C.c_void_p, _f64p, C.c_int64, C.c_int64]),
     "chb_set_samples_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "chb_pairwise_distance": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _f64p]),
@@ -113,6 +114,13 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    METRICS = {"convex": 0, "affine": 1, "affine-qp": 1}
+
+    def set_metric(self, metric: str):
+        if metric not in self.METRICS:
+            raise NotImplementedError(f"Metric {metric} not implemented")   # hull_distance.py:108
+        check(self._lib.chb_set_metric(self._h, self.METRICS[metric]))
 
     # ---- samples
     def set_samples(self, X):

@@ -6,5 +6,10 @@ from .distance_matrix import (  # noqa: F401
     create_in_mem_distance_matrix,
     find_nearest_from_cluster,
 )
-from .hull_distance import calculate_distance, convex_hull_distance  # noqa: F401
+from .hull_distance import (  # noqa: F401
+    affine_hull_distance,
+    affine_hull_distance_qp,
+    calculate_distance,
+    convex_hull_distance,
+)
 from .solve_qp import SOLVERS, solve_qp  # noqa: F401

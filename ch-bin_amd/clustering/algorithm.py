@@ -28,7 +28,7 @@ def fit_cluster(
     algorithm.py:45, so after `np.random.seed(0)` (ch_bin.py:22) the visiting order -- and the RNG
     state left behind -- are the reference's.
     """
-    if metric != "convex":
+    if metric not in ("convex", "affine", "affine-qp"):
         raise NotImplementedError(f"Metric {metric} not implemented")  # hull_distance.py:108
     check_solver(qp_solver)                                              # solve_qp.py:132
 
@@ -45,8 +45,12 @@ def fit_cluster(
 
     ctx = default_context()
     ctx.set_samples_cached(samples)
-    labels, iters, changed = ctx.fit_cluster(int(num_clusters), initial, perms.astype(np.int64),
-                                             int(num_neighbors), int(max_iterations), batch=batch)
+    ctx.set_metric(metric)
+    try:
+        labels, iters, changed = ctx.fit_cluster(int(num_clusters), initial, perms.astype(np.int64),
+                                                 int(num_neighbors), int(max_iterations), batch=batch)
+    finally:
+        ctx.set_metric("convex")
 
     np.random.set_state(state)
     for _ in range(iters):

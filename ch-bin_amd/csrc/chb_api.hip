@@ -133,6 +133,7 @@ struct chb_ctx {
     int D = 0, Dp = 0;
     // fit state
     int B = 0, m = 0;
+    int metric = 0;   // CHB_METRIC_CONVEX / CHB_METRIC_AFFINE
     bool fit_open = false;
     DevBuf<int> labels, inb;
     // batch state
@@ -433,6 +434,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         QpArgs q{};
         q.X = h->X.p; q.D = h->D; q.Dp = h->Dp; q.bq = h->bq.p; q.pos_begin = lo; q.pos_end = hi;
         q.B = h->B; q.m = h->m; q.Kcap = h->Kcap; q.lists = h->L1(); q.dist = h->dist.p;
+        q.metric = h->metric;
         {
             Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
             launch_hull_qp(q, s);
@@ -900,7 +902,7 @@ static int hull_indexed(chb_ctx *h, const double *Xdev, int D, int Dp, int64_t n
     HIPCHK(hipMemcpyAsync(h->xhull.p, hx.data(), sizeof(int) * P * m_max, hipMemcpyHostToDevice, s));
     {
         Timed t(h, "hull_qp", (double)P);
-        launch_hull_qp_indexed(Xdev, D, Dp, h->xq.p, h->xhull.p, h->xcnt.p, (int)P, m_max, h->xdist.p,
+        launch_hull_qp_indexed(Xdev, D, Dp, h->xq.p, h->xhull.p, h->xcnt.p, (int)P, m_max, h->metric, h->xdist.p,
                                h->xalpha.p, s);
     }
     HIPCHK(hipGetLastError());
@@ -980,6 +982,14 @@ int chb_find_nearest_from_row(chb_ctx *h, int64_t c, const int64_t *labels, cons
     if (e != hipSuccess) return fail(CHB_EHIP, hipGetErrorString(e));
     for (int i = 0; i < m; ++i) out_idx[i] = out[(size_t)i];
     *out_cnt = out[(size_t)m];
+    return CHB_OK;
+}
+
+int chb_set_metric(chb_ctx *h, int metric)
+{
+    if (!h) return fail(CHB_EINVAL, "null context");
+    if (metric != CHB_METRIC_CONVEX && metric != CHB_METRIC_AFFINE) return fail(CHB_EINVAL, "unknown metric");
+    h->metric = metric;
     return CHB_OK;
 }
 

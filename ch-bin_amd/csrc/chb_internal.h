@@ -113,13 +113,14 @@ struct QpArgs {
     int B, m, Kcap;
     Lists lists;
     double *dist;  // [Kcap][B]
+    int metric;    // 0 convex hull (hull_distance.py:7-35), 1 affine hull (hull_distance.py:38-87)
 };
 void launch_hull_qp(const QpArgs &a, hipStream_t s);
 
 // explicit problems: query sample q[p], hull_idx[p][m_max] compacted, hull_cnt[p] vertices
 void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,
-                            const int *hull_cnt, int P, int m_max, double *dist, double *alpha,
-                            hipStream_t s);
+                            const int *hull_cnt, int P, int m_max, int metric, double *dist,
+                            double *alpha, hipStream_t s);
 
 // label / bucket helpers
 void launch_fill_i32(int *p, int v, int n, hipStream_t s);

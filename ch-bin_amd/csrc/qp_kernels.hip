@@ -179,6 +179,55 @@ __device__ __forceinline__ double min_norm_point(const double (&Q)[Sym<M>::NP], 
     return val;
 }
 
+// Distance^2 to the AFFINE hull of the first m vertices (hull_distance.py:69-87 affine_hull_distance
+// and :38-66 affine_hull_distance_qp: same quantity): the affine minimiser over a maximal affinely
+// independent subset, built greedily -- a vertex whose addition collapses a pivot of the lifted
+// Gram lies in the affine hull of those already taken and is skipped.
+template <int M>
+__device__ __forceinline__ double affine_min_norm(const double (&Q)[Sym<M>::NP], int m, double (&alpha)[M])
+{
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        alpha[i] = 0.0;
+        if (i < m) scale = fmax(scale, Q[Sym<M>::at(i, i)]);
+    }
+    if (!(scale > 0.0)) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) alpha[i] = (i == 0) ? 1.0 : 0.0;
+        return scale == 0.0 ? 0.0 : scale;
+    }
+    unsigned S = 0u;
+    double beta[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        if (k < m) {
+            double trial[M];
+            if (solve_affine<M>(Q, scale, S | (1u << k), trial)) {
+                S |= 1u << k;
+#pragma unroll
+                for (int i = 0; i < M; ++i) beta[i] = trial[i];
+            }
+        }
+    }
+    if (S == 0u) {   // cannot happen for scale > 0 (a single vertex is always independent)
+#pragma unroll
+        for (int i = 0; i < M; ++i) alpha[i] = (i == 0) ? 1.0 : 0.0;
+        return Q[0];
+    }
+    double val = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) alpha[i] = ((S >> i) & 1u) ? beta[i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        double gi = 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) gi += Q[Sym<M>::at(i, j)] * alpha[j];
+        val += alpha[i] * gi;
+    }
+    return val;
+}
+
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 // INDEXED = false: problems are (batch position, bin) pairs whose vertices come from the top-m
@@ -281,7 +330,7 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
 #pragma unroll
         for (int v = 0; v < M; ++v) alpha[v] = 0.0;
     } else {
-        const double val = min_norm_point<M>(Q, n, alpha);
+        const double val = a.metric == 0 ? min_norm_point<M>(Q, n, alpha) : affine_min_norm<M>(Q, n, alpha);
         dist = sqrt(fmax(val, 0.0));
     }
     if (INDEXED) {
@@ -328,11 +377,11 @@ void launch_hull_qp(const QpArgs &a, hipStream_t s)
 }
 
 void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,
-                            const int *hull_cnt, int P, int m_max, double *dist, double *alpha,
-                            hipStream_t s)
+                            const int *hull_cnt, int P, int m_max, int metric, double *dist,
+                            double *alpha, hipStream_t s)
 {
     QpArgs a{};
-    a.X = X; a.D = D; a.Dp = Dp; a.m = m_max;
+    a.X = X; a.D = D; a.Dp = Dp; a.m = m_max; a.metric = metric;
     dispatch<true>(a, P, m_max, q, hull_idx, hull_cnt, dist, alpha, s);
 }
 

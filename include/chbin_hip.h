@@ -48,6 +48,15 @@ int chb_device_count(void);
 int chb_create(int device_id, chb_ctx **out);
 int chb_destroy(chb_ctx *h);
 
+/* hull_distance.py:90-108 calculate_distance's metric dispatch (AlgoDistanceMetric): selects what
+ * every later hull-distance evaluation of this context computes (chb_fit_cluster,
+ * chb_hull_distance_*).  CONVEX = distance to the convex hull ("convex", default.ini:18);
+ * AFFINE = distance to the affine hull ("affine" :69-87 and "affine-qp" :38-66, the same quantity).
+ * The nearest-member selection is identical for both. */
+#define CHB_METRIC_CONVEX 0
+#define CHB_METRIC_AFFINE 1
+int chb_set_metric(chb_ctx *h, int metric);
+
 /* Feature matrix `samples` of fit_cluster (algorithm.py:13): copied to HBM once and kept resident. */
 int chb_set_samples(chb_ctx *h, const double *X, int64_t N, int64_t D);
 /* same, from a device buffer (e.g. a torch tensor's data_ptr); copied device-to-device */

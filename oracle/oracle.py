@@ -49,6 +49,15 @@ def lib():
         L.chbo_convex_hull_distance.argtypes = [_f64p, _f64p, C.c_int, C.c_int64, _f64p,
                                                 C.POINTER(C.c_int)]
         L.chbo_convex_hull_distance.restype = C.c_double
+        L.chbo_affine_hull_distance.argtypes = [_f64p, _f64p, C.c_int, C.c_int64]
+        L.chbo_affine_hull_distance.restype = C.c_double
+        L.chbo_sweep_metric.argtypes = [_f64p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i64p, C.c_int64,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.chbo_sweep_metric.restype = C.c_int64
+        L.chbo_fit_cluster_metric.argtypes = [_f64p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i64p,
+                                              C.c_int64, C.c_int, C.c_int, C.c_void_p, _i64p, _i64p,
+                                              C.c_int]
+        L.chbo_fit_cluster_metric.restype = C.c_int
         L.chbo_sweep.argtypes = [_f64p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i64p, C.c_int64,
                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.chbo_sweep.restype = C.c_int64
@@ -134,7 +143,17 @@ def convex_hull_distance(x, P, return_alpha=False, return_status=False):
     return out if len(out) > 1 else d
 
 
-def sweep(X, B, labels, perm, m, dm=None, want_all=False):
+METRICS = {"convex": 0, "affine": 1, "affine-qp": 1}
+
+
+def affine_hull_distance(x, P):
+    """hull_distance.py:69-87 (== :38-66 mathematically): distance to the affine hull."""
+    x, P = _f64(x), _f64(P)
+    m = P.shape[0]
+    return lib().chbo_affine_hull_distance(x, P.reshape(m, x.shape[0]), m, x.shape[0])
+
+
+def sweep(X, B, labels, perm, m, dm=None, want_all=False, metric="convex"):
     """algorithm.py:46-60 over perm; mutates and returns labels, plus winning distances."""
     X = _f64(X)
     labels = _i64(labels).copy()
@@ -143,13 +162,13 @@ def sweep(X, B, labels, perm, m, dm=None, want_all=False):
     mind = np.empty(len(perm))
     alld = np.empty((len(perm), B)) if want_all else None
     dmp = None if dm is None else _f64(dm)
-    lib().chbo_sweep(X, N, D, int(B), labels, perm, len(perm), int(m),
-                     None if dmp is None else dmp.ctypes.data, mind.ctypes.data,
-                     None if alld is None else alld.ctypes.data)
+    lib().chbo_sweep_metric(X, N, D, int(B), labels, perm, len(perm), int(m),
+                            None if dmp is None else dmp.ctypes.data, mind.ctypes.data,
+                            None if alld is None else alld.ctypes.data, METRICS[metric])
     return (labels, mind, alld) if want_all else (labels, mind)
 
 
-def fit_cluster(X, B, initial_bins, perms, m, max_iter, dm=None):
+def fit_cluster(X, B, initial_bins, perms, m, max_iter, dm=None, metric="convex"):
     """algorithm.py:12-76; perms = (max_iter, n_move) int64, pre-drawn like algorithm.py:45."""
     X = _f64(X)
     initial = _i64(initial_bins)
@@ -158,7 +177,7 @@ def fit_cluster(X, B, initial_bins, perms, m, max_iter, dm=None):
     out = np.empty(N, dtype=np.int64)
     changed = np.zeros(max_iter, dtype=np.int64)
     dmp = None if dm is None else _f64(dm)
-    its = lib().chbo_fit_cluster(X, N, D, int(B), initial, perms, perms.shape[1], int(m),
-                                 int(max_iter), None if dmp is None else dmp.ctypes.data, out,
-                                 changed)
+    its = lib().chbo_fit_cluster_metric(X, N, D, int(B), initial, perms, perms.shape[1], int(m),
+                                        int(max_iter), None if dmp is None else dmp.ctypes.data, out,
+                                        changed, METRICS[metric])
     return out, its, changed[:its]

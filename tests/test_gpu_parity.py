@@ -191,6 +191,8 @@ def test_mirror_errors():
     with pytest.raises(NotImplementedError):
         clustering.calculate_distance(x, np.zeros((2, 4)), "quadprog", "manhattan")
     with pytest.raises(NotImplementedError):
+        clustering.fit_cluster(np.zeros((4, 4)), 1, np.zeros(4, dtype=np.int64), None, metric="manhattan")
+    with pytest.raises(NotImplementedError):
         clustering.calculate_distance(x, np.zeros((2, 4)), "nosuch", "convex")
     with pytest.raises(NotImplementedError):
         clustering.fit_cluster(np.zeros((4, 4)), 1, np.zeros(4, dtype=np.int64), None, qp_solver="nosuch")
@@ -488,3 +490,52 @@ def test_hull_distance_kkt_properties(ctx, O):
         assert abs(ctx.hull_distance_points(x + shift, P + shift) - d) <= 1e-8 * scale + near0
 
     check()
+
+
+# ------------------------------------------------------------------ affine metrics (8f-4)
+
+def test_affine_hull_distance_vs_reference_formula(ctx, O):
+    """hull_distance.py:69-87 restated with numpy/scipy (orth basis, projector) and the oracle's
+    Gram-Schmidt version, incl. collinear / duplicate vertices and more vertices than dimensions."""
+    import scipy.linalg
+    from chbin_amd import clustering
+
+    def ref(q, P):
+        mean = P.mean(axis=0)
+        basis = scipy.linalg.orth((P - mean).T)
+        if basis.shape[1] == 0:
+            return np.linalg.norm(q - mean)
+        proj = basis @ np.linalg.inv(basis.T @ basis) @ basis.T
+        return np.linalg.norm((np.eye(proj.shape[0]) - proj) @ (q - mean))
+
+    rng = np.random.default_rng(17)
+    for t in range(150):
+        m = int(rng.integers(1, 17))
+        D = int(rng.integers(2, 140))
+        P = rng.random((m, D)) / D
+        x = rng.random(D) / D
+        if t % 4 == 1 and m > 2:
+            P[2] = 0.3 * P[0] + 0.7 * P[1]
+        if t % 4 == 2 and m > 1:
+            P[-1] = P[0]
+        want = ref(x, P)
+        scale = np.linalg.norm(P - x, axis=1).max()
+        for metric in ("affine", "affine-qp"):
+            got = clustering.calculate_distance(x, P, "quadprog", metric)
+            assert abs(got - want) <= 1e-9 + 2e-7 * scale * (want < 1e-6 * scale), (t, m, D, got, want)
+        assert abs(O.affine_hull_distance(x, P) - want) < 1e-12
+        # the affine hull contains the convex hull
+        assert clustering.calculate_distance(x, P, "quadprog", "convex") >= want - 1e-9
+
+
+@pytest.mark.parametrize("metric", ["affine", "affine-qp"])
+def test_fit_cluster_affine_metric(ctx, O, metric):
+    from chbin_amd import clustering
+    X, initial, _ = _synth(800, 64, 6, seed=5, sigma=8e-3, mix=0.5, n_seed=8)
+    perms = _perms(initial, 5)
+    want, its_o, _ = O.fit_cluster(X, 6, initial, perms, 5, 5, metric=metric)
+    np.random.seed(0)
+    got = clustering.fit_cluster(X, 6, initial, None, num_neighbors=5, max_iterations=5, metric=metric)
+    assert np.array_equal(got, want)
+    conv, _, _ = O.fit_cluster(X, 6, initial, perms, 5, 5)
+    assert not np.array_equal(conv, want) or True   # (the two metrics may or may not agree here)

@@ -115,3 +115,27 @@ def test_closed_forms():
     assert abs(O.convex_hull_distance(x, P[::-1].copy()) - d0) < 1e-12
     sh = rng.random(D)
     assert abs(O.convex_hull_distance(x + sh, P + sh) - d0) < 1e-10
+
+
+def test_affine_hull_distance_matches_reference_formula():
+    """hull_distance.py:69-87 restated literally with numpy/scipy vs the oracle's C version."""
+    import scipy.linalg
+
+    def ref(q, P):
+        mean = P.mean(axis=0)
+        basis = scipy.linalg.orth((P - mean).T)
+        if basis.shape[1] == 0:
+            return np.linalg.norm(q - mean)
+        proj = basis @ np.linalg.inv(basis.T @ basis) @ basis.T
+        return np.linalg.norm((np.eye(proj.shape[0]) - proj) @ (q - mean))
+
+    rng = np.random.default_rng(3)
+    for t in range(300):
+        m = int(rng.integers(1, 12))
+        D = int(rng.integers(2, 60))
+        P = rng.random((m, D))
+        x = rng.random(D)
+        if t % 3 == 0 and m > 2:
+            P[2] = 0.5 * (P[0] + P[1])
+        assert abs(O.affine_hull_distance(x, P) - ref(x, P)) < 1e-11
+        assert O.affine_hull_distance(x, P) <= O.convex_hull_distance(x, P) + 1e-9
