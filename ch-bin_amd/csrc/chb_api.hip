@@ -704,9 +704,9 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
     for (int64_t i = 0; i < (int64_t)max_iter * n_move; ++i)
         if (perms[i] < 0 || perms[i] >= N) return fail(CHB_EINVAL, "perm entry out of range");
     if (h->world > 1 && !h->comm) return fail(CHB_ESTATE, "world > 1 but chb_comm_init was not called");
-    // default batch: 8192 positions per GPU (more ranks -> proportionally larger batches, so that
-    // every rank still launches full grids)
-    int Kmax = batch > 0 ? batch : 8192 * std::min(h->world, 8);
+    // default batch: 8192 positions on one GPU, growing with sqrt(world): the batch-member
+    // (update) work per rank is ~K^2/world, the per-rank grids ~K/world
+    int Kmax = batch > 0 ? batch : 8192 * std::max(1, (int)std::lround(std::sqrt((double)h->world)));
     if (Kmax > n_move) Kmax = (int)std::max<int64_t>(n_move, 1);
     rc = ensure_batch_buffers(h, Kmax);
     if (rc) return rc;
