@@ -141,8 +141,9 @@ struct chb_ctx {
     bool batch_open = false;
     DevBuf<int> bq, lab_old, lab_prev, lab_new, first_change;
     DevBuf<double> mind, dist;
-    DevBuf<double> l0d, l1d;
-    DevBuf<int> l0i, l1i, l0c, l1c;
+    DevBuf<double> l0d, l1d, l2d;
+    DevBuf<int> l0i, l1i, l0c, l1c, l2i, l2c;
+    int round_in_batch = 0;   // rounds alternate between the list sets 1 and 2 (the other = previous)
     DevBuf<int> cnt, bin_ptr, cursor, memb_id;
     DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
     DevBuf<int> perm;
@@ -173,6 +174,9 @@ struct chb_ctx {
 
     Lists L0() { return Lists{l0d.p, l0i.p, l0c.p}; }
     Lists L1() { return Lists{l1d.p, l1i.p, l1c.p}; }
+    Lists L2() { return Lists{l2d.p, l2i.p, l2c.p}; }
+    Lists Lcur() { return (round_in_batch & 1) ? L2() : L1(); }
+    Lists Lprev() { return (round_in_batch & 1) ? L1() : L2(); }
 };
 
 namespace {
@@ -224,6 +228,9 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->dist.ensure(K * B));
     HIPCHK(h->l0d.ensure(K * B * m));
     HIPCHK(h->l1d.ensure(K * B * m));
+    HIPCHK(h->l2d.ensure(K * B * m));
+    HIPCHK(h->l2i.ensure(K * B * m));
+    HIPCHK(h->l2c.ensure(K * B));
     HIPCHK(h->l0i.ensure(K * B * m));
     HIPCHK(h->l1i.ensure(K * B * m));
     HIPCHK(h->l0c.ensure(K * B));
@@ -301,6 +308,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
 int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
 {
     h->K = K; h->q_lo = q_lo; h->q_hi = q_hi;
+    h->round_in_batch = 0;
     hipStream_t s = h->stream;
     launch_gather_labels(h->labels.p, h->bq.p, K, h->lab_old.p, s);
     launch_mark_batch(h->inb.p, h->bq.p, K, 1, s);
@@ -382,7 +390,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = lo; a.pos_end = hi;
         a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;
         a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
-        a.in = h->L0(); a.out = h->L1();
+        a.in = h->L0(); a.out = h->Lcur();
         if (h->use_prefilter && h->pf_update && h->shadow_ok && h->cand.p) {
             // batch members that can displace an entry of the base list: bf16 shortlist against
             // the exact m-th distance, exact rescoring seeded with the base list
@@ -411,13 +419,14 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
             ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p;
             ra.active = h->active.p; ra.n_active = h->n_active.p;
-            ra.in = h->L0(); ra.out = h->L1();
+            ra.in = h->L0(); ra.out = h->Lcur();
             // pairs without any candidate keep the base list
             {
                 const size_t nl = (size_t)h->Kcap * h->B;
-                HIPCHK(hipMemcpyAsync(h->l1d.p, h->l0d.p, sizeof(double) * nl * h->m, hipMemcpyDeviceToDevice, s));
-                HIPCHK(hipMemcpyAsync(h->l1i.p, h->l0i.p, sizeof(int) * nl * h->m, hipMemcpyDeviceToDevice, s));
-                HIPCHK(hipMemcpyAsync(h->l1c.p, h->l0c.p, sizeof(int) * nl, hipMemcpyDeviceToDevice, s));
+                const Lists dst = h->Lcur();
+                HIPCHK(hipMemcpyAsync(dst.d, h->l0d.p, sizeof(double) * nl * h->m, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(dst.idx, h->l0i.p, sizeof(int) * nl * h->m, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(dst.cnt, h->l0c.p, sizeof(int) * nl, hipMemcpyDeviceToDevice, s));
             }
             {
                 Timed t(h, "rescore_update", (double)(hi - lo) * h->B);
@@ -433,7 +442,9 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         }
         QpArgs q{};
         q.X = h->X.p; q.D = h->D; q.Dp = h->Dp; q.bq = h->bq.p; q.pos_begin = lo; q.pos_end = hi;
-        q.B = h->B; q.m = h->m; q.Kcap = h->Kcap; q.lists = h->L1(); q.dist = h->dist.p;
+        q.B = h->B; q.m = h->m; q.Kcap = h->Kcap; q.lists = h->Lcur(); q.dist = h->dist.p;
+        // a (position, bin) whose vertex list is the one of the previous round keeps its distance
+        q.prev = h->round_in_batch > 0 ? h->Lprev() : Lists{nullptr, nullptr, nullptr};
         q.metric = h->metric;
         {
             Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
@@ -452,6 +463,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         HIPCHK(hipStreamSynchronize(s));
     }
     h->stats[1] += 1;
+    h->round_in_batch += 1;
     return CHB_OK;
 }
 
@@ -517,11 +529,11 @@ int chb_destroy(chb_ctx *h)
     drain_profile(h);
     if (h->comm && rccl()) { (void)rccl()->CommDestroy(h->comm); h->comm = nullptr; }
     DevBuf<int> *ib[] = {&h->labels, &h->inb, &h->bq, &h->lab_old, &h->lab_prev, &h->lab_new,
-                         &h->first_change, &h->l0i, &h->l1i, &h->l0c, &h->l1c, &h->cnt, &h->bin_ptr,
+                         &h->first_change, &h->l0i, &h->l1i, &h->l0c, &h->l1c, &h->l2i, &h->l2c, &h->cnt, &h->bin_ptr,
                          &h->cursor, &h->memb_id, &h->cnt2, &h->bin_ptr2, &h->cursor2, &h->memb2_id,
                          &h->memb2_code, &h->perm, &h->xq, &h->xhull, &h->xcnt, &h->cand, &h->cand_cnt, &h->flags64, &h->overflow};
     for (auto *b : ib) b->release();
-    DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->xdist, &h->xalpha, &h->xpts};
+    DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->l2d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
     h->Zp.release(); h->znrm_p.release(); h->zrho_p.release(); h->rho_bin.release();
     h->Zs.release(); h->znrm_s.release(); h->zrho_s.release(); h->sn_bin.release(); h->sn_bin2.release();

@@ -112,6 +112,8 @@ struct QpArgs {
     int pos_begin, pos_end;
     int B, m, Kcap;
     Lists lists;
+    Lists prev;    // lists of the previous round of this batch (idx == nullptr: none): unchanged
+                   // vertex lists keep their distance
     double *dist;  // [Kcap][B]
     int metric;    // 0 convex hull (hull_distance.py:7-35), 1 affine hull (hull_distance.py:38-87)
 };

@@ -279,6 +279,19 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
             }
         }
         const bool live = valid && rv < n;
+        if (!INDEXED && a.prev.idx != nullptr) {
+            // skip the tile when every one of its problems has the vertex list of the previous round
+            bool changed = false;
+            if (valid) {
+                const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+                const size_t slot = (size_t)c * a.Kcap + pos;
+                changed = a.prev.cnt[slot] != n || (rv < n && a.prev.idx[slot * m + rv] != id);
+            }
+            if (!__any(changed)) {
+                if (valid && rv == 0) sN[w][t * PPT + rp] = -1;   // keep the stored distance
+                continue;
+            }
+        }
         // The Gram sum over features is order-free, so feature k is assigned to MFMA step / k-slot
         // as k = 16 t + 4 kq + s: every lane then reads 32 contiguous bytes per 4 steps and the 4
         // lanes of a row cover one full 128-byte line.
@@ -323,6 +336,7 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
 #pragma unroll
     for (int e = 0; e < NP; ++e) Q[e] = sQ[w][e][lane];
     const int n = sN[w][lane];
+    if (n == -1) return;   // unchanged vertex list: a.dist already holds this distance
     double alpha[M];
     double dist;
     if (n <= 0) {
