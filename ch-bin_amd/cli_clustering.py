@@ -31,42 +31,41 @@ def perform_clustering(
     operating_dir.mkdir(parents=True, exist_ok=True)
     (operating_dir / "bins").mkdir(parents=True, exist_ok=True)
 
-    # 01. Read feature CSV                                               (cli/clustering.py:47-53)
+    # features.csv schema (cli/features.py:96-110): CONTIG_NAME, PARENT_NAME, CLUSTER, then the k-mer
+    # and coverage columns.  Everything that is not one of the three bookkeeping columns is a feature.
     logger.info(">> Reading feature CSV...")
-    df_features = pd.read_csv(features_csv)
-    num_clusters = df_features.CLUSTER.max() + 1
-    initial_bins: np.ndarray = df_features.CLUSTER.values.copy()
-    samples: np.ndarray = df_features.drop(["CONTIG_NAME", "PARENT_NAME", "CLUSTER"], axis=1).values
-    num_samples = len(samples)
+    table = pd.read_csv(features_csv)
+    seeds = table["CLUSTER"].to_numpy(dtype=np.int64, copy=True)          # -1 = to be binned
+    n_bins = int(seeds.max()) + 1                                         # cli/clustering.py:51
+    feature_cols = [c for c in table.columns if c not in ("CONTIG_NAME", "PARENT_NAME", "CLUSTER")]
+    feats = np.ascontiguousarray(table[feature_cols].to_numpy(dtype=np.float64))
 
-    # 02. (no distance matrix)                                           (cli/clustering.py:55-63)
+    # cli/clustering.py:55-63 builds an N x N matrix here; the HIP path needs none.
     logger.info(">> Skipping the %s distance matrix (tiles are recomputed on the GPU)...",
-                (num_samples, num_samples))
+                (len(feats), len(feats)))
 
-    # 03. Perform binning                                                (cli/clustering.py:65-76)
     logger.info(">> Performing binning using %s solver...", qp_solver)
-    convex_labels = fit_cluster(
-        samples=samples,
-        num_clusters=int(num_clusters),
+    labels = fit_cluster(
+        samples=feats,
+        num_clusters=n_bins,
         distance_matrix=None,
-        initial_bins=initial_bins,
+        initial_bins=seeds,
         num_neighbors=num_neighbors,
         max_iterations=max_iterations,
         metric=metric,
         qp_solver=qp_solver,
     )
-    if np.any(convex_labels < 0):                                      # cli/clustering.py:79-80
+    if np.any(labels < 0):                                                # cli/clustering.py:79-80
         raise ValueError("There were some un-clustered points left... Aborting.")
 
-    # 04. Majority vote per parent contig                               (cli/clustering.py:82-92)
+    # One row per parent contig: the bin most of its sub-contigs landed in, ties to the lowest
+    # bin id, parents in sorted order -- what cli/clustering.py:84-91 gets from
+    # groupby("PARENT_NAME") + np.bincount(x).argmax().
     logger.info(">> Assigning bins...")
-    df_samples: pd.DataFrame = df_features.drop("CLUSTER", axis=1)
-    df_bin_column: pd.DataFrame = pd.DataFrame({"BIN": convex_labels})
-    df_combined: pd.DataFrame = pd.concat([df_samples, df_bin_column], axis=1)
-    parent_groups = df_combined[["PARENT_NAME", "BIN"]].groupby("PARENT_NAME")
-    df_dist_bin: pd.DataFrame = parent_groups.BIN.apply(lambda x: np.bincount(x).argmax()).reset_index()
-    df_dist_bin.rename(columns={"PARENT_NAME": "CONTIG_NAME"}, inplace=True)
-    df_dist_bin.to_csv(dist_bin_csv, index=False)
+    parents, which = np.unique(table["PARENT_NAME"].to_numpy().astype(str), return_inverse=True)
+    votes = np.zeros((len(parents), max(n_bins, 1)), dtype=np.int64)
+    np.add.at(votes, (which, np.asarray(labels, dtype=np.int64)), 1)
+    pd.DataFrame({"CONTIG_NAME": parents, "BIN": votes.argmax(axis=1)}).to_csv(dist_bin_csv, index=False)
     logger.info("Dumped binning assignment CSV at %s...", dist_bin_csv)
     return dist_bin_csv
 
