@@ -276,7 +276,8 @@ __device__ __forceinline__ void list_insert(float (&l)[ML], float v)
 // DMA  = true : member tiles go global -> LDS directly (global_load_lds_dwordx4, no staging
 //               registers, no ds_write); needs packed rows and 18 chunks per row (Dz = 144).  The LDS
 //               image is unpadded and XOR-swizzled through the SOURCE address (chunk c of row r sits
-//               at c ^ ((r >> 4) & 1)), which makes the ds_read_b128 fragment reads conflict-free.
+//               at c ^ f(r): f = (r >> 4) & 1 for 18 chunks per row (Dz = 144), f = (r >> 2) & 3 for 20
+//               (Dz = 160)), which makes the ds_read_b128 fragment reads conflict-free.
 template <int ML, bool UPD, bool DMA>
 __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
                                                         int stride, int *flags64, int nqt64)
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         for (int j = 0; j < 4; ++j) {
             const int pch = (w + 4 * j) * 64 + lane;
             const int r = pch / cpr, cs = pch - r * cpr;
-            dma_off[j] = (r * cpr + (cs ^ ((r >> 4) & 1))) * 16;
+            const int f = (cpr & 15) == 2 ? ((r >> 4) & 1) : ((r >> 2) & 3);
+            dma_off[j] = (r * cpr + (cs ^ f)) * 16;
         }
     }
     // staging registers: up to 4 16-byte chunks per thread (Dz <= 256).  Two sets, so that the tile
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + (DMA ? 0 : h * 16);
-        const int swz = (col >> 4) & 1;
+        const int swz = (cpr & 15) == 2 ? ((col >> 4) & 1) : ((col >> 2) & 3);
 #pragma unroll
         for (int sx = 0; sx < KSMAX; ++sx)
             if (sx < ksteps) {
@@ -650,7 +652,8 @@ static bool use_dma(const PrefilterArgs &a)
 {
     static int env = -1;
     if (env < 0) { const char *e = getenv("CHB_PF_DMA"); env = e ? atoi(e) : 1; }
-    return env != 0 && ((a.shm.Dz >> 3) & 15) == 2;
+    const int c16 = (a.shm.Dz >> 3) & 15;   // 16-byte chunks per row mod 16: swizzles exist for 2 and 4
+    return env != 0 && (c16 == 2 || c16 == 4);
 }
 
 template <int ML, bool UPD>
