@@ -537,5 +537,3 @@ def test_fit_cluster_affine_metric(ctx, O, metric):
     np.random.seed(0)
     got = clustering.fit_cluster(X, 6, initial, None, num_neighbors=5, max_iterations=5, metric=metric)
     assert np.array_equal(got, want)
-    conv, _, _ = O.fit_cluster(X, 6, initial, perms, 5, 5)
-    assert not np.array_equal(conv, want) or True   # (the two metrics may or may not agree here)
