@@ -268,7 +268,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
 int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
 {
     if (!h->X.p) return fail(CHB_ESTATE, "chb_set_samples has not been called");
-    if (B <= 0 || B > (1 << 20)) return fail(CHB_EINVAL, "num_clusters out of range");
+    if (B <= 0) return fail(CHB_EINVAL, "num_clusters must be positive");
+    if (B > 8192) return fail(CHB_EUNSUPPORTED, "more than 8192 bins (per-block LDS histograms of the CSR build)");
     if (m < 1 || m > CHB_MAX_NEIGHBORS)
         return fail(CHB_EUNSUPPORTED, "num_neighbors must be in [1, 16]");
     h->B = (int)B; h->m = m;
