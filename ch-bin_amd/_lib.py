@@ -10,7 +10,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchbin_hip.so")
+LIB_PATH = os.environ.get("CHBIN_LIB", os.path.join(_HERE, "libchbin_hip.so"))   # CHBIN_LIB: developer override
 
 CHB_MAX_NEIGHBORS = 16
 

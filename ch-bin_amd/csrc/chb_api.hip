@@ -151,6 +151,7 @@ struct chb_ctx {
     DevBuf<unsigned short> Zs, Zp, Zp2, Zq;
     DevBuf<float> qs;
     DevBuf<float> znrm_s, zrho_s, znrm_p, zrho_p, znrm_p2, zrho_p2, rho_bin, rho_bin2, sn_bin, sn_bin2;
+    DevBuf<float> code_s, code_b, inf_const;   // shortlist_kernel: eligibility as (s, b); one +inf
     DevBuf<double> centers;
     int Dz = 0;
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
@@ -260,6 +261,13 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->Zp2.ensure((2 * K + 64) * (size_t)h->Dz));
         HIPCHK(h->znrm_p2.ensure(2 * K));
         HIPCHK(h->zrho_p2.ensure(2 * K));
+        HIPCHK(h->code_s.ensure(2 * K));
+        HIPCHK(h->code_b.ensure(2 * K));
+        if (!h->inf_const.p) {
+            HIPCHK(h->inf_const.ensure(4));
+            const float inf4[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+            HIPCHK(hipMemcpy(h->inf_const.p, inf4, sizeof(inf4), hipMemcpyHostToDevice));
+        }
     }
     h->Kcap = Kcap;
     return CHB_OK;
@@ -350,6 +358,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p;
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
         pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
+        pa.inf_ptr = h->inf_const.p;
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
             launch_prefilter(pa, h->flags64.p, s);
@@ -410,6 +419,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
             pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
             pa.active = h->active.p; pa.n_active = h->n_active.p;
+            pa.inf_ptr = h->inf_const.p; pa.code_s = h->code_s.p; pa.code_b = h->code_b.p;
             launch_fill_i32(h->n_active.p, 0, 1, s);
             {
                 Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
@@ -540,6 +550,7 @@ int chb_destroy(chb_ctx *h)
     h->Zs.release(); h->znrm_s.release(); h->zrho_s.release(); h->sn_bin.release(); h->sn_bin2.release();
     h->Zq.release(); h->qs.release();
     h->Zp2.release(); h->znrm_p2.release(); h->zrho_p2.release(); h->rho_bin2.release(); h->centers.release();
+    h->code_s.release(); h->code_b.release(); h->inf_const.release();
     h->active.release(); h->n_active.release();
     (void)hipStreamDestroy(h->stream);
     delete h;

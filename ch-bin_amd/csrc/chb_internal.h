@@ -75,6 +75,8 @@ struct PrefilterArgs {
     const int *bin_ptr;
     const int *memb_id;
     const int *memb_code;  // non-null selects the update mode: batch members, fixed tau from `seed`
+    float *code_s, *code_b;  // update mode scratch [#members]: memb_code as (s, b), eligible <=> s q + b >= 0
+    const float *inf_ptr;    // one float +infinity in device memory (DMA source for rows past a bin's end)
     Lists seed;
     int B, m, Kcap;
     int *cand;       // [B][Kcap][kCandCap] sample indices

@@ -273,12 +273,9 @@ __device__ __forceinline__ void list_insert(float (&l)[ML], float v)
 // The query fragments (B operand) are built in the prologue (x_j - mu_c -> bf16, with the exact
 // ||zh||^2 and rho of THIS query against THIS bin's centre) and live in registers for the whole
 // kernel (Dz <= 160); LDS only holds the double-buffered member tile.
-// DMA  = true : member tiles go global -> LDS directly (global_load_lds_dwordx4, no staging
-//               registers, no ds_write); needs packed rows and 18 chunks per row (Dz = 144).  The LDS
-//               image is unpadded and XOR-swizzled through the SOURCE address (chunk c of row r sits
-//               at c ^ f(r): f = (r >> 4) & 1 for 18 chunks per row (Dz = 144), f = (r >> 2) & 3 for 20
-//               (Dz = 160)), which makes the ds_read_b128 fragment reads conflict-free.
-template <int ML, bool UPD, bool DMA>
+// This is the GENERIC form (any Dz <= 160, register-staged tiles, run-time step count); the two row
+// shapes of real feature tables take shortlist_kernel below.
+template <int ML, bool UPD>
 __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
                                                         int stride, int *flags64, int nqt64)
 {
@@ -287,8 +284,8 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
     unsigned char *sPz = smem;                               // [2][kPfP][stride]
     float *sPn = reinterpret_cast<float *>(sPz + (size_t)2 * kPfP * stride);  // [2][kPfP]
     float *sPr = sPn + 2 * kPfP;                             // [2][kPfP]
-    int *sPid = reinterpret_cast<int *>(sPr + 2 * kPfP);     // [2][kPfP]
-    int *sPcode = sPid + 2 * kPfP;                           // [2][kPfP]
+    int *sPid = reinterpret_cast<int *>(sPr + 2 * kPfP);     // [4][kPfP]: slot = tile & 3 (read one tile late)
+    int *sPcode = sPid + 4 * kPfP;                           // [2][kPfP]
 
     const int per = (total + 7) >> 3;
     const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -349,18 +346,6 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
 
     const int ntile = (nmem + kPfP - 1) / kPfP;
     const int nchunk = kPfP * cpr;      // chunks per member tile (<= 4 per thread for Dz <= 256)
-    // LDS-DMA roles: wave w issues the 1-KiB pieces w, w+4, w+8, w+12 of a tile; lane l of piece i
-    // fills LDS chunk p = 64 i + l and fetches the global chunk that the swizzle maps there
-    int dma_off[4] = {0, 0, 0, 0};
-    if (DMA) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pch = (w + 4 * j) * 64 + lane;
-            const int r = pch / cpr, cs = pch - r * cpr;
-            const int f = (cpr & 15) == 2 ? ((r >> 4) & 1) : ((r >> 2) & 3);
-            dma_off[j] = (r * cpr + (cs ^ f)) * 16;
-        }
-    }
     // staging registers: up to 4 16-byte chunks per thread (Dz <= 256).  Two sets, so that the tile
     // after next is already in flight while the current one is being consumed (one global-memory
     // latency per tile would otherwise be exposed: a tile is only ~0.4 us of work per wavefront).
@@ -374,15 +359,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
 #endif
     // (named scalars + macros: a struct passed by reference to a lambda ends up in scratch)
 #define CHB_PF_FETCH_ONE(I, ST, TT)                                                               \
-    if (DMA) {                                                                                     \
-        if (w + 4 * (I) < (cpr >> 1))                                                              \
-            __builtin_amdgcn_global_load_lds(                                                      \
-                reinterpret_cast<const unsigned char *>(a.shm.Z) +                                 \
-                    ((size_t)(mb + (TT) * kPfP) * Dz) * 2 + dma_off[I],                            \
-                (__attribute__((address_space(3))) void *)(sPz + (size_t)((TT) & 1) * kPfP * stride + \
-                                                          (w + 4 * (I)) * 1024),                  \
-                16, 0, 0);                                                                         \
-    } else {                                                                                       \
+    {                                                                                              \
         const int ch = tid + 256 * (I);                                                            \
         if (ch < nchunk) {                                                                         \
             const int r = ch / cpr, cc = ch - r * cpr;                                             \
@@ -392,7 +369,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         }                                                                                          \
     }
 #define CHB_PF_STASH_ONE(I, ST, BB)                                                               \
-    if (!DMA) {                                                                                    \
+    {                                                                                    \
         const int ch = tid + 256 * (I);                                                            \
         if (ch < nchunk) {                                                                         \
             const int r = ch / cpr, cc = ch - r * cpr;                                             \
@@ -416,7 +393,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
             }                                                                                      \
         }                                                                                          \
     }
-#define CHB_PF_STASH(BB, X)                                                                       \
+#define CHB_PF_STASH(BB, X, IDS)                                                                    \
     {                                                                                              \
         CHB_PF_STASH_ONE(0, c##X##0, BB)                                                           \
         CHB_PF_STASH_ONE(1, c##X##1, BB)                                                           \
@@ -424,7 +401,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         CHB_PF_STASH_ONE(3, c##X##3, BB)                                                           \
         if (tid < kPfP) {                                                                          \
             sPn[(BB) * kPfP + tid] = n##X;                                                         \
-            sPid[(BB) * kPfP + tid] = id##X;                                                       \
+            sPid[(IDS) * kPfP + tid] = id##X;                                                      \
             sPcode[(BB) * kPfP + tid] = code##X;                                                   \
         }                                                                                          \
     }
@@ -438,6 +415,8 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
     // still-loose running threshold.  The matrix-core work is cheap enough to do twice.
     // rho_j + (largest rho of any member this kernel can meet): constant per (query, bin)
     const float rsum = a.rho_bound[c] * (1.0f + kSlack);
+    unsigned pend_mask = 0u;   // candidates of the previous tile whose stores are still to be issued
+    int pend_off = 0, pend_buf = 0;
     float thr = INFINITY;   // sweep 0: m-th smallest t1 so far
     float C2 = FLT_MAX;     // sweep 1: admission bound on t2
     if (UPD && tau < INFINITY) {
@@ -445,23 +424,42 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
     }
     for (int sweep = UPD ? 1 : 0; sweep < 2; ++sweep) {
+        if (!UPD && sweep == 1) {
+            // m-th smallest t1 over BOTH lane halves of the query
+            float mg[ML];
+#pragma unroll
+            for (int i = 0; i < ML; ++i) mg[i] = ub[i];
+#pragma unroll
+            for (int i = 0; i < ML; ++i) list_insert<ML>(mg, __shfl_xor(ub[i], 32, 64));
+#pragma unroll
+            for (int i = 0; i < ML; ++i)
+                if (i == m - 1) thr = mg[i];
+        }
         if (!UPD && sweep == 1 && thr < INFINITY) {
             // tau = m-th smallest upper bound; at least m members are provably within it
             tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
             const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
             C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
         }
-        auto consume = [&](int buf) {
+        auto flush_pending = [&]() {
+            while (pend_mask) {
+                const int r = __ffs(pend_mask) - 1;
+                pend_mask &= pend_mask - 1u;
+                const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (pend_off < kCandCap) cand[pend_off] = sPid[pend_buf * kPfP + prow];
+                ++pend_off;
+            }
+        };
+        auto consume = [&](int buf, int idslot) {
+        flush_pending();
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + (DMA ? 0 : h * 16);
-        const int swz = (cpr & 15) == 2 ? ((col >> 4) & 1) : ((col >> 2) & 3);
+        const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + h * 16;
 #pragma unroll
         for (int sx = 0; sx < KSMAX; ++sx)
             if (sx < ksteps) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(
-                    pbase + (DMA ? ((2 * sx + h) ^ swz) * 16 : sx * 32));
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + sx * 32);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qreg[sx], acc, 0, 0, 0);
             }
 
@@ -486,27 +484,29 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         }
 
         if (sweep == 0) {
-            // Learn tau.  UB'(p) = sqrt(t1_p + n_j(1+g)) + rho_j + rho_bin is monotone in
-            // t1_p = n_p(1+g) - 2<zh_j, zh_p>, so the m smallest t1 are kept (no sqrt per insert);
-            // `thr` = m-th smallest t1 over both lane halves of this query.
-            bool ins = false;
+            // Learn tau.  UB'(p) = sqrt(t1_p + n_j(1+g)) + rho_bin is monotone in
+            // t1_p = n_p(1+g) - 2<zh_j, zh_p>, so the m smallest t1 are kept (no sqrt per insert).
+            // Each lane half keeps ITS m smallest and filters against its own m-th (`thr`); the two
+            // halves of a query are merged once, after the sweep.  Per tile: the 16 values, their
+            // minimum, ONE branch; the (rare) insertions happen smallest-first inside it.
+            float t1v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float t1 = fmaf(kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
-                if (t1 < thr) {
-                    list_insert<ML>(ub, t1);
-                    ins = true;
-                }
-            }
-            if (__any(ins)) {
-                float mg[ML];
+            for (int r = 0; r < 16; ++r) t1v[r] = fmaf(kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
+            float mn = t1v[0];
 #pragma unroll
-                for (int i = 0; i < ML; ++i) mg[i] = ub[i];
-#pragma unroll
-                for (int i = 0; i < ML; ++i) list_insert<ML>(mg, __shfl_xor(ub[i], 32, 64));
+            for (int r = 1; r < 16; ++r) mn = fminf(mn, t1v[r]);
+            while (mn < thr) {
+                list_insert<ML>(ub, mn);
 #pragma unroll
                 for (int i = 0; i < ML; ++i)
-                    if (i == m - 1) thr = mg[i];
+                    if (i == m - 1) thr = ub[i];
+                float nx = INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    t1v[r] = t1v[r] == mn ? INFINITY : t1v[r];   // consume (all copies of a tie at once:
+                    nx = fminf(nx, t1v[r]);                     //  harmless, thr only gets looser)
+                }
+                mn = nx;
             }
         } else {
             // shortlist: LB' = sqrt(s - E) - rho_j - rho_bin <= tau  <=>  t2 <= C2 (constant)
@@ -518,17 +518,13 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
             }
             const int cnt = __popc(mask);
             const int pc = __shfl_xor(cnt, 32, 64);
-            int off = ccount + (h ? pc : 0);
+            // The global stores of this tile's candidates are issued at the START of the next tile
+            // (flush_pending): the barrier that ends a tile waits for vmcnt(0), and a store issued
+            // right before it would expose its whole write latency every tile.
+            pend_mask = qvalid ? mask : 0u;
+            pend_off = ccount + (h ? pc : 0);
+            pend_buf = idslot;
             ccount += cnt + pc;
-            if (qvalid) {
-                while (mask) {
-                    const int r = __ffs(mask) - 1;
-                    mask &= mask - 1u;
-                    const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (off < kCandCap) cand[off] = sPid[buf * kPfP + prow];
-                    ++off;
-                }
-            }
         }
 
         };
@@ -536,37 +532,38 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
 #if CHB_PF_DEEP
         if (ntile > 0) CHB_PF_FETCH(0, A)
         if (ntile > 1) CHB_PF_FETCH(1, B)
-        if (ntile > 0) CHB_PF_STASH(0, A)
+        if (ntile > 0) CHB_PF_STASH(0, A, 0)
         __syncthreads();
         for (int t = 0; t < ntile; t += 2) {
             // even tile t sits in buffer 0, tile t+1 is in flight in SB
             if (t + 2 < ntile) CHB_PF_FETCH(t + 2, A)
             __builtin_amdgcn_sched_barrier(0);
-            consume(0);
+            consume(0, t & 3);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < ntile) CHB_PF_STASH(1, B)
+            if (t + 1 < ntile) CHB_PF_STASH(1, B, (t + 1) & 3)
             __syncthreads();
             if (t + 1 >= ntile) break;
             // odd tile t+1 sits in buffer 1, tile t+2 is in flight in SA
             if (t + 3 < ntile) CHB_PF_FETCH(t + 3, B)
             __builtin_amdgcn_sched_barrier(0);
-            consume(1);
+            consume(1, (t + 1) & 3);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < ntile) CHB_PF_STASH(0, A)
+            if (t + 2 < ntile) CHB_PF_STASH(0, A, (t + 2) & 3)
             __syncthreads();
         }
 #else
-        if (ntile > 0) { CHB_PF_FETCH(0, A) CHB_PF_STASH(0, A) }
+        if (ntile > 0) { CHB_PF_FETCH(0, A) CHB_PF_STASH(0, A, 0) }
         __syncthreads();
         for (int t = 0; t < ntile; ++t) {
             if (t + 1 < ntile) CHB_PF_FETCH(t + 1, A)
             __builtin_amdgcn_sched_barrier(0);
-            consume(t & 1);
+            consume(t & 1, t & 3);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < ntile) CHB_PF_STASH((t + 1) & 1, A)
+            if (t + 1 < ntile) CHB_PF_STASH((t + 1) & 1, A, (t + 1) & 3)
             __syncthreads();
         }
 #endif
+        flush_pending();
     }
 
     if (qvalid && h == 0) {
@@ -574,6 +571,364 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
         if (UPD && ccount > 0 && a.active != nullptr)
             a.active[atomicAdd(a.n_active, 1)] = (qpos - a.pos_begin) * a.B + c;
         if (ccount > kCandCap) {
+            atomicAdd(a.overflow, 1);
+            flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The streamlined form of the kernel above for the two row shapes of real feature tables
+// (Dz = 144: 9 matrix-core steps, Dz = 160: 10).  Same bounds, same shortlist; what differs is
+// how the work is fed:
+//   * Dz / 16 is a compile-time constant, so all fragment reads of a tile are in flight together
+//     and the matrix-core steps issue back to back;
+//   * every global read inside the tile loop is an LDS-DMA (shadow rows in 1-KiB pieces, the
+//     member norms / eligibility as 4-byte pieces): no ordinary load whose use would make the
+//     compiler drain the DMA queue.  Three LDS buffers, two tiles in flight, one raw s_barrier and
+//     one COUNTED s_waitcnt vmcnt(n) per tile (n = this wavefront's DMA instructions per tile);
+//   * n_p (1 +- g) / 2 is folded into the accumulator's start value, so the matrix core returns
+//     -t/2 directly: sweep 0 is a 16-way maximum, sweep 1 sixteen compares;
+//   * shortlist hits are parked per wavefront in LDS as (query, member offset) words through a
+//     ballot + mbcnt compaction (no atomics, no divergent store loop) and written out once, after
+//     the last tile; the order inside a shortlist is irrelevant (rescore_kernel orders exactly).
+constexpr int kPoolW = 1024;   // parked shortlist entries per wavefront (32 queries)
+
+__device__ __forceinline__ void wait_vmcnt(int n)   // n: wave-uniform
+{
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+}
+
+// LDS accesses of the tile loop are issued from inline asm: while an LDS-DMA is in flight the
+// compiler puts s_waitcnt vmcnt(0) in front of every LDS access it can see (it cannot tell the
+// buffers apart), which would drain the two tiles kept in flight.  The asm reads are completed by
+// lds_wait_all() before their results are used.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_frag(unsigned addr)
+{
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_f4(unsigned addr)
+{
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write_u32(unsigned addr, unsigned v)
+{
+    asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void *)p;
+}
+
+template <int ML>
+__device__ __forceinline__ void list_insert_desc(float (&l)[ML], float v)
+{
+#pragma unroll
+    for (int i = 0; i < ML; ++i) {
+        const float hi = fmaxf(l[i], v);
+        v = fminf(l[i], v);
+        l[i] = hi;
+    }
+}
+
+// eligibility code (aux_kernels.hip) -> (s, b) with "eligible for position q  <=>  s q + b >= 0"
+__global__ __launch_bounds__(256) void code_affine_kernel(const int *memb_code, const int *bin_ptr, int B,
+                                                          float *cs, float *cb)
+{
+    const int n = bin_ptr[B];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int code = memb_code[i];
+        float sv = 0.f, bv = 0.f;
+        if (code > 0) { sv = 1.f; bv = -(float)code; }                       // q > code - 1
+        else if (code <= -(1 << 30)) { sv = 0.f; bv = -1.f; }                // "q != i" has no affine form:
+                                                                             // never routed here (launcher)
+        else if (code < 0) { sv = -1.f; bv = (float)(-code - 2); }           // q < -code - 1
+        cs[i] = sv; cb[i] = bv;
+    }
+}
+
+template <int ML, bool UPD, int KS>
+__global__ __launch_bounds__(256, CHB_PF_WAVES) void shortlist_kernel(PrefilterArgs a, int nqt, int total,
+                                                                       int *flags64, int nqt64)
+{
+    constexpr int CPR = 2 * KS;              // 16-byte chunks per shadow row
+    constexpr int ROWB = 32 * KS;            // bytes per shadow row
+    constexpr int TILEB = kPfP * ROWB;       // one member tile
+    constexpr int METAB = 512;               // floats [0,32) n_p | [32,64) s | [64,96) b
+    constexpr int BUFB = TILEB + METAB;
+    constexpr int NBUF = 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *sPool = reinterpret_cast<unsigned *>(smem + NBUF * BUFB);   // [4][kPoolW]
+    int *sCnt = reinterpret_cast<int *>(sPool + 4 * kPoolW);              // [kPfQ]
+
+    const int per = (total + 7) >> 3;
+    const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (W >= total) return;
+    const int c = W / nqt, qt = W - c * nqt;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smem_base = lds_addr(smem);
+    const unsigned pool_base = lds_addr(sPool) + (unsigned)(w * kPoolW * 4);
+    const int col = lane & 31, h = lane >> 5;
+    const int mb = a.bin_ptr[c];
+    const int nmem = a.bin_ptr[c + 1] - mb;
+    const int pos0 = a.pos_begin + qt * kPfQ;
+    const int m = a.m;
+
+    const int qpos = pos0 + 32 * w + col;
+    const bool qvalid = qpos < a.pos_end;
+    bf16x8 qreg[KS];
+    float nj, rq, njx_up, njx_dn;
+    {
+        const size_t qslot = (size_t)c * a.Kcap + (qvalid ? qpos : a.pos_end - 1);
+        const unsigned short *zq = a.Zq + qslot * (KS * 16) + h * 8;
+#pragma unroll
+        for (int sx = 0; sx < KS; ++sx) qreg[sx] = *reinterpret_cast<const bf16x8 *>(zq + sx * 16);
+        const float4 q4 = a.qs[qslot];
+        nj = q4.x; rq = q4.y; njx_up = q4.z; njx_dn = q4.w;
+    }
+    // bounds: see prefilter_kernel
+    const float Aq = (2.0f * rq * a.sn_bound[c] + kGamma * nj) * (1.0f + 4.0f * kSlack);
+    const float nj_hi = (njx_up + Aq) * (1.0f + kSlack);
+    const float nj_lo = (njx_dn - Aq) * (njx_dn > Aq ? (1.0f - kSlack) : (1.0f + kSlack));
+    const float rsum = a.rho_bound[c] * (1.0f + kSlack);
+    const float qposf = (float)qpos;
+
+    // sweep 0: the m largest accumulator values (= m smallest t1) seen by this lane half, descending;
+    // the first ML - m slots are pinned at +inf so that the m-th largest is always lb[ML - 1]
+    float lb[ML];
+#pragma unroll
+    for (int i = 0; i < ML; ++i) lb[i] = i < ML - m ? INFINITY : -INFINITY;
+    float thr_s = -INFINITY;
+    // sweep 1 admits a member iff its accumulator >= thr2  (t2 <= C2, t2 = -2 acc)
+    float thr2 = qvalid ? -FLT_MAX : INFINITY;
+    if (UPD && qvalid) {
+        const size_t sl = (size_t)c * a.Kcap + qpos;
+        if (a.seed.cnt[sl] >= m) {
+            const float tau = round_up_f32(a.seed.d[sl * m + m - 1]) * (1.0f + kSlack);   // exact m-th distance so far
+            const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+            thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
+        }
+    }
+    if (h == 0) sCnt[32 * w + col] = 0;
+
+    const int ntile = (nmem + kPfP - 1) / kPfP;
+    const int nvt = UPD ? ntile : 2 * ntile;   // the tile stream: sweep 0 then sweep 1
+    // DMA roles: wavefront w moves the 1-KiB pieces w, w+4, w+8 of a tile (lane l of piece i fills
+    // LDS chunk 64 i + l from the global chunk the swizzle maps there); wavefront 3 also moves the
+    // norms (+ s), wavefront 2 the b column in update mode
+    int src_off[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int pch = (w + 4 * j) * 64 + lane;
+        const int r = pch / CPR, cs = pch - r * CPR;
+        const int f = KS == 9 ? ((r >> 4) & 1) : ((r >> 2) & 3);
+        src_off[j] = (r * CPR + (cs ^ f)) * 16;
+    }
+    int n_w = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) n_w += (w + 4 * j < KS) ? 1 : 0;
+    n_w += (w == 3) ? 1 : 0;
+    n_w += (UPD && w == 2) ? 1 : 0;
+    const unsigned char *zbase = reinterpret_cast<const unsigned char *>(a.shm.Z) + (size_t)mb * ROWB;
+
+    int it = 0, ibuf = 0;   // next tile to issue and its buffer
+#define CHB_SL_ISSUE()                                                                             \
+    {                                                                                              \
+        unsigned char *dst_ = smem + ibuf * BUFB;                                                  \
+        const unsigned char *src_ = zbase + (size_t)it * TILEB;                                    \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j)                                              \
+            if (w + 4 * j < KS)                                                                    \
+                __builtin_amdgcn_global_load_lds(src_ + src_off[j],                                \
+                    (__attribute__((address_space(3))) void *)(dst_ + (w + 4 * j) * 1024), 16, 0, 0); \
+        if (w == 3) {                                                                              \
+            const int e_ = it * kPfP + col;                                                        \
+            const float *p_ = e_ < nmem ? a.shm.nrm + mb + e_ : a.inf_ptr;                         \
+            if (UPD && h) p_ = a.code_s + mb + (e_ < nmem ? e_ : nmem - 1);                        \
+            __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB), 4, 0, 0); \
+        }                                                                                          \
+        if (UPD && w == 2) {                                                                       \
+            const int e_ = it * kPfP + col;                                                        \
+            const float *p_ = a.code_b + mb + (e_ < nmem ? e_ : nmem - 1);                         \
+            __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB + 256), 4, 0, 0); \
+        }                                                                                          \
+        if (++it == ntile) it = 0;                                                                 \
+        if (++ibuf == NBUF) ibuf = 0;                                                              \
+    }
+
+    if (nvt > 0) CHB_SL_ISSUE()
+    if (nvt > 1) CHB_SL_ISSUE()
+
+    // fragment addressing: chunk (2 sx + h) of row `col`, XOR-swizzled as the DMA laid it out
+    int fbase0, fbase1;
+    if (KS == 9) {
+        const int f = (col >> 4) & 1;
+        fbase0 = col * ROWB + ((h ^ f) << 4);
+        fbase1 = fbase0 + 32;
+    } else {
+        const int f0 = (col >> 2) & 1, f1 = (col >> 3) & 1;
+        fbase0 = col * ROWB + (f1 << 5) + ((h ^ f0) << 4);
+        fbase1 = col * ROWB + ((1 ^ f1) << 5) + ((h ^ f0) << 4);
+    }
+    const float c0 = -0.5f * (1.0f + kGamma), c1 = -0.5f * (1.0f - kGamma);
+    const unsigned ent0 = ((unsigned)col << 27) | (unsigned)(4 * h);
+
+    int ct = 0, cbuf = 0, sweep = UPD ? 1 : 0;
+    const bool tile_best = ntile >= 16;
+    int wcnt = 0;   // entries parked by this wavefront (wave-uniform)
+    for (int vt = 0; vt < nvt; ++vt) {
+        wait_vmcnt(vt + 1 < nvt ? n_w : 0);   // my pieces of tile vt have landed
+        __builtin_amdgcn_s_barrier();         // everybody's have; buffer (vt + 2) % 3 is free again
+        if (vt + 2 < nvt) CHB_SL_ISSUE()
+        if (!UPD && vt == ntile) {
+            // end of sweep 0: m-th smallest t1 over BOTH lane halves -> tau -> thr2
+            sweep = 1; ct = 0;
+            float mg[ML];
+#pragma unroll
+            for (int i = 0; i < ML; ++i) mg[i] = lb[i];
+#pragma unroll
+            for (int i = 0; i < ML; ++i) {
+                const float o = __shfl_xor(lb[i], 32, 64);
+                list_insert_desc<ML>(mg, i >= ML - m ? o : -INFINITY);   // (not the pinned slots twice)
+            }
+            const float ms = mg[ML - 1];
+            if (qvalid && ms > -INFINITY) {
+                // tau = m-th smallest upper bound; at least m members are provably within it
+                const float thr = -2.0f * ms;
+                const float tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
+                const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+                thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
+            }
+        }
+
+        const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
+        // rows held by this lane: (r & 3) + 8 (r >> 2) + 4 h
+        const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
+        f32x4 nv[4], sv[4], bv[4];
+#define CHB_SL_META(G)                                                                             \
+        nv[G] = lds_read_f4<32 * (G)>(ma);                                                         \
+        if (UPD) { sv[G] = lds_read_f4<128 + 32 * (G)>(ma); bv[G] = lds_read_f4<256 + 32 * (G)>(ma); }
+        CHB_SL_META(0) CHB_SL_META(1) CHB_SL_META(2) CHB_SL_META(3)
+#undef CHB_SL_META
+        bf16x8 af[KS == 9 ? 9 : 10];
+        {
+            const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
+            if (KS == 9) {
+                af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<32>(fa0);  af[2] = lds_read_frag<64>(fa0);
+                af[3] = lds_read_frag<96>(fa0);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<160>(fa0);
+                af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<224>(fa0); af[8] = lds_read_frag<256>(fa0);
+            } else {
+                af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<0>(fa1);   af[2] = lds_read_frag<64>(fa0);
+                af[3] = lds_read_frag<64>(fa1);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<128>(fa1);
+                af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<192>(fa1); af[8] = lds_read_frag<256>(fa0);
+                af[9] = lds_read_frag<256>(fa1);
+            }
+        }
+        // every asm read above has landed once this returns (operands tied so that no use can be
+        // scheduled ahead of the wait)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]),
+                       "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]), "+v"(af[8])
+                     :
+                     : "memory");
+        if (KS == 10) asm volatile("" : "+v"(af[KS - 1]) : : "memory");
+        if (UPD)
+            asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(bv[0]), "+v"(bv[1]),
+                              "+v"(bv[2]), "+v"(bv[3]) : : "memory");
+        f32x16 acc;
+        const float cinit = sweep ? c1 : c0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            acc[4 * g + 0] = nv[g][0] * cinit; acc[4 * g + 1] = nv[g][1] * cinit;
+            acc[4 * g + 2] = nv[g][2] * cinit; acc[4 * g + 3] = nv[g][3] * cinit;
+            if (UPD) {
+                // a batch member counts for this query only on the right side of the visiting order
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (fmaf(sv[g][k], qposf, bv[g][k]) < 0.f) acc[4 * g + k] = -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int sx = 0; sx < KS; ++sx)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sx], qreg[sx], acc, 0, 0, 0);
+
+        if (!UPD && sweep == 0) {
+            // acc = -t1/2 with t1 = n_p (1 + g) - 2 <zh_j, zh_p>: UB is monotone in t1, so the m
+            // LARGEST accumulators are kept; per tile a 16-way maximum and one branch
+            float mx = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+            if (tile_best) {
+                // Large bins: only the BEST of the 16 values enters the list.  The m-th best of
+                // per-(tile, lane half) bests is the m-th best of m distinct members, i.e. still a
+                // valid tau; it is the exact m-th unless two of the top m share a tile half
+                // (probability ~ m^2 / (4 ntile)), and then one rank looser.  No rescan loop.
+                if (mx > thr_s) {
+                    list_insert_desc<ML>(lb, mx);
+                    thr_s = lb[ML - 1];
+                }
+            } else
+            while (mx > thr_s) {
+                list_insert_desc<ML>(lb, mx);
+                thr_s = lb[ML - 1];
+                float nx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[r] = acc[r] == mx ? -INFINITY : acc[r];   // (all copies of a tie at once:
+                    nx = fmaxf(nx, acc[r]);                       //  harmless, thr only gets looser)
+                }
+                mx = nx;
+            }
+        } else {
+            const unsigned ebase = ent0 + (unsigned)(ct * kPfP);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool hit = acc[r] >= thr2;
+                const unsigned long long bal = __ballot(hit);
+                if (bal) {
+                    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    const int pos = wcnt + before;
+                    if (hit && pos < kPoolW) lds_write_u32(pool_base + 4u * (unsigned)pos, ebase + (unsigned)((r & 3) + 8 * (r >> 2)));
+                    wcnt += __popcll(bal);
+                }
+            }
+        }
+        if (++ct == ntile) ct = 0;
+        if (++cbuf == NBUF) cbuf = 0;
+    }
+#undef CHB_SL_ISSUE
+
+    // write the parked entries out: entry -> (query of this wavefront, member offset in the bin)
+    const int npark = wcnt < kPoolW ? wcnt : kPoolW;
+    for (int i = lane; i < npark; i += 64) {
+        const unsigned en = sPool[w * kPoolW + i];
+        const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));
+        const int off = atomicAdd(&sCnt[32 * w + qc], 1);
+        if (off < kCandCap)
+            a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * kCandCap + off] = a.memb_id[mb + e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (qvalid && h == 0) {
+        const size_t slot = (size_t)c * a.Kcap + qpos;
+        const int ccount = sCnt[32 * w + col];
+        a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
+        if (UPD && ccount > 0 && a.active != nullptr)
+            a.active[atomicAdd(a.n_active, 1)] = (qpos - a.pos_begin) * a.B + c;
+        if (ccount > kCandCap || wcnt > kPoolW) {
             atomicAdd(a.overflow, 1);
             flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
         }
@@ -637,33 +992,41 @@ void launch_bin_bounds(const float *rho_p, const float *nrm_p, const int *bin_pt
 size_t prefilter_lds_bytes(int Dz)
 {
     const int stride = Dz * 2 + 16;
-    return (size_t)(2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4 + 4);
+    return (size_t)(2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4) + 4 * kPfP * 4;
 }
 
-template <int ML, bool UPD, bool DMA>
-static void launch_pf3(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
-                       int *flags64, int nqt64, hipStream_t s)
+static size_t shortlist_lds_bytes(int ks)
 {
-    hipLaunchKernelGGL((prefilter_kernel<ML, UPD, DMA>), dim3(grid), dim3(256), lds, s, a, nqt, total,
-                       stride, flags64, nqt64);
+    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)4 * kPoolW * 4 + kPfQ * 4;
 }
 
-static bool use_dma(const PrefilterArgs &a)
+// the streamlined kernel exists for 18 or 20 16-byte chunks per row (the two row shapes its
+// source-side swizzle is laid out for); CHB_PF_V2=0 forces the generic kernel
+static bool use_shortlist_kernel(const PrefilterArgs &a)
 {
     static int env = -1;
-    if (env < 0) { const char *e = getenv("CHB_PF_DMA"); env = e ? atoi(e) : 1; }
-    const int c16 = (a.shm.Dz >> 3) & 15;   // 16-byte chunks per row mod 16: swizzles exist for 2 and 4
-    return env != 0 && (c16 == 2 || c16 == 4);
+    if (env < 0) { const char *e = getenv("CHB_PF_V2"); env = e ? atoi(e) : 1; }
+    return env != 0 && (a.shm.Dz == 144 || a.shm.Dz == 160) && a.inf_ptr != nullptr;
 }
 
 template <int ML, bool UPD>
 static void launch_pf(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
                       int *flags64, int nqt64, hipStream_t s)
 {
-    if (use_dma(a))
-        launch_pf3<ML, UPD, true>(a, grid, lds, nqt, total, a.shm.Dz * 2, flags64, nqt64, s);
-    else
-        launch_pf3<ML, UPD, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
+    if (use_shortlist_kernel(a) && (!UPD || (a.code_s != nullptr && a.code_b != nullptr))) {
+        if (UPD)
+            hipLaunchKernelGGL(code_affine_kernel, dim3(64), dim3(256), 0, s, a.memb_code, a.bin_ptr, a.B,
+                               a.code_s, a.code_b);
+        if (a.shm.Dz == 144)
+            hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(256), shortlist_lds_bytes(9), s, a,
+                               nqt, total, flags64, nqt64);
+        else
+            hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(256), shortlist_lds_bytes(10), s, a,
+                               nqt, total, flags64, nqt64);
+        return;
+    }
+    hipLaunchKernelGGL((prefilter_kernel<ML, UPD>), dim3(grid), dim3(256), lds, s, a, nqt, total, stride, flags64,
+                       nqt64);
 }
 
 void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s)

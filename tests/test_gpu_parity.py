@@ -346,13 +346,15 @@ def _brute_ctx():
     return c
 
 
-@pytest.mark.parametrize("kind", ["offset", "tiny", "dups", "wide", "onehot"])
+@pytest.mark.parametrize("kind", ["offset", "tiny", "dups", "wide", "onehot", "bigbins"])
 def test_shortlist_stage_equals_brute_force(ctx, O, kind):
     """The bf16 shortlist + exact rescoring must give bit-identical lists to the brute-force
     kernel on data built to stress the error bounds and the overflow fallback."""
     assert ctx.counter("prefilter_enabled") == 1
     rng = np.random.default_rng(11)
     N, D, B, m = 3000, 136, 6, 5
+    if kind == "bigbins":
+        N, B = 9000, 4          # > 512 members per bin: the per-tile-best threshold mode of sweep 0
     X, _, true = _synth(N, D, B, seed=4, sigma=3e-3, mix=0.5)
     if kind == "offset":
         X = X + 1000.0                                   # huge common offset: centring must cope
