@@ -593,7 +593,10 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterA
 //   * shortlist hits are parked per wavefront in LDS as (query, member offset) words through a
 //     ballot + mbcnt compaction (no atomics, no divergent store loop) and written out once, after
 //     the last tile; the order inside a shortlist is irrelevant (rescore_kernel orders exactly).
-constexpr int kPoolW = 1024;   // parked shortlist entries per wavefront (32 queries)
+// parked shortlist entries per wavefront (32 queries; a pool that fills up sends the wavefront's
+// queries to the brute-force fallback).  512 entries keep the workgroup at 37-40 KB of LDS, i.e.
+// four workgroups per CU; lists for m > 8 are longer and get 1024 (three per CU).
+__host__ __device__ constexpr int shortlist_pool_entries(int ml) { return ml <= 8 ? 512 : 1024; }
 
 __device__ __forceinline__ void wait_vmcnt(int n)   // n: wave-uniform
 {
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(256) void code_affine_kernel(const int *memb_code, 
 }
 
 template <int ML, bool UPD, int KS>
-__global__ __launch_bounds__(256, CHB_PF_WAVES) void shortlist_kernel(PrefilterArgs a, int nqt, int total,
+__global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(PrefilterArgs a, int nqt, int total,
                                                                        int *flags64, int nqt64)
 {
     constexpr int CPR = 2 * KS;              // 16-byte chunks per shadow row
@@ -669,6 +672,7 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void shortlist_kernel(PrefilterA
     constexpr int METAB = 512;               // floats [0,32) n_p | [32,64) s | [64,96) b
     constexpr int BUFB = TILEB + METAB;
     constexpr int NBUF = 3;
+    constexpr int kPoolW = shortlist_pool_entries(ML);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *sPool = reinterpret_cast<unsigned *>(smem + NBUF * BUFB);   // [4][kPoolW]
     int *sCnt = reinterpret_cast<int *>(sPool + 4 * kPoolW);              // [kPfQ]
@@ -922,15 +926,26 @@ __global__ __launch_bounds__(256, CHB_PF_WAVES) void shortlist_kernel(PrefilterA
             a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * kCandCap + off] = a.memb_id[mb + e];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
     if (qvalid && h == 0) {
         const size_t slot = (size_t)c * a.Kcap + qpos;
-        const int ccount = sCnt[32 * w + col];
         a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
-        if (UPD && ccount > 0 && a.active != nullptr)
-            a.active[atomicAdd(a.n_active, 1)] = (qpos - a.pos_begin) * a.B + c;
         if (ccount > kCandCap || wcnt > kPoolW) {
             atomicAdd(a.overflow, 1);
             flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
+        }
+    }
+    if (UPD && a.active != nullptr) {
+        // pairs with a non-empty shortlist, appended with ONE atomic per wavefront
+        const bool act = ccount > 0;
+        const unsigned long long bal = __ballot(act);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(a.n_active, __popcll(bal));
+            base = __shfl(base, leader, 64);
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (act) a.active[base + before] = (qpos - a.pos_begin) * a.B + c;
         }
     }
 }
@@ -995,9 +1010,9 @@ size_t prefilter_lds_bytes(int Dz)
     return (size_t)(2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4) + 4 * kPfP * 4;
 }
 
-static size_t shortlist_lds_bytes(int ks)
+static size_t shortlist_lds_bytes(int ks, int ml)
 {
-    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)4 * kPoolW * 4 + kPfQ * 4;
+    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)4 * shortlist_pool_entries(ml) * 4 + kPfQ * 4;
 }
 
 // the streamlined kernel exists for 18 or 20 16-byte chunks per row (the two row shapes its
@@ -1018,10 +1033,10 @@ static void launch_pf(const PrefilterArgs &a, int grid, size_t lds, int nqt, int
             hipLaunchKernelGGL(code_affine_kernel, dim3(64), dim3(256), 0, s, a.memb_code, a.bin_ptr, a.B,
                                a.code_s, a.code_b);
         if (a.shm.Dz == 144)
-            hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(256), shortlist_lds_bytes(9), s, a,
+            hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(256), shortlist_lds_bytes(9, ML), s, a,
                                nqt, total, flags64, nqt64);
         else
-            hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(256), shortlist_lds_bytes(10), s, a,
+            hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(256), shortlist_lds_bytes(10, ML), s, a,
                                nqt, total, flags64, nqt64);
         return;
     }
