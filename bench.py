@@ -127,7 +127,7 @@ def main():
     ms_per_step = dt / max(args.steps, 1) * 1e3
     value = qp_per_step * args.steps / dt
 
-    prof = {k: ctx.profile_get(k) for k in ("prefilter", "rescore", "prefilter_update", "rescore_update", "query_shadow",
+    prof = {k: ctx.profile_get(k) for k in ("prefilter", "rescore", "prefilter_update", "rescore_update", "query_norms",
                                             "topm_fallback", "topm_base", "topm_update", "hull_qp", "argmin",
                                             "bucket")}
     stats = ctx.fit_stats()
@@ -152,7 +152,7 @@ def main():
         # shortlist stage: bf16 MFMA dot products, 2*Dz flops per (query, member) pair
         p = prof["prefilter"]
         if p["launches"]:
-            Dz = (D + 15) // 16 * 16
+            Dz = 144 if D <= 144 else 160
             ach = p["work"] * 2.0 * Dz / (p["ms"] * 1e-3) / 1e12
             kern.append({"kernel": "prefilter", "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS, "traffic": None,
@@ -160,7 +160,7 @@ def main():
                          "total_ms": p["ms"], "pairs_per_s": p["work"] / (p["ms"] * 1e-3),
                          "note": "bf16 v_mfma_f32_32x32x16 shortlist; selection (VALU) and LDS "
                                  "staging, not the matrix core, set its time"})
-        for name in ("rescore", "prefilter_update", "rescore_update", "query_shadow", "topm_fallback", "argmin",
+        for name in ("rescore", "prefilter_update", "rescore_update", "query_norms", "topm_fallback", "argmin",
                      "bucket"):
             p = prof[name]
             if p["launches"]:
@@ -184,7 +184,7 @@ def main():
             tmap = {"prefilter": "prefilter_kernel<5, false, true>", "hull_qp": "hull_qp_kernel",
                     "rescore": "rescore_kernel<8, 2>", "rescore_update": "rescore_kernel<8, 2>",
                     "prefilter_update": "prefilter_kernel<1, true, true>",
-                    "query_shadow": "query_shadow_kernel"}
+                    "query_norms": "query_shadow_kernel"}
             if (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist:
                 for k in kern:
                     src = tmap.get(k["kernel"])

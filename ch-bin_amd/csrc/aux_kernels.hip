@@ -214,6 +214,76 @@ __global__ __launch_bounds__(256) void select_row_kernel(const int *labels, cons
     }
 }
 
+// ---- compaction of the (position, bin) pairs with a non-empty shortlist (update rounds).
+// Two small passes instead of an atomic append: every wavefront of the shortlist kernel bumping ONE
+// device-scope counter costs ~0.1 us apiece on 8 XCDs -- 1.6 ms per sweep, measured.
+constexpr int kActChunk = 4096;   // pairs per block
+__global__ __launch_bounds__(256) void active_count_kernel(const int *cand_cnt, int pos_begin, int npos, int B,
+                                                           int Kcap, int *blk_cnt)
+{
+    __shared__ int red[256];
+    const long long total = (long long)npos * B;
+    const long long p0 = (long long)blockIdx.x * kActChunk;
+    int n = 0;
+    for (int i = threadIdx.x; i < kActChunk; i += 256) {
+        const long long p = p0 + i;   // bin-major pair order: coalesced reads of cand_cnt
+        if (p < total) {
+            const int c = (int)(p / npos), q = (int)(p - (long long)c * npos);
+            n += cand_cnt[(size_t)c * Kcap + pos_begin + q] > 0;
+        }
+    }
+    red[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void active_write_kernel(const int *cand_cnt, int pos_begin, int npos, int B,
+                                                           int Kcap, const int *blk_cnt, int *active, int *n_active)
+{
+    __shared__ int red[256];
+    __shared__ int sbase;
+    // my output offset = sum of the counts of the blocks before me
+    int pre = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) pre += blk_cnt[b];
+    red[threadIdx.x] = pre;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sbase = red[0];
+    __syncthreads();
+    int base = sbase;
+    const long long total = (long long)npos * B;
+    const long long p0 = (long long)blockIdx.x * kActChunk;
+    for (int i0 = 0; i0 < kActChunk; i0 += 256) {
+        const long long p = p0 + i0 + threadIdx.x;
+        int c = 0, q = 0;
+        bool on = false;
+        if (p < total) {
+            c = (int)(p / npos); q = (int)(p - (long long)c * npos);
+            on = cand_cnt[(size_t)c * Kcap + pos_begin + q] > 0;
+        }
+        // ordered compaction of the 256 flags: ballots per wavefront + 4 wavefront counts
+        const unsigned long long bal = __ballot(on);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) red[w] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int k = 0; k < w; ++k) off += red[k];
+        const int tot = red[0] + red[1] + red[2] + red[3];
+        off += __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (on) active[base + off] = q * B + c;
+        base += tot;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_active = base;
+}
+
 }  // namespace
 
 void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old, int p0, int p1,
@@ -228,6 +298,18 @@ void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K,
 {
     if (K > p0)
         hipLaunchKernelGGL(first_change_kernel, dim3((K - p0 + 255) / 256), dim3(256), 0, s, lab_new, lab_prev, p0, K, first_change);
+}
+
+void launch_compact_active(const int *cand_cnt, int pos_begin, int pos_end, int B, int Kcap, int *blk_cnt,
+                           int *active, int *n_active, hipStream_t s)
+{
+    const long long total = (long long)(pos_end - pos_begin) * B;
+    if (total <= 0) { launch_fill_i32(n_active, 0, 1, s); return; }
+    const int nblk = (int)((total + kActChunk - 1) / kActChunk);
+    hipLaunchKernelGGL(active_count_kernel, dim3(nblk), dim3(256), 0, s, cand_cnt, pos_begin, pos_end - pos_begin, B,
+                       Kcap, blk_cnt);
+    hipLaunchKernelGGL(active_write_kernel, dim3(nblk), dim3(256), 0, s, cand_cnt, pos_begin, pos_end - pos_begin, B,
+                       Kcap, blk_cnt, active, n_active);
 }
 
 void launch_select_row(const int *labels, const double *row, int N, int c, int m, int *out_idx,

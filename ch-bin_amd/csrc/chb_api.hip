@@ -124,6 +124,33 @@ struct DevBuf {
 
 }  // namespace
 
+// device storage behind a MemberPack
+struct PackBufs {
+    DevBuf<unsigned short> Z;
+    DevBuf<float> bias, rho, nrm, amax, cs, cb, bb;
+    DevBuf<int> pad_ptr;
+    hipError_t ensure(size_t rows, size_t B, size_t Dz)
+    {
+        hipError_t e;
+        if ((e = Z.ensure((rows + 64) * Dz)) != hipSuccess) return e;   // + slack: whole 32-row tiles are read
+        DevBuf<float> *f[] = {&bias, &rho, &nrm, &amax, &cs, &cb};
+        for (auto *b : f)
+            if ((e = b->ensure(rows + 64)) != hipSuccess) return e;
+        if ((e = bb.ensure(4 * B)) != hipSuccess) return e;
+        return pad_ptr.ensure(B + 1);
+    }
+    void release()
+    {
+        Z.release(); bias.release(); rho.release(); nrm.release(); amax.release(); cs.release(); cb.release();
+        bb.release(); pad_ptr.release();
+    }
+    chb::MemberPack view()
+    {
+        return chb::MemberPack{Z.p, bias.p, rho.p, nrm.p, amax.p, cs.p, cb.p, pad_ptr.p,
+                               reinterpret_cast<float4 *>(bb.p)};
+    }
+};
+
 struct chb_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
@@ -147,17 +174,20 @@ struct chb_ctx {
     DevBuf<int> cnt, bin_ptr, cursor, memb_id;
     DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
     DevBuf<int> perm;
-    // two-stage selection: bf16 shadow copy + shortlists
-    DevBuf<unsigned short> Zs, Zp, Zp2, Zq;
-    DevBuf<float> qs;
-    DevBuf<float> znrm_s, zrho_s, znrm_p, zrho_p, znrm_p2, zrho_p2, rho_bin, rho_bin2, sn_bin, sn_bin2;
-    DevBuf<float> code_s, code_b, inf_const;   // shortlist_kernel: eligibility as (s, b); one +inf
+    // two-stage selection: fp16 shadow copies + shortlists (prefilter_kernels.hip)
+    DevBuf<unsigned short> Gs, Zs;     // per sample: query-side row (global centre), member-side row (own bin)
+    DevBuf<float> gq, ms;              // per sample: float2 {||qh||^2, rho}, float4 {bias, rho, ||zh||^2, amax}
+    DevBuf<double> mu_g, colsum_part;  // global mean, scratch of its two-pass sum
+    DevBuf<unsigned int> rmax;
+    double shadow_scale = 1.0;         // S
+    PackBufs pk, pk2;                  // padded member packs: base members, the batch's own entries
+    DevBuf<float> qn;                  // [B][Kcap] float2 exact query-to-centre norms
     DevBuf<double> centers;
     int Dz = 0;
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
     bool pf_base = true, pf_update = true;   // developer switches (CHB_PF_BASE / CHB_PF_UPDATE)
     DevBuf<int> cand, cand_cnt, flags64, overflow;
-    DevBuf<int> active, n_active;
+    DevBuf<int> active, n_active, act_blk;
     // scratch for the indexed / explicit-point entry points
     DevBuf<int> xq, xhull, xcnt;
     DevBuf<double> xdist, xalpha, xpts;
@@ -250,24 +280,12 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->cand_cnt.ensure(K * B));
         HIPCHK(h->active.ensure(K * B));
         HIPCHK(h->n_active.ensure(1));
+        HIPCHK(h->act_blk.ensure((K * B + 4095) / 4096 + 1));
         HIPCHK(h->flags64.ensure(B * ((K + kQTile - 1) / kQTile)));
         HIPCHK(h->overflow.ensure(1));
-        HIPCHK(h->rho_bin.ensure(B));
-        HIPCHK(h->rho_bin2.ensure(B));
-        HIPCHK(h->sn_bin.ensure(B));
-        HIPCHK(h->sn_bin2.ensure(B));
-        HIPCHK(h->Zq.ensure(K * B * (size_t)h->Dz));
-        HIPCHK(h->qs.ensure(K * B * 4));
-        HIPCHK(h->Zp2.ensure((2 * K + 64) * (size_t)h->Dz));
-        HIPCHK(h->znrm_p2.ensure(2 * K));
-        HIPCHK(h->zrho_p2.ensure(2 * K));
-        HIPCHK(h->code_s.ensure(2 * K));
-        HIPCHK(h->code_b.ensure(2 * K));
-        if (!h->inf_const.p) {
-            HIPCHK(h->inf_const.ensure(4));
-            const float inf4[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-            HIPCHK(hipMemcpy(h->inf_const.p, inf4, sizeof(inf4), hipMemcpyHostToDevice));
-        }
+        HIPCHK(h->qn.ensure(K * B * 2));
+        HIPCHK(h->pk.ensure((size_t)h->N + 32 * B, B, (size_t)h->Dz));
+        HIPCHK(h->pk2.ensure(2 * K + 32 * B, B, (size_t)h->Dz));
     }
     h->Kcap = Kcap;
     return CHB_OK;
@@ -304,7 +322,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
                            h->memb_id.p, h->stream);
         launch_bin_centers(h->X.p, h->D, h->Dp, h->memb_id.p, h->bin_ptr.p, h->B, h->centers.p, h->stream);
         launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
-                             h->Zs.p, h->Dz, h->znrm_s.p, h->zrho_s.p, h->stream);
+                             h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, h->stream);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -338,30 +356,27 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         const int nq64 = (q_hi - q_lo + kQTile - 1) / kQTile;
         launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
         if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
-        PrefilterArgs pa{};
         {
-            Timed t(h, "query_shadow", (double)(q_hi - q_lo) * h->B);
-            launch_query_shadow(h->X.p, h->D, h->Dp, h->bq.p, q_lo, q_hi, h->B, h->Kcap, h->centers.p, h->Zq.p,
-                                h->Dz, h->qs.p, s);
+            Timed t(h, "query_norms", (double)(q_hi - q_lo) * h->B);
+            launch_query_norms(h->X.p, h->D, h->Dp, h->bq.p, q_lo, q_hi, h->B, h->Kcap, h->centers.p,
+                               h->shadow_scale, h->qn.p, s);
         }
-        pa.Zq = h->Zq.p; pa.qs = reinterpret_cast<const float4 *>(h->qs.p);
-        // the members' shadow rows (relative to their bin's centre) gathered into CSR order
+        // the members' shadow rows (relative to their bin's centre) gathered into padded CSR order
         {
             Timed t(h, "bucket", 0.0);
-            launch_pack_rows(Shadow{h->Zs.p, h->znrm_s.p, h->zrho_s.p, h->Dz}, h->memb_id.p, h->bin_ptr.p,
-                             h->B, (int)h->N, h->Zp.p, h->znrm_p.p, h->zrho_p.p, s);
-            launch_bin_bounds(h->zrho_p.p, h->znrm_p.p, h->bin_ptr.p, h->B, h->rho_bin.p, h->sn_bin.p, s);
+            launch_pack_rows(h->Zs.p, h->ms.p, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->pk.view(), s);
         }
-        pa.shm = Shadow{h->Zp.p, h->znrm_p.p, h->zrho_p.p, h->Dz};
-        pa.rho_bound = h->rho_bin.p; pa.sn_bound = h->sn_bin.p;
+        ShortlistArgs pa{};
+        pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
+        pa.qn = reinterpret_cast<const float2 *>(h->qn.p);
+        pa.P = h->pk.view(); pa.Dz = h->Dz; pa.S = h->shadow_scale;
         pa.bq = h->bq.p; pa.pos_begin = q_lo; pa.pos_end = q_hi;
-        pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p;
+        pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p; pa.update = false;
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
         pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
-        pa.inf_ptr = h->inf_const.p;
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
-            launch_prefilter(pa, h->flags64.p, s);
+            launch_shortlist(pa, h->flags64.p, s);
         }
         RescoreArgs ra{};
         ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = q_lo; ra.pos_end = q_hi;
@@ -406,24 +421,25 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             // the exact m-th distance, exact rescoring seeded with the base list
             const int nq64 = (hi - lo + kQTile - 1) / kQTile;
             launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
-            PrefilterArgs pa{};
-            pa.Zq = h->Zq.p; pa.qs = reinterpret_cast<const float4 *>(h->qs.p);   // built at batch start
-            launch_pack_centered(h->X.p, h->D, h->Dp, h->memb2_id.p, h->bin_ptr2.p, h->B, 2 * h->K,
-                                 h->centers.p, h->Zp2.p, h->Dz, h->znrm_p2.p, h->zrho_p2.p, s);
-            launch_bin_bounds(h->zrho_p2.p, h->znrm_p2.p, h->bin_ptr2.p, h->B, h->rho_bin2.p, h->sn_bin2.p, s);
-            pa.shm = Shadow{h->Zp2.p, h->znrm_p2.p, h->zrho_p2.p, h->Dz};
-            pa.rho_bound = h->rho_bin2.p; pa.sn_bound = h->sn_bin2.p;
+            // (fit rounds only produce the "earlier" / "later" eligibility codes, which have the affine
+            // form the shortlist kernel evaluates; chb_topm_per_bin's "not equal" code stays on launch_topm)
+            launch_pack_centered(h->X.p, h->D, h->Dp, h->memb2_id.p, h->memb2_code.p, h->bin_ptr2.p, h->B, 2 * h->K,
+                                 h->centers.p, h->mu_g.p, h->shadow_scale, h->Dz, h->pk2.view(), s);
+            ShortlistArgs pa{};
+            pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
+            pa.qn = reinterpret_cast<const float2 *>(h->qn.p);   // built at batch start
+            pa.P = h->pk2.view(); pa.Dz = h->Dz; pa.S = h->shadow_scale;
             pa.bq = h->bq.p; pa.pos_begin = lo; pa.pos_end = hi;
-            pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.memb_code = h->memb2_code.p;
+            pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.update = true;
             pa.seed = h->L0();
             pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
             pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
-            pa.active = h->active.p; pa.n_active = h->n_active.p;
-            pa.inf_ptr = h->inf_const.p; pa.code_s = h->code_s.p; pa.code_b = h->code_b.p;
-            launch_fill_i32(h->n_active.p, 0, 1, s);
             {
                 Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
-                launch_prefilter(pa, h->flags64.p, s);
+                launch_shortlist(pa, h->flags64.p, s);
+                // the (position, bin) pairs with a non-empty shortlist, for rescore_kernel
+                launch_compact_active(h->cand_cnt.p, lo, hi, h->B, h->Kcap, h->act_blk.p, h->active.p,
+                                      h->n_active.p, s);
             }
             RescoreArgs ra{};
             ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = lo; ra.pos_end = hi;
@@ -484,8 +500,8 @@ int batch_commit_dev(chb_ctx *h, const int *final_dev)
     launch_scatter_labels(h->labels.p, h->bq.p, final_dev, h->K, s);
     launch_mark_batch(h->inb.p, h->bq.p, h->K, 0, s);
     if (h->use_prefilter && h->shadow_ok && h->centers.p)   // their bin (hence their centre) changed
-        launch_sample_shadow(h->X.p, h->D, h->Dp, h->bq.p, h->K, h->labels.p, h->B, h->centers.p, h->Zs.p,
-                             h->Dz, h->znrm_s.p, h->zrho_s.p, s);
+        launch_sample_shadow(h->X.p, h->D, h->Dp, h->bq.p, h->K, h->labels.p, h->B, h->centers.p, h->mu_g.p,
+                             h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, s);
     HIPCHK(hipGetLastError());
     h->batch_open = false;
     return CHB_OK;
@@ -546,12 +562,10 @@ int chb_destroy(chb_ctx *h)
     for (auto *b : ib) b->release();
     DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->l2d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
-    h->Zp.release(); h->znrm_p.release(); h->zrho_p.release(); h->rho_bin.release();
-    h->Zs.release(); h->znrm_s.release(); h->zrho_s.release(); h->sn_bin.release(); h->sn_bin2.release();
-    h->Zq.release(); h->qs.release();
-    h->Zp2.release(); h->znrm_p2.release(); h->zrho_p2.release(); h->rho_bin2.release(); h->centers.release();
-    h->code_s.release(); h->code_b.release(); h->inf_const.release();
-    h->active.release(); h->n_active.release();
+    h->Gs.release(); h->Zs.release(); h->gq.release(); h->ms.release(); h->mu_g.release();
+    h->colsum_part.release(); h->rmax.release(); h->pk.release(); h->pk2.release(); h->qn.release();
+    h->centers.release();
+    h->active.release(); h->n_active.release(); h->act_blk.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
     return CHB_OK;
@@ -571,16 +585,36 @@ static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D,
                             h->stream));
     h->N = N; h->D = (int)D; h->Dp = Dp;
     h->fit_open = false; h->batch_open = false;
-    // the shortlist stage (prefilter_kernels.hip) keeps its query fragments in registers: Dz <= 160
+    // the shortlist stage (prefilter_kernels.hip) keeps its query fragments in registers: D <= 160
     h->shadow_ok = false;
-    const int Dz = (int)((D + 15) / 16) * 16;
-    if (h->use_prefilter && Dz <= 160) {
-        HIPCHK(h->Zp.ensure((size_t)(N + 64) * Dz));   // + slack: the DMA path reads whole 32-row tiles
-        HIPCHK(h->znrm_p.ensure((size_t)N));
-        HIPCHK(h->zrho_p.ensure((size_t)N));
+    const int Dz = shadow_row_elems((int)D);
+    if (h->use_prefilter && Dz > 0) {
+        // global mean, the power-of-two scale that puts every centred feature inside +-2^14, and the
+        // query-side shadow row of every sample: functions of X alone
+        const int part_blocks = 1024;
+        HIPCHK(h->mu_g.ensure((size_t)Dp));
+        HIPCHK(h->colsum_part.ensure((size_t)part_blocks * Dp));
+        HIPCHK(h->rmax.ensure(1));
+        HIPCHK(h->Gs.ensure((size_t)N * Dz));
+        HIPCHK(h->gq.ensure((size_t)N * 2));
         HIPCHK(h->Zs.ensure((size_t)N * Dz));
-        HIPCHK(h->znrm_s.ensure((size_t)N));
-        HIPCHK(h->zrho_s.ensure((size_t)N));
+        HIPCHK(h->ms.ensure((size_t)N * 4));
+        launch_global_center(h->X.p, (int)N, (int)D, Dp, h->colsum_part.p, part_blocks, h->mu_g.p, h->rmax.p,
+                             h->stream);
+        unsigned int rbits = 0;
+        HIPCHK(hipMemcpyAsync(&rbits, h->rmax.p, sizeof(rbits), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float R;
+        memcpy(&R, &rbits, sizeof(R));
+        double S = 1.0;
+        if (R > 0.f && std::isfinite(R)) {
+            int e = 0;
+            (void)std::frexp((double)R, &e);   // R < 2^e
+            S = std::ldexp(1.0, 13 - e);       // |x - mu_c| S <= 2 R S < 2^14
+        }
+        h->shadow_scale = S;
+        launch_global_shadow(h->X.p, (int)N, (int)D, Dp, h->mu_g.p, S, h->Gs.p, Dz, h->gq.p, h->stream);
+        HIPCHK(hipGetLastError());
         h->Dz = Dz;
         h->shadow_ok = true;
     }

@@ -40,54 +40,61 @@ void launch_topm_flagged(const TopmArgs &a, const int *flags64, hipStream_t s);
 // ---- two-stage exact selection (prefilter_kernels.hip + rescore in topm_kernels.hip)
 constexpr int kCandCap = 128;   // shortlist capacity per (bin, batch position)
 
-// Low-precision shadow rows (one per CSR entry): features minus the bin's centre rounded to bf16,
-// the exact squared norm of the rounded vector and the exact rounding distance rho = ||zhat - z||.
-struct Shadow {
-    const unsigned short *Z;  // [rows][Dz] bf16, Dz % 16 == 0, zero padded
-    const float *nrm;         // [rows] ||zhat||^2 (rounded up)
-    const float *rho;         // [rows] ||zhat - z|| (rounded up)
-    int Dz;
+// fp16 shadow data of the shortlist stage (prefilter_kernels.hip explains the quantities).
+// Members of all bins, grouped by bin, every bin padded to a multiple of 32 rows:
+struct MemberPack {
+    unsigned short *Z;        // [rows][Dz] fp16 bits of (x_p - mu_c) S; zero rows in the padding
+    float *bias;              // [rows] ||zh||^2 + 2 <(mu_c - mu_g) S, zh>; +inf in the padding
+    float *rho, *nrm, *amax;  // [rows] rounding distance, ||zh||^2, ||zh||^2 + 2 |<..>|
+    float *cs, *cb;           // [rows] update mode: entry eligible for position q <=> cs q + cb >= 0
+    int *pad_ptr;             // [B+1] first row of each bin (multiples of 32)
+    float4 *bb;               // [B] {largest rho, largest ||zh||, largest amax, -}
 };
+int shadow_row_elems(int D);   // Dz: 144 or 160 (0: D too large for the shortlist stage)
+// mu_g = column means (deterministic two-pass sum), *rmax = float bits of max |x - mu_g|
+void launch_global_center(const double *X, int N, int D, int Dp, double *part, int part_blocks, double *mu_g,
+                          unsigned int *rmax, hipStream_t s);
+// query-side rows of all samples: Gs[N][Dz], gq[N] = float2 {||qh||^2, rho}
+void launch_global_shadow(const double *X, int N, int D, int Dp, const double *mu_g, double S,
+                          unsigned short *Gs, int Dz, void *gq, hipStream_t s);
 void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
                         double *centers, hipStream_t s);
-void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
-                          int rows_hint, const double *centers, unsigned short *Zp, int Dz, float *nrm_p,
-                          float *rho_p, hipStream_t s);
-void launch_query_shadow(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
-                         int Kcap, const double *centers, unsigned short *Zq, int Dz, void *qs,
-                         hipStream_t s);
-void launch_bin_bounds(const float *rho_p, const float *nrm_p, const int *bin_ptr, int B, float *rho_out,
-                       float *sn_out, hipStream_t s);
+// member-side row of each listed sample relative to the centre of its current bin:
+// Zs[N][Dz], ms[N] = float4 {bias, rho, ||zh||^2, amax}
 void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, const int *labels,
-                          int B, const double *centers, unsigned short *Zs, int Dz, float *nrm_s,
-                          float *rho_s, hipStream_t s);
-void launch_pack_rows(const Shadow &src, const int *memb_id, const int *bin_ptr, int B, int n_max,
-                      unsigned short *Zp, float *nrm_p, float *rho_p, hipStream_t s);
+                          int B, const double *centers, const double *mu_g, double S, unsigned short *Zs,
+                          int Dz, void *ms, hipStream_t s);
+// base members (CSR) -> padded pack (+ pad_ptr, per-bin bounds)
+void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
+                      int B, int rows_hint, const MemberPack &P, hipStream_t s);
+// the batch's own entries (CSR + eligibility codes) -> padded pack (+ pad_ptr, per-bin bounds)
+void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *memb_code,
+                          const int *bin_ptr, int B, int rows_hint, const double *centers, const double *mu_g,
+                          double S, int Dz, const MemberPack &P, hipStream_t s);
+// qn[B][Kcap] = float2 {||(x_j - mu_c) S||^2 rounded up, rounded down}
+void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
+                        int Kcap, const double *centers, double S, void *qn, hipStream_t s);
 
-struct PrefilterArgs {
-    const unsigned short *Zq; // [B][Kcap][Dz] query shadow rows bf16(x_j - mu_c) (query_shadow_kernel)
-    const float4 *qs;         // [B][Kcap] {||zh||^2, rho, ||z||^2 up, ||z||^2 down} of that row
-    Shadow shm;             // member rows relative to their bin's centre, packed in CSR order
-    const float *rho_bound; // [B] largest rho among each bin's packed members
-    const float *sn_bound;  // [B] largest ||zh|| among each bin's packed members
+struct ShortlistArgs {
+    const unsigned short *Gs;  // [N][Dz] query-side rows
+    const float2 *gq;          // [N]
+    const float2 *qn;          // [B][Kcap]
+    MemberPack P;
+    int Dz;
+    double S;
     const int *bq;
     int pos_begin, pos_end;
-    const int *bin_ptr;
+    const int *bin_ptr;        // (unpadded) CSR the pack was built from
     const int *memb_id;
-    const int *memb_code;  // non-null selects the update mode: batch members, fixed tau from `seed`
-    float *code_s, *code_b;  // update mode scratch [#members]: memb_code as (s, b), eligible <=> s q + b >= 0
-    const float *inf_ptr;    // one float +infinity in device memory (DMA source for rows past a bin's end)
+    bool update;               // update mode: the batch's own entries, fixed tau from `seed`
     Lists seed;
     int B, m, Kcap;
     int *cand;       // [B][Kcap][kCandCap] sample indices
     int *cand_cnt;   // [B][Kcap]
-    int *active;     // update mode: compacted list of (position, bin) pairs with a non-empty shortlist
-    int *n_active;   // [1]
     int *overflow;   // [1] number of (bin, position) pairs whose shortlist overflowed
 };
 // flags64[bin][ceil(nq/64)] (pre-zeroed): set for (query tile of 64, bin) pairs whose shortlist overflowed
-void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s);
-size_t prefilter_lds_bytes(int Dz);
+void launch_shortlist(const ShortlistArgs &a, int *flags64, hipStream_t s);
 
 struct RescoreArgs {
     const double *X;
@@ -144,6 +151,10 @@ void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K,
 // round-0 label guess: lab_old where >= 0, else bin of the nearest outside member
 void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old, int p0, int p1,
                   int B, int m, int Kcap, int *lab_prev, hipStream_t s);
+// active[] = the pairs (pos - pos_begin) * B + bin whose cand_cnt is positive, *n_active their number
+// (blk_cnt: scratch, one int per 4096 pairs)
+void launch_compact_active(const int *cand_cnt, int pos_begin, int pos_end, int B, int Kcap, int *blk_cnt,
+                           int *active, int *n_active, hipStream_t s);
 // select up to m smallest (row[p], p) among labels[p] == c; one workgroup
 void launch_select_row(const int *labels, const double *row, int N, int c, int m, int *out_idx,
                        int *out_cnt, hipStream_t s);

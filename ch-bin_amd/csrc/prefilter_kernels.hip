@@ -1,4 +1,4 @@
-// Stage 1 of the two-stage EXACT nearest-member selection: a bf16 matrix-core shortlist.
+// Stage 1 of the two-stage EXACT nearest-member selection: an fp16 matrix-core shortlist.
 //
 // The reference selects the m nearest members of every bin from an exact distance row
 // (distance_matrix.py:47-62 over distance_matrix.py:33-44).  Computing every one of the N^2
@@ -8,22 +8,30 @@
 // cdist-rounded distance on the shortlist only.  The final result is bit-identical to the
 // brute-force path (and is checked against it in tests/).
 //
-// Guarantee.  For the members of bin c and the queries examined against bin c let z = x - mu_c
-// (mu_c = any fixed centre; the mean of the bin's current members is used, so member vectors are
-// small and the bf16 rounding error is RELATIVE to the within-bin spread, whatever the absolute
-// scale of the features -- coverage columns of magnitude 0.2 next to k-mer frequencies of 0.007
-// included), zh = bf16(z) and rho = ||zh - z||_2, measured exactly when the shadow row is built
-// (members: once per batch in pack_centered_kernel; queries: in the kernel prologue).  By the
-// triangle inequality
-//     | ||x_j - x_p|| - ||zh_j - zh_p|| |  <=  rho_j + rho_p .
-// ||zh_j - zh_p||^2 = n_j + n_p - 2 <zh_j, zh_p> with n = ||zh||^2 exact and the dot product from
-// v_mfma_f32_32x32x16_bf16 (bf16 products are exact in fp32; accumulation error <= g (n_j + n_p)
-// with g = 1e-4, several times the worst-case fp32 summation bound for D <= 512).  Hence for every
-// member p:  LB(j,p) <= d(j,p) <= UB(j,p).  The kernel keeps tau = (an upper bound of) the m-th
-// smallest UB seen so far in the bin -- at least m members are provably within tau -- and
-// shortlists every member with LB <= tau.  Any member of the true top-m has d <= tau, hence
-// LB <= tau: it is on the list.  A relative slack of 1e-6 covers fp32 rounding of the bound
-// arithmetic itself and the fp64 rounding of the exact distances.
+// Shadows.  S is one power of two for the whole fit (all features end up within +-2^14, the
+// comfortable middle of the fp16 range; multiplying by it is exact) and mu_g the global mean.
+//   member p of bin c :  zh_p = fp16((x_p - mu_c) S)      mu_c = centre of bin c (fixed during a fit)
+//                        rho_p = ||zh_p - (x_p - mu_c) S||   measured exactly when the row is built
+//                        bias_p = ||zh_p||^2 + 2 <(mu_c - mu_g) S, zh_p>
+//   query j (any bin) :  qh_j = fp16((x_j - mu_g) S),  rho_j = ||qh_j - (x_j - mu_g) S||   (once per fit)
+//   query j vs bin c  :  N_jc = ||(x_j - mu_c) S||^2 in fp64 (query_norms_kernel, once per batch)
+// Members are centred on their own bin, so their rounding error is relative to the within-bin spread
+// whatever the absolute scale of the features; the query keeps ONE row for all bins.
+//
+// Guarantee.  With z_j = (x_j - mu_c) S exact,
+//     T(j,p) := ||z_j - zh_p||^2 = N_jc + bias_p - 2 <qh_j, zh_p> - 2 <(x_j - mu_g) S - qh_j, zh_p>
+// and the matrix core returns acc = -bias_p / 2 + <qh_j, zh_p> (v_mfma_f32_32x32x16_f16: fp16
+// products are exact in fp32), so that | T - (N_jc - 2 acc) | <= E(j,c) with
+//     E = 2^-24 Bmax_c + g (Bmax_c + 2 ||qh_j|| snb_c) + 2 rho_j snb_c
+// (rounding of bias to fp32; accumulation error, g = 1e-4 is several times the worst-case fp32
+// summation bound for D <= 512; Cauchy-Schwarz on the query's rounding error, damped by the small
+// norm snb_c = max ||zh_p|| of the bin-centred members; Bmax_c = max (||zh_p||^2 + 2 |<..>|)).
+// By the triangle inequality | S d(j,p) - sqrt(T) | <= rho_p <= rho_bin, hence for every member
+//     LB(j,p) <= S d(j,p) <= UB(j,p),   UB/LB = sqrt(N_jc - 2 acc +- E) +- rho_bin .
+// Sweep 0 over a bin learns tau = (an upper bound of) the m-th smallest UB -- at least m members
+// are provably within tau -- and sweep 1 shortlists every member with LB <= tau.  Any member of
+// the true top-m has d <= tau, hence LB <= tau: it is on the list.  A relative slack of 1e-6
+// covers fp32 rounding of the bound arithmetic itself and the fp64 rounding of the exact distances.
 // If a shortlist overflows its capacity the (query tile, bin) is flagged and recomputed by the
 // brute-force tile kernel, so correctness never depends on the data.
 #include "chb_internal.h"
@@ -34,18 +42,12 @@
 
 #include <algorithm>
 
-#ifndef CHB_PF_DEEP
-#define CHB_PF_DEEP 0
-#endif
-#ifndef CHB_PF_WAVES
-#define CHB_PF_WAVES 3
-#endif
-
 namespace chb {
 namespace {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr float kGamma = 1e-4f;
 constexpr float kSlack = 1e-6f;
@@ -59,11 +61,84 @@ __device__ __forceinline__ float round_up_f32(double v)
     return f;
 }
 
-__device__ __forceinline__ unsigned short bf16_rn(float zf)
+// fp16 shadow of a scaled feature; `back` is the value the matrix core will see
+__device__ __forceinline__ unsigned short f16_shadow(double zs, double &back)
 {
-    unsigned int u = __float_as_uint(zf);
-    u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;   // round-to-nearest-even
-    return (unsigned short)u;
+    float f = (float)zs;
+    f = fminf(fmaxf(f, -65504.f), 65504.f);   // (S keeps real data far inside; NaN-free whatever comes)
+    const _Float16 hv = (_Float16)f;
+    back = (double)(float)hv;
+    return __builtin_bit_cast(unsigned short, hv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fit-level preparation
+
+// partial column sums of rows [r0, r1) -> part[blockIdx.x][Dp]; summed in block order by the
+// second kernel (deterministic)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const double *X, int N, int Dp, int rows_per,
+                                                             double *part)
+{
+    const int r0 = blockIdx.x * rows_per, r1 = min(N, r0 + rows_per);
+    for (int k = threadIdx.x; k < Dp; k += 256) {
+        double s = 0.0;
+        for (int r = r0; r < r1; ++r) s += X[(size_t)r * Dp + k];
+        part[(size_t)blockIdx.x * Dp + k] = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double *part, int nblk, int N, int Dp,
+                                                           double *mu_g)
+{
+    for (int k = threadIdx.x; k < Dp; k += 256) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += part[(size_t)b * Dp + k];
+        mu_g[k] = N > 0 ? s / (double)N : 0.0;
+    }
+}
+// *rmax (float bits, pre-zeroed) = max |x - mu_g| over everything
+__global__ __launch_bounds__(256) void absmax_kernel(const double *X, int N, int Dp, const double *mu_g,
+                                                     unsigned int *rmax)
+{
+    float v = 0.f;
+    const long long tot = (long long)N * Dp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
+        const double d = fabs(X[i] - mu_g[i % Dp]);
+        v = fmaxf(v, d < 3e38 ? round_up_f32(d) : 3e38f);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(rmax, __float_as_uint(v));
+}
+
+// Query-side rows of ALL samples (any sample can become a batch position), relative to the global
+// mean; gq[p] = {||qh||^2 rounded up, rho rounded up}.  One wavefront per sample.
+__global__ __launch_bounds__(256) void global_shadow_kernel(const double *X, int N, int D, int Dp,
+                                                            const double *mu_g, double S, unsigned short *Gs,
+                                                            int Dz, float2 *gq)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= N) return;
+    const double *x = X + (size_t)p * Dp;
+    double n2 = 0.0, e2 = 0.0;
+    for (int k = lane; k < Dz; k += 64) {
+        unsigned short hb = 0;
+        if (k < D) {
+            const double z = (x[k] - mu_g[k]) * S;
+            double zh;
+            hb = f16_shadow(z, zh);
+            n2 += zh * zh;
+            e2 += (zh - z) * (zh - z);
+        }
+        Gs[(size_t)p * Dz + k] = hb;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        n2 += __shfl_xor(n2, off, 64);
+        e2 += __shfl_xor(e2, off, 64);
+    }
+    if (lane == 0)
+        gq[p] = make_float2(round_up_f32(n2 * (1.0 + 1e-12)), round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300));
 }
 
 // centers[c][k] = mean over the members of bin c (0 for an empty bin); one block per bin, a thread
@@ -82,49 +157,44 @@ __global__ __launch_bounds__(256) void bin_center_kernel(const double *X, int D,
     }
 }
 
-// Shadow rows of the CSR-ordered members, relative to their bin's centre, stored contiguously in
-// CSR order (the shortlist kernel streams plain sequential memory).  One wavefront per member.
-__global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int D, int Dp,
-                                                            const int *memb_id, const int *bin_ptr,
-                                                            const double *centers, unsigned short *Zp,
-                                                            int Dz, float *nrm_p, float *rho_p)
+// Member-side shadow of one sample relative to bin c's centre, computed by one wavefront.
+// Returns (on every lane) {bias, rho, ||zh||^2, ||zh||^2 + 2 |<(mu_c - mu_g) S, zh>|}.
+__device__ __forceinline__ float4 member_shadow_row(const double *x, const double *mu, const double *mu_g,
+                                                    double S, int D, int Dz, int lane, unsigned short *zrow)
 {
-    const int c = blockIdx.x;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const double *mu = centers + (size_t)c * Dp;
-    for (int e = bin_ptr[c] + blockIdx.y * 4 + w; e < bin_ptr[c + 1]; e += gridDim.y * 4) {
-        const double *x = X + (size_t)memb_id[e] * Dp;
-        double n2 = 0.0, e2 = 0.0;
-        for (int k = lane; k < Dz; k += 64) {
-            unsigned short hb = 0;
-            if (k < D) {
-                const double z = x[k] - mu[k];
-                hb = bf16_rn((float)z);
-                const double zh = (double)__uint_as_float(((unsigned int)hb) << 16);
-                n2 += zh * zh;
-                e2 += (zh - z) * (zh - z);
-            }
-            Zp[(size_t)e * Dz + k] = hb;
+    double n2 = 0.0, e2 = 0.0, sp = 0.0;
+    for (int k = lane; k < Dz; k += 64) {
+        unsigned short hb = 0;
+        if (k < D) {
+            const double z = (x[k] - mu[k]) * S;
+            double zh;
+            hb = f16_shadow(z, zh);
+            n2 += zh * zh;
+            e2 += (zh - z) * (zh - z);
+            sp += ((mu[k] - mu_g[k]) * S) * zh;
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            n2 += __shfl_xor(n2, off, 64);
-            e2 += __shfl_xor(e2, off, 64);
-        }
-        if (lane == 0) {
-            nrm_p[e] = round_up_f32(n2 * (1.0 + 1e-12));
-            rho_p[e] = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
-        }
+        zrow[k] = hb;
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        n2 += __shfl_xor(n2, off, 64);
+        e2 += __shfl_xor(e2, off, 64);
+        sp += __shfl_xor(sp, off, 64);
+    }
+    float4 o;
+    o.x = (float)(n2 + 2.0 * sp);
+    o.y = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
+    o.z = round_up_f32(n2 * (1.0 + 1e-12));
+    o.w = round_up_f32((n2 + 2.0 * fabs(sp)) * (1.0 + 1e-12));
+    return o;
 }
 
-// Per-sample shadow rows relative to the centre of the sample's CURRENT bin (labels[p] >= 0).
+// Per-sample member rows relative to the centre of the sample's CURRENT bin (labels[p] >= 0).
 // ids == nullptr: all samples 0..n-1; otherwise the n listed samples (the batch just committed).
-// One wavefront per sample.
 __global__ __launch_bounds__(256) void sample_shadow_kernel(const double *X, int D, int Dp, const int *ids,
                                                             int n, const int *labels, int B,
-                                                            const double *centers, unsigned short *Zs,
-                                                            int Dz, float *nrm_s, float *rho_s)
+                                                            const double *centers, const double *mu_g, double S,
+                                                            unsigned short *Zs, int Dz, float4 *ms)
 {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -132,467 +202,212 @@ __global__ __launch_bounds__(256) void sample_shadow_kernel(const double *X, int
     const int p = ids ? ids[i] : i;
     const int c = labels[p];
     if (c < 0 || c >= B) return;
-    const double *mu = centers + (size_t)c * Dp;
-    const double *x = X + (size_t)p * Dp;
-    double n2 = 0.0, e2 = 0.0;
-    for (int k = lane; k < Dz; k += 64) {
-        unsigned short hb = 0;
-        if (k < D) {
-            const double z = x[k] - mu[k];
-            hb = bf16_rn((float)z);
-            const double zh = (double)__uint_as_float(((unsigned int)hb) << 16);
-            n2 += zh * zh;
-            e2 += (zh - z) * (zh - z);
-        }
-        Zs[(size_t)p * Dz + k] = hb;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        n2 += __shfl_xor(n2, off, 64);
-        e2 += __shfl_xor(e2, off, 64);
-    }
-    if (lane == 0) {
-        nrm_s[p] = round_up_f32(n2 * (1.0 + 1e-12));
-        rho_s[p] = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
-    }
+    const float4 o = member_shadow_row(X + (size_t)p * Dp, centers + (size_t)c * Dp, mu_g, S, D, Dz, lane,
+                                       Zs + (size_t)p * Dz);
+    if (lane == 0) ms[p] = o;
 }
 
-// Gathers the per-sample shadow rows of the CSR-ordered members into contiguous storage.
-__global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs, const float *nrm_s,
-                                                        const float *rho_s, int Dz, const int *memb_id,
-                                                        const int *bin_ptr, int B, unsigned short *Zp,
-                                                        float *nrm_p, float *rho_p)
+// pad_ptr[c] = first row of bin c when every bin is padded to a multiple of 32 rows; one block
+__global__ __launch_bounds__(256) void pad_ptr_kernel(const int *bin_ptr, int B, int *pad_ptr)
 {
-    const int total = bin_ptr[B];
-    const int cpr = Dz >> 3;
-    const long long nch = (long long)total * cpr;
-    for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nch;
-         ch += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(ch / cpr), cc = (int)(ch - (long long)e * cpr);
-        const int id = memb_id[e];
-        *reinterpret_cast<uint4 *>(Zp + (size_t)e * Dz + cc * 8) =
-            *reinterpret_cast<const uint4 *>(Zs + (size_t)id * Dz + cc * 8);
-        if (cc == 0) { nrm_p[e] = nrm_s[id]; rho_p[e] = rho_s[id]; }
-    }
-}
-
-// Query-side shadow rows, one per (batch position, bin): bf16(x_j - mu_c) plus the four scalars
-// the bounds need {||zh||^2, rho, ||z||^2 rounded up, ||z||^2 rounded down}.  One wavefront per
-// row, lanes along the features (coalesced); computed once per batch and shared by the base and
-// the update shortlist launches.
-__global__ __launch_bounds__(256) void query_shadow_kernel(const double *X, int D, int Dp, const int *bq,
-                                                           int pos_begin, int pos_end, int B, int Kcap,
-                                                           const double *centers, unsigned short *Zq,
-                                                           int Dz, float4 *qs)
-{
-    // 16 lanes per row (4 rows per wavefront); a lane owns feature pairs (2 l + 32 t, 2 l + 32 t + 1)
-    const int l16 = threadIdx.x & 15;
-    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const long long nrow = (long long)(pos_end - pos_begin) * B;
-    const bool rvalid = row < nrow;
-    const long long rr = rvalid ? row : 0;
-    const int pos = pos_begin + (int)(rr / B), c = (int)(rr - (rr / B) * B);
-    const double *x = X + (size_t)bq[pos] * Dp;
-    const double *mu = centers + (size_t)c * Dp;
-    const size_t slot = (size_t)c * Kcap + pos;
-    double n2 = 0.0, e2 = 0.0, x2 = 0.0;
-    for (int k = 2 * l16; k < Dz; k += 32) {
-        unsigned int packed = 0u;
-        if (k < Dp) {   // Dp is even and rows are zero padded to Dp: k + 1 < Dp as well
-            const double2 xv = *reinterpret_cast<const double2 *>(x + k);
-            const double2 mv = *reinterpret_cast<const double2 *>(mu + k);
-            const double z0 = xv.x - mv.x, z1 = xv.y - mv.y;   // padding columns give exactly 0
-            const unsigned short h0 = bf16_rn((float)z0), h1 = bf16_rn((float)z1);
-            const double zh0 = (double)__uint_as_float(((unsigned int)h0) << 16);
-            const double zh1 = (double)__uint_as_float(((unsigned int)h1) << 16);
-            n2 += zh0 * zh0 + zh1 * zh1;
-            e2 += (zh0 - z0) * (zh0 - z0) + (zh1 - z1) * (zh1 - z1);
-            x2 += z0 * z0 + z1 * z1;
-            packed = (unsigned int)h0 | ((unsigned int)h1 << 16);
-        }
-        if (rvalid) *reinterpret_cast<unsigned int *>(Zq + slot * Dz + k) = packed;
-    }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        n2 += __shfl_xor(n2, off, 16);
-        e2 += __shfl_xor(e2, off, 16);
-        x2 += __shfl_xor(x2, off, 16);
-    }
-    if (rvalid && l16 == 0) {
-        float4 o;
-        o.x = round_up_f32(n2 * (1.0 + 1e-12));
-        o.y = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
-        o.z = round_up_f32(x2 * (1.0 + 1e-12));
-        o.w = (float)(x2 * (1.0 - 1e-6));
-        qs[slot] = o;
-    }
-}
-
-// rho_bound[c] = largest rounding distance, sn_bound[c] = largest ||zh|| among the (packed) members
-// of bin c; one block per bin
-__global__ __launch_bounds__(256) void bin_bounds_kernel(const float *rho_p, const float *nrm_p,
-                                                         const int *bin_ptr, float *rho_out, float *sn_out)
-{
-    __shared__ float red[256], red2[256];
-    const int c = blockIdx.x;
-    float v = 0.f, u = 0.f;
-    for (int e = bin_ptr[c] + threadIdx.x; e < bin_ptr[c + 1]; e += 256) {
-        v = fmaxf(v, rho_p[e]);
-        u = fmaxf(u, nrm_p[e]);
-    }
-    red[threadIdx.x] = v; red2[threadIdx.x] = u;
+    __shared__ int part[256];
+    const int per = (B + 255) / 256;
+    const int b0 = threadIdx.x * per, b1 = min(B, b0 + per);
+    int s = 0;
+    for (int c = b0; c < b1; ++c) s += (bin_ptr[c + 1] - bin_ptr[c] + kPfP - 1) / kPfP * kPfP;
+    part[threadIdx.x] = s;
     __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
-            red2[threadIdx.x] = fmaxf(red2[threadIdx.x], red2[threadIdx.x + off]);
-        }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        rho_out[c] = red[0];
-        sn_out[c] = sqrtf(red2[0]) * (1.0f + 1e-6f);
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int c = b0; c < b1; ++c) {
+        pad_ptr[c] = run;
+        run += (bin_ptr[c + 1] - bin_ptr[c] + kPfP - 1) / kPfP * kPfP;
+    }
+    if (b1 == B && b0 < B) pad_ptr[B] = run;
+    if (B == 0 && threadIdx.x == 0) pad_ptr[0] = 0;
+}
+
+// bin of padded row r (pad_ptr ascending, pad_ptr[B] > r)
+__device__ __forceinline__ int bin_of_row(const int *pad_ptr, int B, int r)
+{
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pad_ptr[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Gathers the per-sample member rows of the CSR-ordered base members into the padded layout;
+// 16 lanes per row.  Padding rows: zero features, bias = +inf (never selectable).
+__global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs, const float4 *ms, int Dz,
+                                                        const int *memb_id, const int *bin_ptr,
+                                                        const int *pad_ptr, int B, MemberPack P)
+{
+    const int total = pad_ptr[B];
+    const int cpr = Dz >> 3;
+    const int l16 = threadIdx.x & 15;
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < total; r += gridDim.x * 16) {
+        const int c = bin_of_row(pad_ptr, B, r);
+        const int e = r - pad_ptr[c];
+        const bool real = e < bin_ptr[c + 1] - bin_ptr[c];
+        const int id = real ? memb_id[bin_ptr[c] + e] : 0;
+        for (int cc = l16; cc < cpr; cc += 16) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (real) v = *reinterpret_cast<const uint4 *>(Zs + (size_t)id * Dz + cc * 8);
+            *reinterpret_cast<uint4 *>(P.Z + (size_t)r * Dz + cc * 8) = v;
+        }
+        if (l16 == 0) {
+            const float4 o = real ? ms[id] : make_float4(INFINITY, 0.f, 0.f, 0.f);
+            P.bias[r] = o.x; P.rho[r] = o.y; P.nrm[r] = o.z; P.amax[r] = o.w;
+        }
     }
 }
 
-template <int ML>
-__device__ __forceinline__ void list_insert(float (&l)[ML], float v)
+// Update mode: the batch's own entries (CSR over bins, eligibility code per entry, see
+// aux_kernels.hip) relative to the centre of the bin they are listed under, into the padded layout,
+// with the code rewritten as (s, b): "eligible for position q  <=>  s q + b >= 0".
+// Block (bin, y); one wavefront per entry.
+__global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int D, int Dp, const int *memb_id,
+                                                            const int *memb_code, const int *bin_ptr,
+                                                            const int *pad_ptr, const double *centers,
+                                                            const double *mu_g, double S, int Dz, MemberPack P)
 {
-#pragma unroll
-    for (int i = 0; i < ML; ++i) {
-        const float lo = fminf(l[i], v);
-        v = fmaxf(l[i], v);
-        l[i] = lo;
-    }
-}
-
-// UPD = false: base members of the bin, tau learned on the fly (top-m of the upper bounds).
-// UPD = true : the batch's own members (eligibility code per member, see aux_kernels.hip) against a
-//              FIXED tau = the exact m-th distance of the already known list `seed`; members that
-//              cannot displace a list entry are dropped without ever touching fp64.
-// The query fragments (B operand) are built in the prologue (x_j - mu_c -> bf16, with the exact
-// ||zh||^2 and rho of THIS query against THIS bin's centre) and live in registers for the whole
-// kernel (Dz <= 160); LDS only holds the double-buffered member tile.
-// This is the GENERIC form (any Dz <= 160, register-staged tiles, run-time step count); the two row
-// shapes of real feature tables take shortlist_kernel below.
-template <int ML, bool UPD>
-__global__ __launch_bounds__(256, CHB_PF_WAVES) void prefilter_kernel(PrefilterArgs a, int nqt, int total,
-                                                        int stride, int *flags64, int nqt64)
-{
-    constexpr int KSMAX = 10;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sPz = smem;                               // [2][kPfP][stride]
-    float *sPn = reinterpret_cast<float *>(sPz + (size_t)2 * kPfP * stride);  // [2][kPfP]
-    float *sPr = sPn + 2 * kPfP;                             // [2][kPfP]
-    int *sPid = reinterpret_cast<int *>(sPr + 2 * kPfP);     // [4][kPfP]: slot = tile & 3 (read one tile late)
-    int *sPcode = sPid + 4 * kPfP;                           // [2][kPfP]
-
-    const int per = (total + 7) >> 3;
-    const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (W >= total) return;
-    const int c = W / nqt, qt = W - c * nqt;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int col = lane & 31, h = lane >> 5;
-    const int mb = a.bin_ptr[c];
-    const int nmem = a.bin_ptr[c + 1] - mb;
-    const int pos0 = a.pos_begin + qt * kPfQ;
-    const int Dz = a.shm.Dz;
-    const int cpr = Dz >> 3;            // 16-byte chunks per row
-    const int ksteps = Dz >> 4;
-    const int m = a.m;
-
-    // my query
-    const int qpos = pos0 + 32 * w + col;
-    const bool qvalid = qpos < a.pos_end;
-    // Query fragment: lane (col, h) owns B[k = 16 s + 8 h + j][col] of the precomputed shadow row
-    // bf16(x_j - mu_c) of (this position, this bin)  (query_shadow_kernel).
-    bf16x8 qreg[KSMAX];
-    float nj, rq, njx_up, njx_dn;
-    {
-        const size_t qslot = (size_t)c * a.Kcap + (qvalid ? qpos : a.pos_end - 1);
-        const unsigned short *zq = a.Zq + qslot * Dz + h * 8;
-#pragma unroll
-        for (int sx = 0; sx < KSMAX; ++sx) {
-            if (sx < ksteps) qreg[sx] = *reinterpret_cast<const bf16x8 *>(zq + sx * 16);
-            else qreg[sx] = qreg[0];
-        }
-        const float4 q4 = a.qs[qslot];
-        nj = q4.x; rq = q4.y; njx_up = q4.z; njx_dn = q4.w;
-    }
-    // Bounds.  With z_j EXACT on the query side:
-    //   ||z_j - zh_p||^2 = ||z_j||^2 + n_p - 2 <z_j, zh_p>,   <z_j, zh_p> = <zh_j, zh_p> + <z_j - zh_j, zh_p>,
-    //   |<z_j - zh_j, zh_p>| <= rho_j sqrt(n_p) <= rho_j * snb   (snb = largest ||zh_p|| in the bin),
-    // so the query's rounding error is damped by the (small) norm of the bin-centred member instead
-    // of entering the distance at full size -- what keeps far bins, whose members are all almost
-    // equally far, from flooding the shortlist.  The matrix-core accumulation error is bounded by
-    // g (n_j + n_p) as before; the member's own rounding enters as +-rho_p <= rho_bin on d.
-    const float Aq = (2.0f * rq * a.sn_bound[c] + kGamma * nj) * (1.0f + 4.0f * kSlack);
-    const float nj_hi = (njx_up + Aq) * (1.0f + kSlack);
-    const float nj_lo = (njx_dn - Aq) * (njx_dn > Aq ? (1.0f - kSlack) : (1.0f + kSlack));
-
-    float ub[ML];
-#pragma unroll
-    for (int i = 0; i < ML; ++i) ub[i] = INFINITY;
-    float tau = INFINITY;   // m-th smallest UB over both lane halves of this query
-    int ccount = 0;
-    if (UPD && qvalid) {
-        const size_t sl = (size_t)c * a.Kcap + qpos;
-        if (a.seed.cnt[sl] >= m) {
-            const double e = a.seed.d[sl * m + m - 1];   // exact m-th distance so far
-            tau = round_up_f32(e) * (1.0f + kSlack);
-        }
-    }
-
-    const int ntile = (nmem + kPfP - 1) / kPfP;
-    const int nchunk = kPfP * cpr;      // chunks per member tile (<= 4 per thread for Dz <= 256)
-    // staging registers: up to 4 16-byte chunks per thread (Dz <= 256).  Two sets, so that the tile
-    // after next is already in flight while the current one is being consumed (one global-memory
-    // latency per tile would otherwise be exposed: a tile is only ~0.4 us of work per wavefront).
-    uint4 cA0 = {0, 0, 0, 0}, cA1 = cA0, cA2 = cA0, cA3 = cA0;
-    float nA = INFINITY;
-    int idA = -1, codeA = 0;
-#if CHB_PF_DEEP
-    uint4 cB0 = cA0, cB1 = cA0, cB2 = cA0, cB3 = cA0;
-    float nB = INFINITY;
-    int idB = -1, codeB = 0;
-#endif
-    // (named scalars + macros: a struct passed by reference to a lambda ends up in scratch)
-#define CHB_PF_FETCH_ONE(I, ST, TT)                                                               \
-    {                                                                                              \
-        const int ch = tid + 256 * (I);                                                            \
-        if (ch < nchunk) {                                                                         \
-            const int r = ch / cpr, cc = ch - r * cpr;                                             \
-            const int e = (TT) * kPfP + r;                                                         \
-            const int id = e < nmem ? mb + e : mb;                                                 \
-            ST = *reinterpret_cast<const uint4 *>(a.shm.Z + (size_t)id * Dz + cc * 8);            \
-        }                                                                                          \
-    }
-#define CHB_PF_STASH_ONE(I, ST, BB)                                                               \
-    {                                                                                    \
-        const int ch = tid + 256 * (I);                                                            \
-        if (ch < nchunk) {                                                                         \
-            const int r = ch / cpr, cc = ch - r * cpr;                                             \
-            *reinterpret_cast<uint4 *>(sPz + ((size_t)(BB) * kPfP + r) * stride + cc * 16) = ST;   \
-        }                                                                                          \
-    }
-#define CHB_PF_FETCH(TT, X)                                                                       \
-    {                                                                                              \
-        CHB_PF_FETCH_ONE(0, c##X##0, TT)                                                           \
-        CHB_PF_FETCH_ONE(1, c##X##1, TT)                                                           \
-        CHB_PF_FETCH_ONE(2, c##X##2, TT)                                                           \
-        CHB_PF_FETCH_ONE(3, c##X##3, TT)                                                           \
-        if (tid < kPfP) {                                                                          \
-            const int e = (TT) * kPfP + tid;                                                       \
-            if (e < nmem) {                                                                        \
-                id##X = a.memb_id[mb + e];                                                         \
-                n##X = a.shm.nrm[mb + e];                                                          \
-                code##X = UPD ? a.memb_code[mb + e] : 0;                                           \
-            } else {                                                                               \
-                id##X = -1; n##X = INFINITY; code##X = 0;                                          \
-            }                                                                                      \
-        }                                                                                          \
-    }
-#define CHB_PF_STASH(BB, X, IDS)                                                                    \
-    {                                                                                              \
-        CHB_PF_STASH_ONE(0, c##X##0, BB)                                                           \
-        CHB_PF_STASH_ONE(1, c##X##1, BB)                                                           \
-        CHB_PF_STASH_ONE(2, c##X##2, BB)                                                           \
-        CHB_PF_STASH_ONE(3, c##X##3, BB)                                                           \
-        if (tid < kPfP) {                                                                          \
-            sPn[(BB) * kPfP + tid] = n##X;                                                         \
-            sPid[(IDS) * kPfP + tid] = id##X;                                                      \
-            sPcode[(BB) * kPfP + tid] = code##X;                                                   \
-        }                                                                                          \
-    }
-
-    const size_t slot = (size_t)c * a.Kcap + qpos;
-    int *cand = a.cand + slot * kCandCap;
-
-    // Two sweeps over the bin's members.  Sweep 0 (base mode only) learns tau = m-th smallest upper
-    // bound; sweep 1 shortlists against that FINAL tau, so the list holds only the members whose
-    // error interval reaches below it (about m + a handful) instead of everything that passed a
-    // still-loose running threshold.  The matrix-core work is cheap enough to do twice.
-    // rho_j + (largest rho of any member this kernel can meet): constant per (query, bin)
-    const float rsum = a.rho_bound[c] * (1.0f + kSlack);
-    unsigned pend_mask = 0u;   // candidates of the previous tile whose stores are still to be issued
-    int pend_off = 0, pend_buf = 0;
-    float thr = INFINITY;   // sweep 0: m-th smallest t1 so far
-    float C2 = FLT_MAX;     // sweep 1: admission bound on t2
-    if (UPD && tau < INFINITY) {
-        const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
-        C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
-    }
-    for (int sweep = UPD ? 1 : 0; sweep < 2; ++sweep) {
-        if (!UPD && sweep == 1) {
-            // m-th smallest t1 over BOTH lane halves of the query
-            float mg[ML];
-#pragma unroll
-            for (int i = 0; i < ML; ++i) mg[i] = ub[i];
-#pragma unroll
-            for (int i = 0; i < ML; ++i) list_insert<ML>(mg, __shfl_xor(ub[i], 32, 64));
-#pragma unroll
-            for (int i = 0; i < ML; ++i)
-                if (i == m - 1) thr = mg[i];
-        }
-        if (!UPD && sweep == 1 && thr < INFINITY) {
-            // tau = m-th smallest upper bound; at least m members are provably within it
-            tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
-            const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
-            C2 = hi * hi * (1.0f + 4.0f * kSlack) - nj_lo;
-        }
-        auto flush_pending = [&]() {
-            while (pend_mask) {
-                const int r = __ffs(pend_mask) - 1;
-                pend_mask &= pend_mask - 1u;
-                const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (pend_off < kCandCap) cand[pend_off] = sPid[pend_buf * kPfP + prow];
-                ++pend_off;
-            }
-        };
-        auto consume = [&](int buf, int idslot) {
-        flush_pending();
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const unsigned char *pbase = sPz + ((size_t)buf * kPfP + col) * stride + h * 16;
-#pragma unroll
-        for (int sx = 0; sx < KSMAX; ++sx)
-            if (sx < ksteps) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(pbase + sx * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qreg[sx], acc, 0, 0, 0);
-            }
-
-        // rows held by this lane: (r&3) + 8*(r>>2) + 4*h
-        float np[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4 *>(&sPn[buf * kPfP + 8 * g + 4 * h]);
-            np[4 * g + 0] = v.x; np[4 * g + 1] = v.y; np[4 * g + 2] = v.z; np[4 * g + 3] = v.w;
-        }
-        if (UPD) {
-            // a batch member counts for this query only on the right side of the visiting order
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int code = sPcode[buf * kPfP + (r & 3) + 8 * (r >> 2) + 4 * h];
-                bool ok = true;
-                if (code > 0) ok = qpos > code - 1;
-                else if (code <= -(1 << 30)) ok = qpos != -(1 << 30) - code;
-                else if (code < 0) ok = qpos < -code - 1;
-                if (!ok) np[r] = INFINITY;
-            }
-        }
-
-        if (sweep == 0) {
-            // Learn tau.  UB'(p) = sqrt(t1_p + n_j(1+g)) + rho_bin is monotone in
-            // t1_p = n_p(1+g) - 2<zh_j, zh_p>, so the m smallest t1 are kept (no sqrt per insert).
-            // Each lane half keeps ITS m smallest and filters against its own m-th (`thr`); the two
-            // halves of a query are merged once, after the sweep.  Per tile: the 16 values, their
-            // minimum, ONE branch; the (rare) insertions happen smallest-first inside it.
-            float t1v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t1v[r] = fmaf(kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
-            float mn = t1v[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mn = fminf(mn, t1v[r]);
-            while (mn < thr) {
-                list_insert<ML>(ub, mn);
-#pragma unroll
-                for (int i = 0; i < ML; ++i)
-                    if (i == m - 1) thr = ub[i];
-                float nx = INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    t1v[r] = t1v[r] == mn ? INFINITY : t1v[r];   // consume (all copies of a tie at once:
-                    nx = fminf(nx, t1v[r]);                     //  harmless, thr only gets looser)
-                }
-                mn = nx;
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b0 = bin_ptr[c], cnt = bin_ptr[c + 1] - b0, r0 = pad_ptr[c];
+    const int padded = pad_ptr[c + 1] - r0;
+    for (int e = blockIdx.y * 4 + w; e < padded; e += gridDim.y * 4) {
+        const int r = r0 + e;
+        if (e < cnt) {
+            const float4 o = member_shadow_row(X + (size_t)memb_id[b0 + e] * Dp, centers + (size_t)c * Dp, mu_g,
+                                               S, D, Dz, lane, P.Z + (size_t)r * Dz);
+            if (lane == 0) {
+                P.bias[r] = o.x; P.rho[r] = o.y; P.nrm[r] = o.z; P.amax[r] = o.w;
+                const int code = memb_code[b0 + e];
+                float sv = 0.f, bv = 0.f;
+                if (code > 0) { sv = 1.f; bv = -(float)code; }               // q > code - 1
+                else if (code <= -(1 << 30)) { sv = 0.f; bv = -1.f; }        // "q != i" has no affine form:
+                                                                             // never routed here (chb_api.hip)
+                else if (code < 0) { sv = -1.f; bv = (float)(-code - 2); }   // q < -code - 1
+                P.cs[r] = sv; P.cb[r] = bv;
             }
         } else {
-            // shortlist: LB' = sqrt(s - E) - rho_j - rho_bin <= tau  <=>  t2 <= C2 (constant)
-            unsigned mask = 0u;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float t2 = fmaf(-kGamma, np[r], fmaf(-2.0f, acc[r], np[r]));
-                if (t2 <= C2) mask |= 1u << r;
+            for (int k = lane; k < Dz; k += 64) P.Z[(size_t)r * Dz + k] = 0;
+            if (lane == 0) {
+                P.bias[r] = INFINITY; P.rho[r] = 0.f; P.nrm[r] = 0.f; P.amax[r] = 0.f;
+                P.cs[r] = 0.f; P.cb[r] = 0.f;
             }
-            const int cnt = __popc(mask);
-            const int pc = __shfl_xor(cnt, 32, 64);
-            // The global stores of this tile's candidates are issued at the START of the next tile
-            // (flush_pending): the barrier that ends a tile waits for vmcnt(0), and a store issued
-            // right before it would expose its whole write latency every tile.
-            pend_mask = qvalid ? mask : 0u;
-            pend_off = ccount + (h ? pc : 0);
-            pend_buf = idslot;
-            ccount += cnt + pc;
-        }
-
-        };
-        __syncthreads();
-#if CHB_PF_DEEP
-        if (ntile > 0) CHB_PF_FETCH(0, A)
-        if (ntile > 1) CHB_PF_FETCH(1, B)
-        if (ntile > 0) CHB_PF_STASH(0, A, 0)
-        __syncthreads();
-        for (int t = 0; t < ntile; t += 2) {
-            // even tile t sits in buffer 0, tile t+1 is in flight in SB
-            if (t + 2 < ntile) CHB_PF_FETCH(t + 2, A)
-            __builtin_amdgcn_sched_barrier(0);
-            consume(0, t & 3);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < ntile) CHB_PF_STASH(1, B, (t + 1) & 3)
-            __syncthreads();
-            if (t + 1 >= ntile) break;
-            // odd tile t+1 sits in buffer 1, tile t+2 is in flight in SA
-            if (t + 3 < ntile) CHB_PF_FETCH(t + 3, B)
-            __builtin_amdgcn_sched_barrier(0);
-            consume(1, (t + 1) & 3);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < ntile) CHB_PF_STASH(0, A, (t + 2) & 3)
-            __syncthreads();
-        }
-#else
-        if (ntile > 0) { CHB_PF_FETCH(0, A) CHB_PF_STASH(0, A, 0) }
-        __syncthreads();
-        for (int t = 0; t < ntile; ++t) {
-            if (t + 1 < ntile) CHB_PF_FETCH(t + 1, A)
-            __builtin_amdgcn_sched_barrier(0);
-            consume(t & 1, t & 3);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < ntile) CHB_PF_STASH((t + 1) & 1, A, (t + 1) & 3)
-            __syncthreads();
-        }
-#endif
-        flush_pending();
-    }
-
-    if (qvalid && h == 0) {
-        a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
-        if (UPD && ccount > 0 && a.active != nullptr)
-            a.active[atomicAdd(a.n_active, 1)] = (qpos - a.pos_begin) * a.B + c;
-        if (ccount > kCandCap) {
-            atomicAdd(a.overflow, 1);
-            flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
         }
     }
 }
 
+// bb[c] = {largest rounding distance, largest ||zh|| (rounded up), largest ||zh||^2 + 2|<..>|, 0}
+// over the members of bin c; one block per bin
+__global__ __launch_bounds__(256) void bin_bounds_kernel(MemberPack P, const int *bin_ptr)
+{
+    __shared__ float red[3][256];
+    const int c = blockIdx.x;
+    const int r0 = P.pad_ptr[c], cnt = bin_ptr[c + 1] - bin_ptr[c];
+    float v = 0.f, u = 0.f, a = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        v = fmaxf(v, P.rho[r0 + e]);
+        u = fmaxf(u, P.nrm[r0 + e]);
+        a = fmaxf(a, P.amax[r0 + e]);
+    }
+    red[0][threadIdx.x] = v; red[1][threadIdx.x] = u; red[2][threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int q = 0; q < 3; ++q)
+                red[q][threadIdx.x] = fmaxf(red[q][threadIdx.x], red[q][threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        P.bb[c] = make_float4(red[0][0], sqrtf(red[1][0]) * (1.0f + 1e-6f), red[2][0], 0.f);
+}
+
+// qn[c][pos] = ||(x_j - mu_c) S||^2 in fp64, rounded {up, down}.  A 64 positions x 64 bins tile per
+// block, features staged through LDS 16 at a time (already scaled by S: exact, and keeps tiny
+// feature scales away from underflow); each thread owns a 4 x 4 micro-tile.
+__global__ __launch_bounds__(256) void query_norms_kernel(const double *X, int D, int Dp, const int *bq,
+                                                          int pos_begin, int pos_end, int B, int Kcap,
+                                                          const double *centers, double S, float2 *qn)
+{
+    constexpr int KC = 16;
+    __shared__ double xs[64][KC + 1], cs[64][KC + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int p0 = pos_begin + blockIdx.x * 64, c0 = blockIdx.y * 64;
+    // staging role: row tid / 4, four consecutive features
+    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    const int spos = p0 + srow, sc = c0 + srow;
+    const double *xrow = spos < pos_end ? X + (size_t)bq[spos] * Dp : nullptr;
+    const double *crow = sc < B ? centers + (size_t)sc * Dp : nullptr;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < D; k0 += KC) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = k0 + sk + t;
+            xs[srow][sk + t] = (xrow && k < D) ? xrow[k] * S : 0.0;
+            cs[srow][sk + t] = (crow && k < D) ? crow[k] * S : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            double xv[4], cv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xv[i] = xs[4 * ty + i][kk]; cv[i] = cs[tx + 16 * i][kk]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double z = xv[i] - cv[j];
+                    acc[i][j] += z * z;
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pos = p0 + 4 * ty + i, c = c0 + tx + 16 * j;
+            if (pos < pos_end && c < B)
+                qn[(size_t)c * Kcap + pos] = make_float2(round_up_f32(acc[i][j] * (1.0 + 1e-12)),
+                                                        (float)(acc[i][j] * (1.0 - 1e-6)));
+        }
+}
 
 // ---------------------------------------------------------------------------------------------
-// The streamlined form of the kernel above for the two row shapes of real feature tables
-// (Dz = 144: 9 matrix-core steps, Dz = 160: 10).  Same bounds, same shortlist; what differs is
-// how the work is fed:
-//   * Dz / 16 is a compile-time constant, so all fragment reads of a tile are in flight together
-//     and the matrix-core steps issue back to back;
+// the shortlist kernel
+//
+// Workgroup = 128 batch positions (32 per wavefront: members are the A operand, queries the B
+// operand, so each lane owns one query column) x a run of consecutive bins.  The query fragments
+// are loaded once; the members of the run's bins stream through LDS as 32-row tiles.
+//   * Dz / 16 (9 or 10 matrix-core steps) is a compile-time constant: all fragment reads of a tile
+//     are in flight together and the steps issue back to back;
 //   * every global read inside the tile loop is an LDS-DMA (shadow rows in 1-KiB pieces, the
-//     member norms / eligibility as 4-byte pieces): no ordinary load whose use would make the
+//     member bias / eligibility as 4-byte pieces): no ordinary load whose use would make the
 //     compiler drain the DMA queue.  Three LDS buffers, two tiles in flight, one raw s_barrier and
-//     one COUNTED s_waitcnt vmcnt(n) per tile (n = this wavefront's DMA instructions per tile);
-//   * n_p (1 +- g) / 2 is folded into the accumulator's start value, so the matrix core returns
-//     -t/2 directly: sweep 0 is a 16-way maximum, sweep 1 sixteen compares;
+//     one COUNTED s_waitcnt vmcnt(n) per tile (n = this wavefront's DMA instructions per tile).
+//     The tile stream runs across sweep and bin boundaries without a bubble;
+//   * -bias/2 is the accumulator's start value, so the matrix core returns -t/2 directly: sweep 0
+//     is a 16-way maximum, sweep 1 sixteen compares;
 //   * shortlist hits are parked per wavefront in LDS as (query, member offset) words through a
-//     ballot + mbcnt compaction (no atomics, no divergent store loop) and written out once, after
-//     the last tile; the order inside a shortlist is irrelevant (rescore_kernel orders exactly).
+//     ballot + mbcnt compaction (no atomics, no divergent store loop) and written out at the end of
+//     the bin; the order inside a shortlist is irrelevant (rescore_kernel orders exactly).
+// UPD = false: base members of the bin, two sweeps (tau learned, then shortlist).
+// UPD = true : the batch's own entries against a FIXED tau = the exact m-th distance of the already
+//              known list `seed`; entries that cannot displace a list entry never touch fp64.
+
 // parked shortlist entries per wavefront (32 queries; a pool that fills up sends the wavefront's
 // queries to the brute-force fallback).  512 entries keep the workgroup at 37-40 KB of LDS, i.e.
 // four workgroups per CU; lists for m > 8 are longer and get 1024 (three per CU).
@@ -610,12 +425,11 @@ __device__ __forceinline__ void wait_vmcnt(int n)   // n: wave-uniform
 // LDS accesses of the tile loop are issued from inline asm: while an LDS-DMA is in flight the
 // compiler puts s_waitcnt vmcnt(0) in front of every LDS access it can see (it cannot tell the
 // buffers apart), which would drain the two tiles kept in flight.  The asm reads are completed by
-// lds_wait_all() before their results are used.
-using f32x4 = __attribute__((ext_vector_type(4))) float;
+// an explicit s_waitcnt lgkmcnt(0) before their results are used.
 template <int OFF>
-__device__ __forceinline__ bf16x8 lds_read_frag(unsigned addr)
+__device__ __forceinline__ f16x8 lds_read_frag(unsigned addr)
 {
-    bf16x8 v;
+    f16x8 v;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
@@ -646,30 +460,14 @@ __device__ __forceinline__ void list_insert_desc(float (&l)[ML], float v)
     }
 }
 
-// eligibility code (aux_kernels.hip) -> (s, b) with "eligible for position q  <=>  s q + b >= 0"
-__global__ __launch_bounds__(256) void code_affine_kernel(const int *memb_code, const int *bin_ptr, int B,
-                                                          float *cs, float *cb)
-{
-    const int n = bin_ptr[B];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int code = memb_code[i];
-        float sv = 0.f, bv = 0.f;
-        if (code > 0) { sv = 1.f; bv = -(float)code; }                       // q > code - 1
-        else if (code <= -(1 << 30)) { sv = 0.f; bv = -1.f; }                // "q != i" has no affine form:
-                                                                             // never routed here (launcher)
-        else if (code < 0) { sv = -1.f; bv = (float)(-code - 2); }           // q < -code - 1
-        cs[i] = sv; cb[i] = bv;
-    }
-}
-
 template <int ML, bool UPD, int KS>
-__global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(PrefilterArgs a, int nqt, int total,
-                                                                       int *flags64, int nqt64)
+__global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
+                                                                         int bpw, int *flags64, int nqt64)
 {
     constexpr int CPR = 2 * KS;              // 16-byte chunks per shadow row
     constexpr int ROWB = 32 * KS;            // bytes per shadow row
     constexpr int TILEB = kPfP * ROWB;       // one member tile
-    constexpr int METAB = 512;               // floats [0,32) n_p | [32,64) s | [64,96) b
+    constexpr int METAB = 512;               // floats [0,32) bias | [32,64) s | [64,96) b
     constexpr int BUFB = TILEB + METAB;
     constexpr int NBUF = 3;
     constexpr int kPoolW = shortlist_pool_entries(ML);
@@ -677,63 +475,44 @@ __global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(Prefilt
     unsigned *sPool = reinterpret_cast<unsigned *>(smem + NBUF * BUFB);   // [4][kPoolW]
     int *sCnt = reinterpret_cast<int *>(sPool + 4 * kPoolW);              // [kPfQ]
 
+    // consecutive workgroups alternate over the 8 XCDs: give each XCD a contiguous range of work
+    // items (bins-major), so that the member tiles of a bin stay in one L2
+    const int total = nqt * nchunk;
     const int per = (total + 7) >> 3;
     const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (W >= total) return;
-    const int c = W / nqt, qt = W - c * nqt;
+    const int chunk = W / nqt, qt = W - chunk * nqt;
+    const int c0 = chunk * bpw, c1 = min(a.B, c0 + bpw);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned smem_base = lds_addr(smem);
     const unsigned pool_base = lds_addr(sPool) + (unsigned)(w * kPoolW * 4);
     const int col = lane & 31, h = lane >> 5;
-    const int mb = a.bin_ptr[c];
-    const int nmem = a.bin_ptr[c + 1] - mb;
     const int pos0 = a.pos_begin + qt * kPfQ;
     const int m = a.m;
 
+    // my query: lane (col, h) owns B[k = 16 s + 8 h + j][col] of its global-centred row
     const int qpos = pos0 + 32 * w + col;
     const bool qvalid = qpos < a.pos_end;
-    bf16x8 qreg[KS];
-    float nj, rq, njx_up, njx_dn;
+    f16x8 qreg[KS];
+    float nq, rg;
     {
-        const size_t qslot = (size_t)c * a.Kcap + (qvalid ? qpos : a.pos_end - 1);
-        const unsigned short *zq = a.Zq + qslot * (KS * 16) + h * 8;
+        const int sidx = a.bq[qvalid ? qpos : a.pos_end - 1];
+        const unsigned short *zq = a.Gs + (size_t)sidx * (KS * 16) + h * 8;
 #pragma unroll
-        for (int sx = 0; sx < KS; ++sx) qreg[sx] = *reinterpret_cast<const bf16x8 *>(zq + sx * 16);
-        const float4 q4 = a.qs[qslot];
-        nj = q4.x; rq = q4.y; njx_up = q4.z; njx_dn = q4.w;
+        for (int sx = 0; sx < KS; ++sx) qreg[sx] = *reinterpret_cast<const f16x8 *>(zq + sx * 16);
+        const float2 g2 = a.gq[sidx];
+        nq = g2.x; rg = g2.y;
     }
-    // bounds: see prefilter_kernel
-    const float Aq = (2.0f * rq * a.sn_bound[c] + kGamma * nj) * (1.0f + 4.0f * kSlack);
-    const float nj_hi = (njx_up + Aq) * (1.0f + kSlack);
-    const float nj_lo = (njx_dn - Aq) * (njx_dn > Aq ? (1.0f - kSlack) : (1.0f + kSlack));
-    const float rsum = a.rho_bound[c] * (1.0f + kSlack);
+    const float snq = sqrtf(nq) * (1.0f + kSlack);
     const float qposf = (float)qpos;
 
-    // sweep 0: the m largest accumulator values (= m smallest t1) seen by this lane half, descending;
-    // the first ML - m slots are pinned at +inf so that the m-th largest is always lb[ML - 1]
-    float lb[ML];
-#pragma unroll
-    for (int i = 0; i < ML; ++i) lb[i] = i < ML - m ? INFINITY : -INFINITY;
-    float thr_s = -INFINITY;
-    // sweep 1 admits a member iff its accumulator >= thr2  (t2 <= C2, t2 = -2 acc)
-    float thr2 = qvalid ? -FLT_MAX : INFINITY;
-    if (UPD && qvalid) {
-        const size_t sl = (size_t)c * a.Kcap + qpos;
-        if (a.seed.cnt[sl] >= m) {
-            const float tau = round_up_f32(a.seed.d[sl * m + m - 1]) * (1.0f + kSlack);   // exact m-th distance so far
-            const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
-            thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
-        }
-    }
-    if (h == 0) sCnt[32 * w + col] = 0;
-
-    const int ntile = (nmem + kPfP - 1) / kPfP;
-    const int nvt = UPD ? ntile : 2 * ntile;   // the tile stream: sweep 0 then sweep 1
     // DMA roles: wavefront w moves the 1-KiB pieces w, w+4, w+8 of a tile (lane l of piece i fills
-    // LDS chunk 64 i + l from the global chunk the swizzle maps there); wavefront 3 also moves the
-    // norms (+ s), wavefront 2 the b column in update mode
+    // LDS chunk 64 i + l from the global chunk the swizzle maps there: chunk cs of row r sits at
+    // cs ^ f(r), f = (r >> 4) & 1 for 18 chunks per row, (r >> 2) & 3 for 20, which makes the
+    // ds_read_b128 fragment reads conflict-free); wavefront 3 also moves the bias (+ s) column,
+    // wavefront 2 the b column in update mode
     int src_off[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -747,34 +526,51 @@ __global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(Prefilt
     for (int j = 0; j < 3; ++j) n_w += (w + 4 * j < KS) ? 1 : 0;
     n_w += (w == 3) ? 1 : 0;
     n_w += (UPD && w == 2) ? 1 : 0;
-    const unsigned char *zbase = reinterpret_cast<const unsigned char *>(a.shm.Z) + (size_t)mb * ROWB;
+    const unsigned char *zall = reinterpret_cast<const unsigned char *>(a.P.Z);
 
-    int it = 0, ibuf = 0;   // next tile to issue and its buffer
+    // ---- issue side of the tile stream: (bin ic, sweep isw, tile it), two tiles ahead of the consumer
+    int ic = c0, it = 0, isw = UPD ? 1 : 0, ibuf = 0, n_issued = 0;
+    int irow0 = 0, int_ = 0;   // first padded row and tile count of bin ic
+    bool ivalid = false;
+    // move to the first / next non-empty bin
+#define CHB_SL_ISSUE_SEEK()                                                                        \
+    {                                                                                              \
+        ivalid = false;                                                                            \
+        while (ic < c1) {                                                                          \
+            irow0 = a.P.pad_ptr[ic];                                                               \
+            int_ = (a.P.pad_ptr[ic + 1] - irow0) / kPfP;                                           \
+            if (int_ > 0) { ivalid = true; break; }                                                \
+            ++ic;                                                                                  \
+        }                                                                                          \
+    }
 #define CHB_SL_ISSUE()                                                                             \
     {                                                                                              \
         unsigned char *dst_ = smem + ibuf * BUFB;                                                  \
-        const unsigned char *src_ = zbase + (size_t)it * TILEB;                                    \
+        const size_t row_ = (size_t)irow0 + (size_t)it * kPfP;                                     \
+        const unsigned char *src_ = zall + row_ * ROWB;                                            \
         _Pragma("unroll") for (int j = 0; j < 3; ++j)                                              \
             if (w + 4 * j < KS)                                                                    \
                 __builtin_amdgcn_global_load_lds(src_ + src_off[j],                                \
                     (__attribute__((address_space(3))) void *)(dst_ + (w + 4 * j) * 1024), 16, 0, 0); \
         if (w == 3) {                                                                              \
-            const int e_ = it * kPfP + col;                                                        \
-            const float *p_ = e_ < nmem ? a.shm.nrm + mb + e_ : a.inf_ptr;                         \
-            if (UPD && h) p_ = a.code_s + mb + (e_ < nmem ? e_ : nmem - 1);                        \
+            const float *p_ = ((UPD && h) ? a.P.cs : a.P.bias) + row_ + col;                       \
             __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB), 4, 0, 0); \
         }                                                                                          \
         if (UPD && w == 2) {                                                                       \
-            const int e_ = it * kPfP + col;                                                        \
-            const float *p_ = a.code_b + mb + (e_ < nmem ? e_ : nmem - 1);                         \
+            const float *p_ = a.P.cb + row_ + col;                                                 \
             __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB + 256), 4, 0, 0); \
         }                                                                                          \
-        if (++it == ntile) it = 0;                                                                 \
+        ++n_issued;                                                                                \
         if (++ibuf == NBUF) ibuf = 0;                                                              \
+        if (++it == int_) {                                                                        \
+            it = 0;                                                                                \
+            if (!UPD && isw == 0) isw = 1;                                                         \
+            else { isw = UPD ? 1 : 0; ++ic; CHB_SL_ISSUE_SEEK() }                                  \
+        }                                                                                          \
     }
-
-    if (nvt > 0) CHB_SL_ISSUE()
-    if (nvt > 1) CHB_SL_ISSUE()
+    CHB_SL_ISSUE_SEEK()
+    if (ivalid) CHB_SL_ISSUE()
+    if (ivalid) CHB_SL_ISSUE()
 
     // fragment addressing: chunk (2 sx + h) of row `col`, XOR-swizzled as the DMA laid it out
     int fbase0, fbase1;
@@ -787,227 +583,186 @@ __global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(Prefilt
         fbase0 = col * ROWB + (f1 << 5) + ((h ^ f0) << 4);
         fbase1 = col * ROWB + ((1 ^ f1) << 5) + ((h ^ f0) << 4);
     }
-    const float c0 = -0.5f * (1.0f + kGamma), c1 = -0.5f * (1.0f - kGamma);
     const unsigned ent0 = ((unsigned)col << 27) | (unsigned)(4 * h);
 
-    int ct = 0, cbuf = 0, sweep = UPD ? 1 : 0;
-    const bool tile_best = ntile >= 16;
-    int wcnt = 0;   // entries parked by this wavefront (wave-uniform)
-    for (int vt = 0; vt < nvt; ++vt) {
-        wait_vmcnt(vt + 1 < nvt ? n_w : 0);   // my pieces of tile vt have landed
-        __builtin_amdgcn_s_barrier();         // everybody's have; buffer (vt + 2) % 3 is free again
-        if (vt + 2 < nvt) CHB_SL_ISSUE()
-        if (!UPD && vt == ntile) {
-            // end of sweep 0: m-th smallest t1 over BOTH lane halves -> tau -> thr2
-            sweep = 1; ct = 0;
-            float mg[ML];
+    int cbuf = 0, n_consumed = 0;
+    for (int c = c0; c < c1; ++c) {
+        const int row0 = a.P.pad_ptr[c];
+        const int ntile = (a.P.pad_ptr[c + 1] - row0) / kPfP;
+        const size_t slot = (size_t)c * a.Kcap + (qvalid ? qpos : a.pos_end - 1);
+        // ---- per-(query, bin) bounds
+        const float4 bb = a.P.bb[c];                      // {rho_bin, snb, Bmax, -}
+        const float2 qn2 = a.qn[slot];                    // N_jc {up, down}
+        const float E = (6e-8f * bb.z + kGamma * (bb.z + 2.0f * snq * bb.y) + 2.0f * rg * bb.y) *
+                        (1.0f + 4.0f * kSlack);
+        const float nj_hi = (qn2.x + E) * (1.0f + kSlack);
+        const float nj_lo = (qn2.y - E) * (qn2.y > E ? (1.0f - kSlack) : (1.0f + kSlack));
+        const float rsum = bb.x * (1.0f + kSlack);
+        // sweep 0: the m largest accumulator values (= m smallest t) seen by this lane half,
+        // descending; the first ML - m slots are pinned at +inf so that the m-th largest is lb[ML - 1]
+        float lb[ML];
 #pragma unroll
-            for (int i = 0; i < ML; ++i) mg[i] = lb[i];
-#pragma unroll
-            for (int i = 0; i < ML; ++i) {
-                const float o = __shfl_xor(lb[i], 32, 64);
-                list_insert_desc<ML>(mg, i >= ML - m ? o : -INFINITY);   // (not the pinned slots twice)
-            }
-            const float ms = mg[ML - 1];
-            if (qvalid && ms > -INFINITY) {
-                // tau = m-th smallest upper bound; at least m members are provably within it
-                const float thr = -2.0f * ms;
-                const float tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
-                const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
-                thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
-            }
+        for (int i = 0; i < ML; ++i) lb[i] = i < ML - m ? INFINITY : -INFINITY;
+        float thr_s = -INFINITY;
+        // sweep 1 admits a member iff its accumulator >= thr2  (t <= C2, t = -2 acc)
+        float thr2 = qvalid ? -FLT_MAX : INFINITY;
+        if (UPD && qvalid && a.seed.cnt[slot] >= m) {
+            // exact m-th distance so far, in shadow units
+            const float tau = round_up_f32(a.seed.d[slot * m + m - 1] * a.S) * (1.0f + kSlack);
+            const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+            thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
         }
+        if (h == 0) sCnt[32 * w + col] = 0;
+        const bool tile_best = ntile >= 16;
+        int wcnt = 0;   // entries parked by this wavefront for this bin (wave-uniform)
 
-        const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
-        // rows held by this lane: (r & 3) + 8 (r >> 2) + 4 h
-        const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
-        f32x4 nv[4], sv[4], bv[4];
+        for (int sweep = UPD ? 1 : 0; sweep < 2; ++sweep) {
+            if (!UPD && sweep == 1) {
+                // end of sweep 0: m-th smallest t over BOTH lane halves -> tau -> thr2
+                float mg[ML];
+#pragma unroll
+                for (int i = 0; i < ML; ++i) mg[i] = lb[i];
+#pragma unroll
+                for (int i = 0; i < ML; ++i) {
+                    const float o = __shfl_xor(lb[i], 32, 64);
+                    list_insert_desc<ML>(mg, i >= ML - m ? o : -INFINITY);   // (not the pinned slots twice)
+                }
+                const float ms = mg[ML - 1];
+                if (qvalid && ms > -INFINITY) {
+                    // tau = m-th smallest upper bound; at least m members are provably within it
+                    const float thr = -2.0f * ms;
+                    const float tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
+                    const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+                    thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
+                }
+            }
+            for (int ct = 0; ct < ntile; ++ct) {
+                wait_vmcnt(n_issued - n_consumed > 1 ? n_w : 0);   // my pieces of this tile have landed
+                __builtin_amdgcn_s_barrier();   // everybody's have; the buffer two tiles ahead is free again
+                if (ivalid) CHB_SL_ISSUE()
+
+                const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
+                // rows held by this lane: (r & 3) + 8 (r >> 2) + 4 h
+                const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
+                f32x4 nv[4], sv[4], bv[4];
 #define CHB_SL_META(G)                                                                             \
-        nv[G] = lds_read_f4<32 * (G)>(ma);                                                         \
-        if (UPD) { sv[G] = lds_read_f4<128 + 32 * (G)>(ma); bv[G] = lds_read_f4<256 + 32 * (G)>(ma); }
-        CHB_SL_META(0) CHB_SL_META(1) CHB_SL_META(2) CHB_SL_META(3)
+                nv[G] = lds_read_f4<32 * (G)>(ma);                                                 \
+                if (UPD) { sv[G] = lds_read_f4<128 + 32 * (G)>(ma); bv[G] = lds_read_f4<256 + 32 * (G)>(ma); }
+                CHB_SL_META(0) CHB_SL_META(1) CHB_SL_META(2) CHB_SL_META(3)
 #undef CHB_SL_META
-        bf16x8 af[KS == 9 ? 9 : 10];
-        {
-            const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
-            if (KS == 9) {
-                af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<32>(fa0);  af[2] = lds_read_frag<64>(fa0);
-                af[3] = lds_read_frag<96>(fa0);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<160>(fa0);
-                af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<224>(fa0); af[8] = lds_read_frag<256>(fa0);
-            } else {
-                af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<0>(fa1);   af[2] = lds_read_frag<64>(fa0);
-                af[3] = lds_read_frag<64>(fa1);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<128>(fa1);
-                af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<192>(fa1); af[8] = lds_read_frag<256>(fa0);
-                af[9] = lds_read_frag<256>(fa1);
-            }
-        }
-        // every asm read above has landed once this returns (operands tied so that no use can be
-        // scheduled ahead of the wait)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]),
-                       "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]), "+v"(af[8])
-                     :
-                     : "memory");
-        if (KS == 10) asm volatile("" : "+v"(af[KS - 1]) : : "memory");
-        if (UPD)
-            asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(bv[0]), "+v"(bv[1]),
-                              "+v"(bv[2]), "+v"(bv[3]) : : "memory");
-        f32x16 acc;
-        const float cinit = sweep ? c1 : c0;
+                // (asm reads are complete once the tied s_waitcnt below returns: no use can be scheduled
+                //  ahead of it.  Two phases -- bias column, then fragments -- keep the peak register
+                //  count at four wavefronts per SIMD.)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]) : : "memory");
+                if (UPD)
+                    asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(bv[0]), "+v"(bv[1]),
+                                      "+v"(bv[2]), "+v"(bv[3]) : : "memory");
+                f32x16 acc;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            acc[4 * g + 0] = nv[g][0] * cinit; acc[4 * g + 1] = nv[g][1] * cinit;
-            acc[4 * g + 2] = nv[g][2] * cinit; acc[4 * g + 3] = nv[g][3] * cinit;
-            if (UPD) {
-                // a batch member counts for this query only on the right side of the visiting order
+                for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (fmaf(sv[g][k], qposf, bv[g][k]) < 0.f) acc[4 * g + k] = -INFINITY;
-            }
-        }
+                    for (int k = 0; k < 4; ++k) {
+                        acc[4 * g + k] = -0.5f * nv[g][k];
+                        // a batch member counts for this query only on the right side of the visiting order
+                        if (UPD && fmaf(sv[g][k], qposf, bv[g][k]) < 0.f) acc[4 * g + k] = -INFINITY;
+                    }
+                }
+                f16x8 af[KS == 9 ? 9 : 10];
+                {
+                    const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
+                    if (KS == 9) {
+                        af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<32>(fa0);  af[2] = lds_read_frag<64>(fa0);
+                        af[3] = lds_read_frag<96>(fa0);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<160>(fa0);
+                        af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<224>(fa0); af[8] = lds_read_frag<256>(fa0);
+                    } else {
+                        af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<0>(fa1);   af[2] = lds_read_frag<64>(fa0);
+                        af[3] = lds_read_frag<64>(fa1);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<128>(fa1);
+                        af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<192>(fa1); af[8] = lds_read_frag<256>(fa0);
+                        af[9] = lds_read_frag<256>(fa1);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                               "+v"(af[6]), "+v"(af[7]), "+v"(af[8])
+                             :
+                             : "memory");
+                if (KS == 10) asm volatile("" : "+v"(af[KS - 1]) : : "memory");
 #pragma unroll
-        for (int sx = 0; sx < KS; ++sx)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sx], qreg[sx], acc, 0, 0, 0);
+                for (int sx = 0; sx < KS; ++sx)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[sx], qreg[sx], acc, 0, 0, 0);
 
-        if (!UPD && sweep == 0) {
-            // acc = -t1/2 with t1 = n_p (1 + g) - 2 <zh_j, zh_p>: UB is monotone in t1, so the m
-            // LARGEST accumulators are kept; per tile a 16-way maximum and one branch
-            float mx = acc[0];
+                if (!UPD && sweep == 0) {
+                    // acc = -t/2: UB is monotone in t, so the m LARGEST accumulators are kept; per
+                    // tile a 16-way maximum and one branch
+                    float mx = acc[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-            if (tile_best) {
-                // Large bins: only the BEST of the 16 values enters the list.  The m-th best of
-                // per-(tile, lane half) bests is the m-th best of m distinct members, i.e. still a
-                // valid tau; it is the exact m-th unless two of the top m share a tile half
-                // (probability ~ m^2 / (4 ntile)), and then one rank looser.  No rescan loop.
-                if (mx > thr_s) {
-                    list_insert_desc<ML>(lb, mx);
-                    thr_s = lb[ML - 1];
-                }
-            } else
-            while (mx > thr_s) {
-                list_insert_desc<ML>(lb, mx);
-                thr_s = lb[ML - 1];
-                float nx = -INFINITY;
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                    if (tile_best) {
+                        // Large bins: only the BEST of the 16 values enters the list.  The m-th best
+                        // of per-(tile, lane half) bests is the m-th best of m distinct members, i.e.
+                        // still a valid tau; it is the exact m-th unless two of the top m share a tile
+                        // half (probability ~ m^2 / (4 ntile)), and then one rank looser.
+                        if (mx > thr_s) {
+                            list_insert_desc<ML>(lb, mx);
+                            thr_s = lb[ML - 1];
+                        }
+                    } else
+                    while (mx > thr_s) {
+                        list_insert_desc<ML>(lb, mx);
+                        thr_s = lb[ML - 1];
+                        float nx = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[r] = acc[r] == mx ? -INFINITY : acc[r];   // (all copies of a tie at once:
-                    nx = fmaxf(nx, acc[r]);                       //  harmless, thr only gets looser)
-                }
-                mx = nx;
-            }
-        } else {
-            const unsigned ebase = ent0 + (unsigned)(ct * kPfP);
+                        for (int r = 0; r < 16; ++r) {
+                            acc[r] = acc[r] == mx ? -INFINITY : acc[r];   // (all copies of a tie at once:
+                            nx = fmaxf(nx, acc[r]);                       //  harmless, thr only gets looser)
+                        }
+                        mx = nx;
+                    }
+                } else {
+                    const unsigned ebase = ent0 + (unsigned)(ct * kPfP);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool hit = acc[r] >= thr2;
-                const unsigned long long bal = __ballot(hit);
-                if (bal) {
-                    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    const int pos = wcnt + before;
-                    if (hit && pos < kPoolW) lds_write_u32(pool_base + 4u * (unsigned)pos, ebase + (unsigned)((r & 3) + 8 * (r >> 2)));
-                    wcnt += __popcll(bal);
+                    for (int r = 0; r < 16; ++r) {
+                        const bool hit = acc[r] >= thr2;
+                        const unsigned long long bal = __ballot(hit);
+                        if (bal) {
+                            const int before = __builtin_amdgcn_mbcnt_hi(
+                                (unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                            const int pos = wcnt + before;
+                            if (hit && pos < kPoolW)
+                                lds_write_u32(pool_base + 4u * (unsigned)pos,
+                                              ebase + (unsigned)((r & 3) + 8 * (r >> 2)));
+                            wcnt += __popcll(bal);
+                        }
+                    }
                 }
+                ++n_consumed;
+                if (++cbuf == NBUF) cbuf = 0;
             }
         }
-        if (++ct == ntile) ct = 0;
-        if (++cbuf == NBUF) cbuf = 0;
+
+        // ---- end of the bin: write the parked entries out
+        // entry -> (query of this wavefront, member offset in the bin)
+        const int mb = a.bin_ptr[c];
+        const int npark = wcnt < kPoolW ? wcnt : kPoolW;
+        for (int i = lane; i < npark; i += 64) {
+            const unsigned en = sPool[w * kPoolW + i];
+            const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));
+            const int off = atomicAdd(&sCnt[32 * w + qc], 1);
+            if (off < kCandCap)
+                a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * kCandCap + off] = a.memb_id[mb + e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
+        if (qvalid && h == 0) {
+            a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
+            if (ccount > kCandCap || wcnt > kPoolW) {
+                atomicAdd(a.overflow, 1);
+                flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
+            }
+        }
     }
 #undef CHB_SL_ISSUE
-
-    // write the parked entries out: entry -> (query of this wavefront, member offset in the bin)
-    const int npark = wcnt < kPoolW ? wcnt : kPoolW;
-    for (int i = lane; i < npark; i += 64) {
-        const unsigned en = sPool[w * kPoolW + i];
-        const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));
-        const int off = atomicAdd(&sCnt[32 * w + qc], 1);
-        if (off < kCandCap)
-            a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * kCandCap + off] = a.memb_id[mb + e];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
-    if (qvalid && h == 0) {
-        const size_t slot = (size_t)c * a.Kcap + qpos;
-        a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
-        if (ccount > kCandCap || wcnt > kPoolW) {
-            atomicAdd(a.overflow, 1);
-            flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
-        }
-    }
-    if (UPD && a.active != nullptr) {
-        // pairs with a non-empty shortlist, appended with ONE atomic per wavefront
-        const bool act = ccount > 0;
-        const unsigned long long bal = __ballot(act);
-        if (bal) {
-            const int leader = __ffsll((long long)bal) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(a.n_active, __popcll(bal));
-            base = __shfl(base, leader, 64);
-            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-            if (act) a.active[base + before] = (qpos - a.pos_begin) * a.B + c;
-        }
-    }
-}
-
-}  // namespace
-
-void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
-                        double *centers, hipStream_t s)
-{
-    if (B > 0) hipLaunchKernelGGL(bin_center_kernel, dim3(B), dim3(256), 0, s, X, D, Dp, memb_id, bin_ptr, centers);
-}
-
-void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
-                          int rows_hint, const double *centers, unsigned short *Zp, int Dz, float *nrm_p,
-                          float *rho_p, hipStream_t s)
-{
-    if (B <= 0) return;
-    int gy = (rows_hint / std::max(B, 1) + 15) / 16;   // ~4 members per wavefront per bin
-    gy = std::max(1, std::min(gy, 64));
-    hipLaunchKernelGGL(pack_centered_kernel, dim3(B, gy), dim3(256), 0, s, X, D, Dp, memb_id, bin_ptr,
-                       centers, Zp, Dz, nrm_p, rho_p);
-}
-
-void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, const int *labels,
-                          int B, const double *centers, unsigned short *Zs, int Dz, float *nrm_s,
-                          float *rho_s, hipStream_t s)
-{
-    if (n > 0)
-        hipLaunchKernelGGL(sample_shadow_kernel, dim3((n + 3) / 4), dim3(256), 0, s, X, D, Dp, ids, n, labels,
-                           B, centers, Zs, Dz, nrm_s, rho_s);
-}
-
-void launch_pack_rows(const Shadow &src, const int *memb_id, const int *bin_ptr, int B, int n_max,
-                      unsigned short *Zp, float *nrm_p, float *rho_p, hipStream_t s)
-{
-    if (n_max <= 0) return;
-    long long nch = (long long)n_max * (src.Dz >> 3);
-    int grid = (int)std::min<long long>((nch + 255) / 256, 8192);
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(256), 0, s, src.Z, src.nrm, src.rho, src.Dz,
-                       memb_id, bin_ptr, B, Zp, nrm_p, rho_p);
-}
-
-void launch_query_shadow(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
-                         int Kcap, const double *centers, unsigned short *Zq, int Dz, void *qs,
-                         hipStream_t s)
-{
-    const long long nrow = (long long)(pos_end - pos_begin) * B;
-    if (nrow <= 0) return;
-    hipLaunchKernelGGL(query_shadow_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, s, X, D, Dp, bq,
-                       pos_begin, pos_end, B, Kcap, centers, Zq, Dz, reinterpret_cast<float4 *>(qs));
-}
-
-void launch_bin_bounds(const float *rho_p, const float *nrm_p, const int *bin_ptr, int B, float *rho_out,
-                       float *sn_out, hipStream_t s)
-{
-    if (B > 0) hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, rho_p, nrm_p, bin_ptr, rho_out, sn_out);
-}
-
-size_t prefilter_lds_bytes(int Dz)
-{
-    const int stride = Dz * 2 + 16;
-    return (size_t)(2 * kPfP) * stride + 2 * kPfP * (4 + 4 + 4) + 4 * kPfP * 4;
+#undef CHB_SL_ISSUE_SEEK
 }
 
 static size_t shortlist_lds_bytes(int ks, int ml)
@@ -1015,53 +770,115 @@ static size_t shortlist_lds_bytes(int ks, int ml)
     return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)4 * shortlist_pool_entries(ml) * 4 + kPfQ * 4;
 }
 
-// the streamlined kernel exists for 18 or 20 16-byte chunks per row (the two row shapes its
-// source-side swizzle is laid out for); CHB_PF_V2=0 forces the generic kernel
-static bool use_shortlist_kernel(const PrefilterArgs &a)
-{
-    static int env = -1;
-    if (env < 0) { const char *e = getenv("CHB_PF_V2"); env = e ? atoi(e) : 1; }
-    return env != 0 && (a.shm.Dz == 144 || a.shm.Dz == 160) && a.inf_ptr != nullptr;
-}
-
 template <int ML, bool UPD>
-static void launch_pf(const PrefilterArgs &a, int grid, size_t lds, int nqt, int total, int stride,
-                      int *flags64, int nqt64, hipStream_t s)
+static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
 {
-    if (use_shortlist_kernel(a) && (!UPD || (a.code_s != nullptr && a.code_b != nullptr))) {
-        if (UPD)
-            hipLaunchKernelGGL(code_affine_kernel, dim3(64), dim3(256), 0, s, a.memb_code, a.bin_ptr, a.B,
-                               a.code_s, a.code_b);
-        if (a.shm.Dz == 144)
-            hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(256), shortlist_lds_bytes(9, ML), s, a,
-                               nqt, total, flags64, nqt64);
-        else
-            hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(256), shortlist_lds_bytes(10, ML), s, a,
-                               nqt, total, flags64, nqt64);
-        return;
-    }
-    hipLaunchKernelGGL((prefilter_kernel<ML, UPD>), dim3(grid), dim3(256), lds, s, a, nqt, total, stride, flags64,
-                       nqt64);
+    const int nq = a.pos_end - a.pos_begin;
+    const int nqt = (nq + kPfQ - 1) / kPfQ;
+    const int nqt64 = (nq + kQTile - 1) / kQTile;
+    // bins per workgroup: long tile streams per workgroup, but enough workgroups for the 256 CUs x 4
+    static int env_bpw = -2;
+    if (env_bpw == -2) { const char *e = getenv("CHB_SL_BPW"); env_bpw = e ? atoi(e) : 0; }
+    const long long units = (long long)nqt * a.B;
+    int bpw = (int)std::max<long long>(1, units / (UPD ? 1024 : 2048));
+    if (env_bpw > 0) bpw = env_bpw;
+    bpw = std::min(bpw, a.B);
+    const int nchunk = (a.B + bpw - 1) / bpw;
+    const int total = nqt * nchunk;
+    const int grid = ((total + 7) / 8) * 8;
+    if (a.Dz == 144)
+        hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(256), shortlist_lds_bytes(9, ML), s, a,
+                           nqt, nchunk, bpw, flags64, nqt64);
+    else
+        hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(256), shortlist_lds_bytes(10, ML), s, a,
+                           nqt, nchunk, bpw, flags64, nqt64);
 }
 
-void launch_prefilter(const PrefilterArgs &a, int *flags64, hipStream_t s)
+}  // namespace
+
+int shadow_row_elems(int D) { return D <= 144 ? 144 : (D <= 160 ? 160 : 0); }
+
+void launch_global_center(const double *X, int N, int D, int Dp, double *part, int part_blocks, double *mu_g,
+                          unsigned int *rmax, hipStream_t s)
+{
+    if (N <= 0) return;
+    const int rows_per = (N + part_blocks - 1) / part_blocks;
+    const int nblk = (N + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, s, X, N, Dp, rows_per, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, s, part, nblk, N, Dp, mu_g);
+    (void)hipMemsetAsync(rmax, 0, sizeof(unsigned int), s);
+    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, s, X, N, Dp, mu_g, rmax);
+}
+
+void launch_global_shadow(const double *X, int N, int D, int Dp, const double *mu_g, double S,
+                          unsigned short *Gs, int Dz, void *gq, hipStream_t s)
+{
+    if (N > 0)
+        hipLaunchKernelGGL(global_shadow_kernel, dim3((N + 3) / 4), dim3(256), 0, s, X, N, D, Dp, mu_g, S, Gs, Dz,
+                           reinterpret_cast<float2 *>(gq));
+}
+
+void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
+                        double *centers, hipStream_t s)
+{
+    if (B > 0) hipLaunchKernelGGL(bin_center_kernel, dim3(B), dim3(256), 0, s, X, D, Dp, memb_id, bin_ptr, centers);
+}
+
+void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, const int *labels,
+                          int B, const double *centers, const double *mu_g, double S, unsigned short *Zs,
+                          int Dz, void *ms, hipStream_t s)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(sample_shadow_kernel, dim3((n + 3) / 4), dim3(256), 0, s, X, D, Dp, ids, n, labels,
+                           B, centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms));
+}
+
+void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
+                      int B, int rows_hint, const MemberPack &P, hipStream_t s)
+{
+    if (B <= 0) return;
+    hipLaunchKernelGGL(pad_ptr_kernel, dim3(1), dim3(256), 0, s, bin_ptr, B, P.pad_ptr);
+    const long long rows = (long long)rows_hint + 32LL * B;
+    const int grid = (int)std::min<long long>((rows + 15) / 16, 16384);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, Zs,
+                       reinterpret_cast<const float4 *>(ms), Dz, memb_id, bin_ptr, P.pad_ptr, B, P);
+    hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, P, bin_ptr);
+}
+
+void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *memb_code,
+                          const int *bin_ptr, int B, int rows_hint, const double *centers, const double *mu_g,
+                          double S, int Dz, const MemberPack &P, hipStream_t s)
+{
+    if (B <= 0) return;
+    hipLaunchKernelGGL(pad_ptr_kernel, dim3(1), dim3(256), 0, s, bin_ptr, B, P.pad_ptr);
+    int gy = ((rows_hint + 31 * B) / std::max(B, 1) + 15) / 16;   // ~4 entries per wavefront per bin
+    gy = std::max(1, std::min(gy, 64));
+    hipLaunchKernelGGL(pack_centered_kernel, dim3(B, gy), dim3(256), 0, s, X, D, Dp, memb_id, memb_code, bin_ptr,
+                       P.pad_ptr, centers, mu_g, S, Dz, P);
+    hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, P, bin_ptr);
+}
+
+void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
+                        int Kcap, const double *centers, double S, void *qn, hipStream_t s)
+{
+    const int nq = pos_end - pos_begin;
+    if (nq <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(query_norms_kernel, dim3((nq + 63) / 64, (B + 63) / 64), dim3(256), 0, s, X, D, Dp, bq,
+                       pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn));
+}
+
+void launch_shortlist(const ShortlistArgs &a, int *flags64, hipStream_t s)
 {
     const int nq = a.pos_end - a.pos_begin;
     if (nq <= 0 || a.B <= 0) return;
-    const int nqt = (nq + kPfQ - 1) / kPfQ;
-    const int total = nqt * a.B;
-    const int grid = ((total + 7) / 8) * 8;
-    const int stride = a.shm.Dz * 2 + 16;
-    const size_t lds = prefilter_lds_bytes(a.shm.Dz);
-    const int nqt64 = (nq + kQTile - 1) / kQTile;
-    if (a.memb_code != nullptr) {
-        launch_pf<1, true>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
+    if (a.update) {
+        launch_sl<1, true>(a, flags64, s);
     } else if (a.m <= 5) {
-        launch_pf<5, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
+        launch_sl<5, false>(a, flags64, s);
     } else if (a.m <= 8) {
-        launch_pf<8, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
+        launch_sl<8, false>(a, flags64, s);
     } else {
-        launch_pf<16, false>(a, grid, lds, nqt, total, stride, flags64, nqt64, s);
+        launch_sl<16, false>(a, flags64, s);
     }
 }
 
