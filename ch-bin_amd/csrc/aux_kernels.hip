@@ -47,16 +47,35 @@ __global__ void count_base_kernel(const int *labels, const int *inb, int N, int 
         if (hist[b]) atomicAdd(&cnt[b], hist[b]);
 }
 
-__global__ void scan_kernel(const int *cnt, int B, int *bin_ptr, int *cursor)
+// bin_ptr / cursor = exclusive scan of cnt; pad_ptr (optional) = the same with every count rounded
+// up to a multiple of 32 (the padded layout of the shortlist stage).  One block of 256 threads.
+__global__ __launch_bounds__(256) void scan_kernel(const int *cnt, int B, int *bin_ptr, int *cursor, int *pad_ptr)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int run = 0;
-        for (int b = 0; b < B; ++b) {
-            bin_ptr[b] = run;
-            cursor[b] = run;
-            run += cnt[b];
+    __shared__ int part[256], ppart[256];
+    const int per = (B + 255) / 256;
+    const int b0 = min(B, (int)threadIdx.x * per), b1 = min(B, b0 + per);
+    int s = 0, sp = 0;
+    for (int b = b0; b < b1; ++b) { s += cnt[b]; sp += (cnt[b] + 31) / 32 * 32; }
+    part[threadIdx.x] = s; ppart[threadIdx.x] = sp;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0, prun = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int v = part[i], pv = ppart[i];
+            part[i] = run; ppart[i] = prun;
+            run += v; prun += pv;
         }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x], prun = ppart[threadIdx.x];
+    for (int b = b0; b < b1; ++b) {
+        bin_ptr[b] = run; cursor[b] = run;
+        if (pad_ptr) pad_ptr[b] = prun;
+        run += cnt[b]; prun += (cnt[b] + 31) / 32 * 32;
+    }
+    if (threadIdx.x == 255) {   // (its prefix + its own bins = everything)
         bin_ptr[B] = run;
+        if (pad_ptr) pad_ptr[B] = prun;
     }
 }
 
@@ -151,23 +170,34 @@ __global__ void first_change_kernel(const int *lab_new, const int *lab_prev, int
 // First-round label guess for batch members that carry no label yet (sweep 1): the bin of the
 // single nearest outside member.  Only a guess -- the rounds converge to the exact sequential
 // labels from any starting point; a good guess just saves a round.
-__global__ void guess_kernel(const double *list_d, const int *list_cnt, const int *lab_old, int p0,
-                             int K, int B, int m, int Kcap, int *lab_prev)
+// 16 lanes per position, each over every 16th bin; ties go to the lower bin as in a serial scan.
+__global__ __launch_bounds__(256) void guess_kernel(const double *list_d, const int *list_cnt, const int *lab_old,
+                                                    int p0, int K, int B, int m, int Kcap, int *lab_prev)
 {
-    const int pos = p0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= K) return;
-    int g = lab_old[pos];
-    if (g < 0) {
+    const int l16 = threadIdx.x & 15;
+    const int pos = p0 + blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool valid = pos < K;
+    int g = valid ? lab_old[pos] : 0;
+    if (__ballot(valid && g < 0) != 0ull) {
         double best = kInf;
-        for (int c = 0; c < B; ++c) {
-            const size_t slot = (size_t)c * Kcap + pos;
-            if (list_cnt[slot] > 0) {
-                const double d = list_d[slot * m];
-                if (d < best) { best = d; g = c; }
+        int bc = -1;
+        if (valid && g < 0)
+            for (int c = l16; c < B; c += 16) {
+                const size_t slot = (size_t)c * Kcap + pos;
+                if (list_cnt[slot] > 0) {
+                    const double d = list_d[slot * m];
+                    if (d < best) { best = d; bc = c; }
+                }
             }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const double od = __shfl_xor(best, off, 16);
+            const int oc = __shfl_xor(bc, off, 16);
+            if (oc >= 0 && (od < best || (od == best && (bc < 0 || oc < bc)))) { best = od; bc = oc; }
         }
+        if (g < 0) g = bc;
     }
-    lab_prev[pos] = g;
+    if (valid && l16 == 0) lab_prev[pos] = g;
 }
 
 // distance_matrix.py:47-62 on a caller-supplied distance row: m rounds of a block-wide
@@ -290,7 +320,7 @@ void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old,
                   int B, int m, int Kcap, int *lab_prev, hipStream_t s)
 {
     if (p1 > p0)
-        hipLaunchKernelGGL(guess_kernel, dim3((p1 - p0 + 127) / 128), dim3(128), 0, s, list_d, list_cnt, lab_old, p0, p1, B, m, Kcap, lab_prev);
+        hipLaunchKernelGGL(guess_kernel, dim3((p1 - p0 + 15) / 16), dim3(256), 0, s, list_d, list_cnt, lab_old, p0, p1, B, m, Kcap, lab_prev);
 }
 
 void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,
@@ -336,24 +366,24 @@ void launch_scatter_labels(int *labels, const int *bq, const int *lab, int K, hi
 }
 
 void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
-                        int *cursor, int *memb_id, hipStream_t s)
+                        int *cursor, int *memb_id, int *pad_ptr, hipStream_t s)
 {
     launch_fill_i32(cnt, 0, B, s);
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, cnt, B, bin_ptr, cursor);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr);
     hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * sizeof(int), s, labels, inb, N, B, cursor, memb_id);
 }
 
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
-                         int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code,
+                         int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
                          hipStream_t s)
 {
     launch_fill_i32(cnt, 0, B, s);
     if (K > 0)
         hipLaunchKernelGGL(count_batch_kernel, dim3((K + 255) / 256), dim3(256), 0, s, lab_prev, lab_old, K, B, cnt);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, cnt, B, bin_ptr, cursor);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr);
     if (K > 0)
         hipLaunchKernelGGL(fill_batch_kernel, dim3((K + 255) / 256), dim3(256), 0, s, lab_prev, lab_old, bq, K, B, cursor, memb_id, memb_code);
 }

@@ -319,7 +319,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
         // the bin keeps them tight.  Then every labelled sample's shadow row against its own bin.
         HIPCHK(h->centers.ensure((size_t)B * h->Dp));
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p,
-                           h->memb_id.p, h->stream);
+                           h->memb_id.p, nullptr, h->stream);
         launch_bin_centers(h->X.p, h->D, h->Dp, h->memb_id.p, h->bin_ptr.p, h->B, h->centers.p, h->stream);
         launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
                              h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, h->stream);
@@ -342,7 +342,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
     {
         Timed t(h, "bucket", (double)h->N);
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
-                           h->cursor.p, h->memb_id.p, s);
+                           h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, s);
     }
     TopmArgs a{};
     a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = q_lo; a.pos_end = q_hi;
@@ -409,7 +409,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         {
             Timed t(h, "bucket", (double)h->K);
             launch_bucket_batch(h->lab_prev.p, h->lab_old.p, h->bq.p, h->K, h->B, h->cnt2.p,
-                                h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, s);
+                                h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, h->pk2.pad_ptr.p, s);
         }
         TopmArgs a{};
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = lo; a.pos_end = hi;
@@ -891,7 +891,7 @@ int chb_topm_per_bin(chb_ctx *h, const int64_t *labels, int64_t B, int m, const 
         if (rc) return rc;
         // every other query of the chunk is an ordinary member: code "pos != i"
         launch_bucket_batch(h->lab_old.p, nullptr, h->bq.p, K, h->B, h->cnt2.p, h->bin_ptr2.p,
-                            h->cursor2.p, h->memb2_id.p, h->memb2_code.p, s);
+                            h->cursor2.p, h->memb2_id.p, h->memb2_code.p, nullptr, s);
         TopmArgs a{};
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = 0; a.pos_end = K;
         a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;

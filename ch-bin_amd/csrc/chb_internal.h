@@ -64,10 +64,10 @@ void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, cons
 void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, const int *labels,
                           int B, const double *centers, const double *mu_g, double S, unsigned short *Zs,
                           int Dz, void *ms, hipStream_t s);
-// base members (CSR) -> padded pack (+ pad_ptr, per-bin bounds)
+// base members (CSR; P.pad_ptr from launch_bucket_base) -> padded pack (+ per-bin bounds)
 void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
                       int B, int rows_hint, const MemberPack &P, hipStream_t s);
-// the batch's own entries (CSR + eligibility codes) -> padded pack (+ pad_ptr, per-bin bounds)
+// the batch's own entries (CSR + eligibility codes; P.pad_ptr from launch_bucket_batch) -> padded pack
 void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *memb_code,
                           const int *bin_ptr, int B, int rows_hint, const double *centers, const double *mu_g,
                           double S, int Dz, const MemberPack &P, hipStream_t s);
@@ -139,11 +139,12 @@ void launch_mark_batch(int *inb, const int *bq, int K, int set, hipStream_t s);
 void launch_gather_labels(const int *labels, const int *bq, int K, int *out, hipStream_t s);
 void launch_scatter_labels(int *labels, const int *bq, const int *lab, int K, hipStream_t s);
 // CSR of all labelled samples outside the batch
+// (pad_ptr, optional: the same CSR with every bin padded to a multiple of 32 rows -> MemberPack)
 void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
-                        int *cursor, int *memb_id, hipStream_t s);
+                        int *cursor, int *memb_id, int *pad_ptr, hipStream_t s);
 // CSR of the batch's own members: earlier positions under lab_prev, later positions under lab_old
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
-                         int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code,
+                         int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
                          hipStream_t s);
 // first position in [p0,K) whose label changed (atomicMin into *first_change)
 void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,

@@ -207,30 +207,6 @@ __global__ __launch_bounds__(256) void sample_shadow_kernel(const double *X, int
     if (lane == 0) ms[p] = o;
 }
 
-// pad_ptr[c] = first row of bin c when every bin is padded to a multiple of 32 rows; one block
-__global__ __launch_bounds__(256) void pad_ptr_kernel(const int *bin_ptr, int B, int *pad_ptr)
-{
-    __shared__ int part[256];
-    const int per = (B + 255) / 256;
-    const int b0 = threadIdx.x * per, b1 = min(B, b0 + per);
-    int s = 0;
-    for (int c = b0; c < b1; ++c) s += (bin_ptr[c + 1] - bin_ptr[c] + kPfP - 1) / kPfP * kPfP;
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
-    }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    for (int c = b0; c < b1; ++c) {
-        pad_ptr[c] = run;
-        run += (bin_ptr[c + 1] - bin_ptr[c] + kPfP - 1) / kPfP * kPfP;
-    }
-    if (b1 == B && b0 < B) pad_ptr[B] = run;
-    if (B == 0 && threadIdx.x == 0) pad_ptr[0] = 0;
-}
-
 // bin of padded row r (pad_ptr ascending, pad_ptr[B] > r)
 __device__ __forceinline__ int bin_of_row(const int *pad_ptr, int B, int r)
 {
@@ -331,42 +307,48 @@ __global__ __launch_bounds__(256) void bin_bounds_kernel(MemberPack P, const int
         P.bb[c] = make_float4(red[0][0], sqrtf(red[1][0]) * (1.0f + 1e-6f), red[2][0], 0.f);
 }
 
-// qn[c][pos] = ||(x_j - mu_c) S||^2 in fp64, rounded {up, down}.  A 64 positions x 64 bins tile per
+// qn[c][pos] = ||(x_j - mu_c) S||^2 in fp64, rounded {up, down}.  A 32 positions x 64 bins tile per
 // block, features staged through LDS 16 at a time (already scaled by S: exact, and keeps tiny
-// feature scales away from underflow); each thread owns a 4 x 4 micro-tile.
+// feature scales away from underflow); each thread owns a 2 x 4 micro-tile.
 __global__ __launch_bounds__(256) void query_norms_kernel(const double *X, int D, int Dp, const int *bq,
                                                           int pos_begin, int pos_end, int B, int Kcap,
                                                           const double *centers, double S, float2 *qn)
 {
     constexpr int KC = 16;
-    __shared__ double xs[64][KC + 1], cs[64][KC + 1];
+    __shared__ double xs[32][KC + 1], cs[64][KC + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int p0 = pos_begin + blockIdx.x * 64, c0 = blockIdx.y * 64;
-    // staging role: row tid / 4, four consecutive features
-    const int srow = tid >> 2, sk = (tid & 3) * 4;
-    const int spos = p0 + srow, sc = c0 + srow;
-    const double *xrow = spos < pos_end ? X + (size_t)bq[spos] * Dp : nullptr;
-    const double *crow = sc < B ? centers + (size_t)sc * Dp : nullptr;
-    double acc[4][4];
+    const int p0 = pos_begin + blockIdx.x * 32, c0 = blockIdx.y * 64;
+    // staging roles: centre row tid / 4 with four consecutive features, query row tid / 8 with two
+    const int crow_i = tid >> 2, ck = (tid & 3) * 4;
+    const int xrow_i = tid >> 3, xk = (tid & 7) * 2;
+    const double *xrow = p0 + xrow_i < pos_end ? X + (size_t)bq[p0 + xrow_i] * Dp : nullptr;
+    const double *crow = c0 + crow_i < B ? centers + (size_t)(c0 + crow_i) * Dp : nullptr;
+    double acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
     for (int k0 = 0; k0 < D; k0 += KC) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int k = k0 + sk + t;
-            xs[srow][sk + t] = (xrow && k < D) ? xrow[k] * S : 0.0;
-            cs[srow][sk + t] = (crow && k < D) ? crow[k] * S : 0.0;
+            const int k = k0 + ck + t;
+            cs[crow_i][ck + t] = (crow && k < D) ? crow[k] * S : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = k0 + xk + t;
+            xs[xrow_i][xk + t] = (xrow && k < D) ? xrow[k] * S : 0.0;
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-            double xv[4], cv[4];
+            double xv[2], cv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { xv[i] = xs[4 * ty + i][kk]; cv[i] = cs[tx + 16 * i][kk]; }
+            for (int i = 0; i < 2; ++i) xv[i] = xs[2 * ty + i][kk];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) cv[j] = cs[tx + 16 * j][kk];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const double z = xv[i] - cv[j];
@@ -376,10 +358,10 @@ __global__ __launch_bounds__(256) void query_norms_kernel(const double *X, int D
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int pos = p0 + 4 * ty + i, c = c0 + tx + 16 * j;
+            const int pos = p0 + 2 * ty + i, c = c0 + tx + 16 * j;
             if (pos < pos_end && c < B)
                 qn[(size_t)c * Kcap + pos] = make_float2(round_up_f32(acc[i][j] * (1.0 + 1e-12)),
                                                         (float)(acc[i][j] * (1.0 - 1e-6)));
@@ -837,7 +819,6 @@ void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const in
                       int B, int rows_hint, const MemberPack &P, hipStream_t s)
 {
     if (B <= 0) return;
-    hipLaunchKernelGGL(pad_ptr_kernel, dim3(1), dim3(256), 0, s, bin_ptr, B, P.pad_ptr);
     const long long rows = (long long)rows_hint + 32LL * B;
     const int grid = (int)std::min<long long>((rows + 15) / 16, 16384);
     hipLaunchKernelGGL(pack_rows_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, Zs,
@@ -850,7 +831,6 @@ void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, co
                           double S, int Dz, const MemberPack &P, hipStream_t s)
 {
     if (B <= 0) return;
-    hipLaunchKernelGGL(pad_ptr_kernel, dim3(1), dim3(256), 0, s, bin_ptr, B, P.pad_ptr);
     int gy = ((rows_hint + 31 * B) / std::max(B, 1) + 15) / 16;   // ~4 entries per wavefront per bin
     gy = std::max(1, std::min(gy, 64));
     hipLaunchKernelGGL(pack_centered_kernel, dim3(B, gy), dim3(256), 0, s, X, D, Dp, memb_id, memb_code, bin_ptr,
@@ -863,7 +843,7 @@ void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_b
 {
     const int nq = pos_end - pos_begin;
     if (nq <= 0 || B <= 0) return;
-    hipLaunchKernelGGL(query_norms_kernel, dim3((nq + 63) / 64, (B + 63) / 64), dim3(256), 0, s, X, D, Dp, bq,
+    hipLaunchKernelGGL(query_norms_kernel, dim3((nq + 31) / 32, (B + 63) / 64), dim3(256), 0, s, X, D, Dp, bq,
                        pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn));
 }
 
