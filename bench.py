@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (AMD public spec; the local guide lists no fp64 row)
-BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -149,17 +149,18 @@ def main():
                              "total_ms": p["ms"],
                              "note": "fp64 VALU (non-fused sub/mul/add, 1 flop per instruction); "
                                      "peak is the fp64 vector==matrix FMA peak, so 0.5 is the ceiling"})
-        # shortlist stage: bf16 MFMA dot products, 2*Dz flops per (query, member) pair
+        # shortlist stage: fp16 MFMA dot products, 2*Dz flops per (query, member) pair (one pass; the
+        # kernel streams a bin's members twice -- threshold sweep, then shortlist sweep)
         p = prof["prefilter"]
         if p["launches"]:
             Dz = 144 if D <= 144 else 160
             ach = p["work"] * 2.0 * Dz / (p["ms"] * 1e-3) / 1e12
-            kern.append({"kernel": "prefilter", "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS, "traffic": None,
+            kern.append({"kernel": "prefilter", "bound": "mfma", "achieved": ach, "peak": F16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / F16_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": p["ms"] / p["launches"], "launches": p["launches"],
                          "total_ms": p["ms"], "pairs_per_s": p["work"] / (p["ms"] * 1e-3),
-                         "note": "bf16 v_mfma_f32_32x32x16 shortlist; selection (VALU) and LDS "
-                                 "staging, not the matrix core, set its time"})
+                         "note": "fp16 v_mfma_f32_32x32x16 shortlist; LDS fragment reads and the "
+                                 "selection VALU work, not the matrix core, set its time"})
         for name in ("rescore", "prefilter_update", "rescore_update", "query_norms", "topm_fallback", "argmin",
                      "bucket"):
             p = prof[name]

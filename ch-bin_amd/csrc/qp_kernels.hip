@@ -240,15 +240,31 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 // M x M blocks of the 16x16 product are their Gram matrices, and the k-reduction over the feature
 // dimension happens inside the MFMA accumulator: no cross-lane reduction at all.  Each lane streams
 // ONE vertex row (every 4th feature), 8 loads in flight per operand.
+// Sum v[e] over the 16 lanes of a group and leave entry e = l16 on lane l16: a reduce-scatter in
+// four halving steps (15 exchanges instead of the 64 of sixteen butterfly reductions).
+__device__ __forceinline__ double reduce_scatter16(const double (&v)[16], int l16)
+{
+    double t8[8], t4[4], t2[2];
+    const bool b8 = l16 & 8, b4 = l16 & 4, b2 = l16 & 2, b1 = l16 & 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t8[e] = (b8 ? v[e + 8] : v[e]) + __shfl_xor(b8 ? v[e] : v[e + 8], 8, 64);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t4[e] = (b4 ? t8[e + 4] : t8[e]) + __shfl_xor(b4 ? t8[e] : t8[e + 4], 4, 64);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) t2[e] = (b2 ? t4[e + 2] : t4[e]) + __shfl_xor(b2 ? t4[e] : t4[e + 2], 2, 64);
+    return (b1 ? t2[1] : t2[0]) + __shfl_xor(b1 ? t2[0] : t2[1], 1, 64);
+}
+
 template <int M, int WAVES, bool INDEXED>
 __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(QpArgs a, int nprob, const int *xq,
                                                               const int *xhull, const int *xn,
                                                               int xm, double *xdist, double *xalpha)
 {
     constexpr int NP = Sym<M>::NP;
+    constexpr bool VGRAM = M <= 8;   // Gram by vector FMAs (16 lanes per problem) instead of the matrix core
     constexpr int PPT = 16 / M;    // problems per MFMA tile
     constexpr int NT = 64 / PPT;   // tiles per wavefront
-    constexpr int PPW = PPT * NT;  // problems per wavefront (one per lane in phase 2)
+    constexpr int PPW = VGRAM ? 64 : PPT * NT;  // problems per wavefront (one per lane in phase 2)
     __shared__ double sQ[WAVES][NP][64];
     __shared__ int sN[WAVES][64];
 
@@ -259,6 +275,75 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
     const int row = lane & 15, kq = lane >> 4;
     const int rp = row / M, rv = row - rp * M;
 
+    if constexpr (VGRAM) {
+        // 16 lanes per problem, lane l16 over the features k = l16 (mod 16): every row is read in
+        // full 128-byte lines, each lane accumulates all M (M + 1) / 2 products of its features, and
+        // a reduce-scatter leaves one finished Gram entry per lane.  For M <= 8 this beats the
+        // 16 x 16 matrix-core tile, most of which (the blocks between different problems) is waste.
+        const int grp = lane >> 4, l16 = lane & 15;
+        for (int pass = 0; pass < 16; ++pass) {
+            const int pl = pass * 4 + grp;
+            const int g = g0 + pl;
+            const bool valid = g < nprob;
+            int n = 0, idm = -1, qid = 0;
+            size_t slot = 0;
+            if (valid) {
+                if (INDEXED) {
+                    qid = xq[g];
+                    n = xn[g];
+                    if (l16 < n) idm = xhull[(size_t)g * m + l16];
+                } else {
+                    const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+                    qid = a.bq[pos];
+                    slot = (size_t)c * a.Kcap + pos;
+                    n = a.lists.cnt[slot];
+                    if (l16 < n) idm = a.lists.idx[slot * m + l16];
+                }
+            }
+            bool changed = valid;
+            if (!INDEXED && a.prev.idx != nullptr && valid)
+                changed = a.prev.cnt[slot] != n || (l16 < n && a.prev.idx[slot * m + l16] != idm);
+            const bool doit = ((__ballot(changed) >> (16 * grp)) & 0xFFFFull) != 0ull;
+            const double *vrow[M];
+#pragma unroll
+            for (int v = 0; v < M; ++v) {
+                const int idv = __shfl(idm, 16 * grp + v, 64);
+                // a missing vertex reads the query row: y = 0, its Gram row/column stays 0 (never used)
+                vrow[v] = a.X + (size_t)(idv >= 0 ? idv : qid) * a.Dp;
+            }
+            if (!valid) continue;
+            if (!doit) {   // unchanged vertex list: keep the stored distance
+                if (l16 == 0) sN[w][pl] = -1;
+                continue;
+            }
+            const double *xrow = a.X + (size_t)qid * a.Dp;
+            double acc[NP];
+#pragma unroll
+            for (int e = 0; e < NP; ++e) acc[e] = 0.0;
+            if (n > 0) {
+#pragma unroll 3
+                for (int k = l16; k < a.Dp; k += 16) {
+                    const double xk = xrow[k];
+                    double y[M];
+#pragma unroll
+                    for (int v = 0; v < M; ++v) y[v] = vrow[v][k] - xk;
+#pragma unroll
+                    for (int i = 0; i < M; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) acc[Sym<M>::at(i, j)] = fma(y[i], y[j], acc[Sym<M>::at(i, j)]);
+                }
+            }
+#pragma unroll
+            for (int e0 = 0; e0 < NP; e0 += 16) {
+                double v16[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v16[e] = e0 + e < NP ? acc[e0 + e] : 0.0;
+                const double r = reduce_scatter16(v16, l16);
+                if (e0 + l16 < NP) sQ[w][e0 + l16][pl] = r;
+            }
+            if (l16 == 0) sN[w][pl] = n;
+        }
+    } else
     for (int t = 0; t < NT; ++t) {
         const int gt = g0 + t * PPT;
         if (gt >= nprob) break;
@@ -364,7 +449,7 @@ template <int M, int WV, bool INDEXED>
 void launch_one(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull, const int *xn,
                 double *xdist, double *xalpha, hipStream_t s)
 {
-    constexpr int PPW = (16 / M) * (64 / (16 / M));
+    constexpr int PPW = M <= 8 ? 64 : (16 / M) * (64 / (16 / M));
     const int nwaves = (nprob + PPW - 1) / PPW;
     const int grid = (nwaves + WV - 1) / WV;
     hipLaunchKernelGGL((hull_qp_kernel<M, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a, nprob,
