@@ -22,6 +22,10 @@
 
 #include <math.h>
 
+#ifndef CHB_QP_UNROLL
+#define CHB_QP_UNROLL 2
+#endif
+
 namespace chb {
 namespace {
 
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
 #pragma unroll
             for (int e = 0; e < NP; ++e) acc[e] = 0.0;
             if (n > 0) {
-#pragma unroll 3
+#pragma unroll CHB_QP_UNROLL
                 for (int k = l16; k < a.Dp; k += 16) {
                     const double xk = xrow[k];
                     double y[M];
