@@ -161,8 +161,21 @@ def main():
                          "total_ms": p["ms"], "pairs_per_s": p["work"] / (p["ms"] * 1e-3),
                          "note": "fp16 v_mfma_f32_32x32x16 shortlist; LDS fragment reads and the "
                                  "selection VALU work, not the matrix core, set its time"})
-        for name in ("rescore", "prefilter_update", "rescore_update", "query_norms", "topm_fallback", "argmin",
-                     "bucket"):
+        # exact rescoring of the shortlists: at least the m winners' rows have to be read to know their
+        # exact distances, so the algorithmic bytes per (position, bin) pair are m * D * 8 (the
+        # shortlist itself is ~5.2 rows at m = 5); same no-reuse gather model as the hull QP
+        p = prof["rescore"]
+        if p["launches"]:
+            bytes_pair = 8.0 * m * D
+            ach = p["work"] * bytes_pair / (p["ms"] * 1e-3) / 1e9
+            kern.append({"kernel": "rescore", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": p["ms"] / p["launches"], "launches": p["launches"],
+                         "total_ms": p["ms"], "pairs_per_s": p["work"] / (p["ms"] * 1e-3),
+                         "bytes_per_pair": bytes_pair,
+                         "note": "gather of the shortlisted rows (fp64, 8*D bytes each), unfused sequential "
+                                 "sums; no-reuse model, rows come largely out of L2 / Infinity Cache"})
+        for name in ("prefilter_update", "rescore_update", "query_norms", "topm_fallback", "argmin", "bucket"):
             p = prof[name]
             if p["launches"]:
                 kern.append({"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,
@@ -177,21 +190,24 @@ def main():
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": p["ms"] / p["launches"], "launches": p["launches"],
                          "total_ms": p["ms"], "qp_per_s_kernel": p["work"] / (p["ms"] * 1e-3),
-                         "bytes_per_qp": bytes_qp})
+                         "bytes_per_qp": bytes_qp,
+                         "note": "achieved = SURVEY 8(d)'s no-reuse gather model (bytes_QP per hull distance); "
+                                 "vertex rows are re-used out of L2 / Infinity Cache, so it can exceed the HBM "
+                                 "peak -- `traffic` is what actually crossed the fabric per launch"})
         # HBM-side traffic per launch from the committed PMC profile (separate rocprofv3 --pmc passes,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null when unavailable
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01d_traffic.json")))["kernels"]
-            tmap = {"prefilter": "prefilter_kernel<5, false, true>", "hull_qp": "hull_qp_kernel",
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01e_traffic.json")))["kernels"]
+            tmap = {"prefilter": "shortlist_kernel<5, false, 9>", "hull_qp": "hull_qp_kernel<5, 4, false>",
                     "rescore": "rescore_kernel<8, 2>", "rescore_update": "rescore_kernel<8, 2>",
-                    "prefilter_update": "prefilter_kernel<1, true, true>",
-                    "query_norms": "query_shadow_kernel"}
+                    "prefilter_update": "shortlist_kernel<1, true, 9>",
+                    "query_norms": "query_norms_kernel"}
             if (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist:
                 for k in kern:
                     src = tmap.get(k["kernel"])
                     if src in tr:
                         k["traffic"] = tr[src]["traffic_bytes_per_launch"]
-                        k["traffic_source"] = "profiles/r01d_traffic.json (" + src + ")"
+                        k["traffic_source"] = "profiles/r01e_traffic.json (" + src + ")"
         except Exception:  # noqa: BLE001
             pass
         kern.sort(key=lambda k: -k["total_ms"])

@@ -46,6 +46,7 @@ struct MemberPack {
     unsigned short *Z;        // [rows][Dz] fp16 bits of (x_p - mu_c) S; zero rows in the padding
     float *bias;              // [rows] ||zh||^2 + 2 <(mu_c - mu_g) S, zh>; +inf in the padding
     float *rho, *nrm, *amax;  // [rows] rounding distance, ||zh||^2, ||zh||^2 + 2 |<..>|
+    float *sn;                // [rows] ||zh|| (rounded up)
     float *cs, *cb;           // [rows] update mode: entry eligible for position q <=> cs q + cb >= 0
     int *pad_ptr;             // [B+1] first row of each bin (multiples of 32)
     float4 *bb;               // [B] {largest rho, largest ||zh||, largest amax, -}
@@ -92,6 +93,8 @@ struct ShortlistArgs {
     int *cand;       // [B][Kcap][kCandCap] sample indices
     int *cand_cnt;   // [B][Kcap]
     int *overflow;   // [1] number of (bin, position) pairs whose shortlist overflowed
+    float gamma;         // accumulation error factor g (set by launch_shortlist)
+    int tile_best_min;   // bins with at least this many tiles learn tau from per-tile bests (ditto)
 };
 // flags64[bin][ceil(nq/64)] (pre-zeroed): set for (query tile of 64, bin) pairs whose shortlist overflowed
 void launch_shortlist(const ShortlistArgs &a, int *flags64, hipStream_t s);

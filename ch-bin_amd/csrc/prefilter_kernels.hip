@@ -21,13 +21,18 @@
 // Guarantee.  With z_j = (x_j - mu_c) S exact,
 //     T(j,p) := ||z_j - zh_p||^2 = N_jc + bias_p - 2 <qh_j, zh_p> - 2 <(x_j - mu_g) S - qh_j, zh_p>
 // and the matrix core returns acc = -bias_p / 2 + <qh_j, zh_p> (v_mfma_f32_32x32x16_f16: fp16
-// products are exact in fp32), so that | T - (N_jc - 2 acc) | <= E(j,c) with
-//     E = 2^-24 Bmax_c + g (Bmax_c + 2 ||qh_j|| snb_c) + 2 rho_j snb_c
-// (rounding of bias to fp32; accumulation error, g = 1e-4 is several times the worst-case fp32
-// summation bound for D <= 512; Cauchy-Schwarz on the query's rounding error, damped by the small
-// norm snb_c = max ||zh_p|| of the bin-centred members; Bmax_c = max (||zh_p||^2 + 2 |<..>|)).
+// products are exact in fp32), so that | T - (N_jc - 2 acc) | <= E(j,c) + 2 rho_j ||zh_p|| with
+//     E = 2^-24 Bmax_c + g (Bmax_c + 2 ||qh_j|| snb_c)
+// (rounding of bias to fp32; accumulation error: g = 2.5e-5 exceeds the worst case (n - 1) u of summing
+// the n <= 161 fp32 terms in ANY order with one-ulp truncating adds, u = 2^-23 -- round-to-nearest
+// halves it, and the observed error is two orders of magnitude smaller; the terms are the start
+// value and the Dz <= 160 exact products; snb_c = max ||zh_p||, Bmax_c = max (||zh_p||^2 + 2 |<..>|)
+// over the bin).  The last term is Cauchy-Schwarz on the query's rounding error, damped by the small
+// norm of the bin-centred member -- per member: it is folded into the accumulator's start value,
+// -bias_p / 2 -+ rho_j ||zh_p||, minus for the upper bounds of sweep 0, plus for the lower bounds of
+// sweep 1, so the tile loop does not see it.
 // By the triangle inequality | S d(j,p) - sqrt(T) | <= rho_p <= rho_bin, hence for every member
-//     LB(j,p) <= S d(j,p) <= UB(j,p),   UB/LB = sqrt(N_jc - 2 acc +- E) +- rho_bin .
+//     LB(j,p) <= S d(j,p) <= UB(j,p),   UB/LB = sqrt(N_jc - 2 acc' +- E) +- rho_bin .
 // Sweep 0 over a bin learns tau = (an upper bound of) the m-th smallest UB -- at least m members
 // are provably within tau -- and sweep 1 shortlists every member with LB <= tau.  Any member of
 // the true top-m has d <= tau, hence LB <= tau: it is on the list.  A relative slack of 1e-6
@@ -49,7 +54,7 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr float kGamma = 1e-4f;
+constexpr float kGamma = 2.5e-5f;
 constexpr float kSlack = 1e-6f;
 constexpr int kPfQ = 128;  // batch positions per workgroup (32 per wavefront)
 constexpr int kPfP = 32;   // members per tile
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs
         if (l16 == 0) {
             const float4 o = real ? ms[id] : make_float4(INFINITY, 0.f, 0.f, 0.f);
             P.bias[r] = o.x; P.rho[r] = o.y; P.nrm[r] = o.z; P.amax[r] = o.w;
+            P.sn[r] = sqrtf(o.z) * (1.0f + 1e-6f);
         }
     }
 }
@@ -264,6 +270,7 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
                                                S, D, Dz, lane, P.Z + (size_t)r * Dz);
             if (lane == 0) {
                 P.bias[r] = o.x; P.rho[r] = o.y; P.nrm[r] = o.z; P.amax[r] = o.w;
+                P.sn[r] = sqrtf(o.z) * (1.0f + 1e-6f);
                 const int code = memb_code[b0 + e];
                 float sv = 0.f, bv = 0.f;
                 if (code > 0) { sv = 1.f; bv = -(float)code; }               // q > code - 1
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
         } else {
             for (int k = lane; k < Dz; k += 64) P.Z[(size_t)r * Dz + k] = 0;
             if (lane == 0) {
-                P.bias[r] = INFINITY; P.rho[r] = 0.f; P.nrm[r] = 0.f; P.amax[r] = 0.f;
+                P.bias[r] = INFINITY; P.rho[r] = 0.f; P.nrm[r] = 0.f; P.amax[r] = 0.f; P.sn[r] = 0.f;
                 P.cs[r] = 0.f; P.cb[r] = 0.f;
             }
         }
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(Shortli
     constexpr int CPR = 2 * KS;              // 16-byte chunks per shadow row
     constexpr int ROWB = 32 * KS;            // bytes per shadow row
     constexpr int TILEB = kPfP * ROWB;       // one member tile
-    constexpr int METAB = 512;               // floats [0,32) bias | [32,64) s | [64,96) b
+    constexpr int METAB = 512;               // floats [0,32) bias | [32,64) ||zh|| (base) or s | [64,96) b | [96,128) ||zh|| (update)
     constexpr int BUFB = TILEB + METAB;
     constexpr int NBUF = 3;
     constexpr int kPoolW = shortlist_pool_entries(ML);
@@ -535,11 +542,11 @@ __global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(Shortli
                 __builtin_amdgcn_global_load_lds(src_ + src_off[j],                                \
                     (__attribute__((address_space(3))) void *)(dst_ + (w + 4 * j) * 1024), 16, 0, 0); \
         if (w == 3) {                                                                              \
-            const float *p_ = ((UPD && h) ? a.P.cs : a.P.bias) + row_ + col;                       \
+            const float *p_ = (h ? (UPD ? a.P.cs : a.P.sn) : a.P.bias) + row_ + col;               \
             __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB), 4, 0, 0); \
         }                                                                                          \
         if (UPD && w == 2) {                                                                       \
-            const float *p_ = a.P.cb + row_ + col;                                                 \
+            const float *p_ = (h ? a.P.sn : a.P.cb) + row_ + col;                                  \
             __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB + 256), 4, 0, 0); \
         }                                                                                          \
         ++n_issued;                                                                                \
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(Shortli
         // ---- per-(query, bin) bounds
         const float4 bb = a.P.bb[c];                      // {rho_bin, snb, Bmax, -}
         const float2 qn2 = a.qn[slot];                    // N_jc {up, down}
-        const float E = (6e-8f * bb.z + kGamma * (bb.z + 2.0f * snq * bb.y) + 2.0f * rg * bb.y) *
+        const float E = (1.2e-7f * bb.z + a.gamma * (bb.z + 2.0f * snq * bb.y)) *
                         (1.0f + 4.0f * kSlack);
         const float nj_hi = (qn2.x + E) * (1.0f + kSlack);
         const float nj_lo = (qn2.y - E) * (qn2.y > E ? (1.0f - kSlack) : (1.0f + kSlack));
@@ -595,10 +602,11 @@ __global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(Shortli
             thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
         }
         if (h == 0) sCnt[32 * w + col] = 0;
-        const bool tile_best = ntile >= 16;
+        const bool tile_best = ntile >= a.tile_best_min;
         int wcnt = 0;   // entries parked by this wavefront for this bin (wave-uniform)
 
         for (int sweep = UPD ? 1 : 0; sweep < 2; ++sweep) {
+            const float rgs = (sweep ? rg : -rg) * (1.0f + kSlack);
             if (!UPD && sweep == 1) {
                 // end of sweep 0: m-th smallest t over BOTH lane halves -> tau -> thr2
                 float mg[ML];
@@ -626,16 +634,21 @@ __global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(Shortli
                 const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
                 // rows held by this lane: (r & 3) + 8 (r >> 2) + 4 h
                 const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
-                f32x4 nv[4], sv[4], bv[4];
+                f32x4 nv[4], nn[4], sv[4], bv[4];
 #define CHB_SL_META(G)                                                                             \
                 nv[G] = lds_read_f4<32 * (G)>(ma);                                                 \
+                nn[G] = lds_read_f4<(UPD ? 384 : 128) + 32 * (G)>(ma);                             \
                 if (UPD) { sv[G] = lds_read_f4<128 + 32 * (G)>(ma); bv[G] = lds_read_f4<256 + 32 * (G)>(ma); }
                 CHB_SL_META(0) CHB_SL_META(1) CHB_SL_META(2) CHB_SL_META(3)
 #undef CHB_SL_META
                 // (asm reads are complete once the tied s_waitcnt below returns: no use can be scheduled
                 //  ahead of it.  Two phases -- bias column, then fragments -- keep the peak register
                 //  count at four wavefronts per SIMD.)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]) : : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "+v"(nn[0]), "+v"(nn[1]), "+v"(nn[2]),
+                               "+v"(nn[3])
+                             :
+                             : "memory");
                 if (UPD)
                     asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(bv[0]), "+v"(bv[1]),
                                       "+v"(bv[2]), "+v"(bv[3]) : : "memory");
@@ -644,7 +657,9 @@ __global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(Shortli
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        acc[4 * g + k] = -0.5f * nv[g][k];
+                        // -bias / 2, pushed down (sweep 0: upper bounds) or up (sweep 1: lower bounds) by
+                        // the query's rounding error against THIS member's norm
+                        acc[4 * g + k] = fmaf(rgs, nn[g][k], -0.5f * nv[g][k]);
                         // a batch member counts for this query only on the right side of the visiting order
                         if (UPD && fmaf(sv[g][k], qposf, bv[g][k]) < 0.f) acc[4 * g + k] = -INFINITY;
                     }
@@ -847,8 +862,15 @@ void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_b
                        pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn));
 }
 
-void launch_shortlist(const ShortlistArgs &a, int *flags64, hipStream_t s)
+void launch_shortlist(const ShortlistArgs &a_, int *flags64, hipStream_t s)
 {
+    ShortlistArgs a = a_;
+    {
+        static float g = -1.f; static int tb = -1;
+        if (g < 0.f) { const char *e = getenv("CHB_SL_GAMMA"); g = e ? (float)atof(e) : kGamma; }
+        if (tb < 0) { const char *e = getenv("CHB_SL_TILEBEST"); tb = e ? atoi(e) : 16; }
+        a.gamma = g; a.tile_best_min = tb;
+    }
     const int nq = a.pos_end - a.pos_begin;
     if (nq <= 0 || a.B <= 0) return;
     if (a.update) {

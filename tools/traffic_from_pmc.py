@@ -1,0 +1,42 @@
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into the per-kernel traffic table bench.py reads.
+
+usage: python tools/traffic_from_pmc.py <dir with the pmc passes> <out prefix, e.g. profiles/r01e>
+Writes <prefix>_pmc_hbm_counters.csv and <prefix>_traffic.json.
+traffic_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches: FETCH_SIZE is doubled as
+MI355X_MICROARCH.md prescribes for gfx950 (it reports half the bytes of wide coalesced reads).
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].replace("chb::(anonymous namespace)::", "").replace("void ", "")
+        k = re.sub(r"\(.*$", "", k)
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        calls[k][r["Counter_Name"]] += 1
+with open(prefix + "_pmc_hbm_counters.csv", "w", newline="") as fo:
+    w = csv.writer(fo)
+    w.writerow(["kernel", "Counter_Name", "total", "launches"])
+    for k in sorted(tot):
+        for c in sorted(tot[k]):
+            w.writerow([k, c, tot[k][c], calls[k][c]])
+kern = {}
+for k in sorted(tot):
+    if "FETCH_SIZE" not in tot[k] or "WRITE_SIZE" not in tot[k]:
+        continue
+    n = calls[k]["FETCH_SIZE"]
+    kern[k] = {"launches": n, "fetch_kb": tot[k]["FETCH_SIZE"], "write_kb": tot[k]["WRITE_SIZE"],
+               "traffic_bytes_per_launch": (2.0 * tot[k]["FETCH_SIZE"] + tot[k]["WRITE_SIZE"]) * 1024.0 / n}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on "
+                     "bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-e2e; FETCH_SIZE doubled per "
+                     "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); fabric-side "
+                     "counters, Infinity-Cache hits included",
+           "kernels": kern}, open(prefix + "_traffic.json", "w"), indent=1)
+print("kernels:", ", ".join(kern))
