@@ -63,6 +63,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "chb_fit_stats": (C.c_int, [C.c_void_p, _i64p]),
     "chb_counter": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    "chb_kmer_dim": (C.c_int, [C.c_int]),
+    "chb_kmer_frequencies": (C.c_int, [C.c_void_p, C.c_char_p, _i64p, C.c_int64, C.c_int, _f64p, C.c_void_p]),
 }
 
 
@@ -262,6 +264,21 @@ class Context:
         v = C.c_int64(0)
         check(self._lib.chb_counter(self._h, name.encode(), C.byref(v)))
         return int(v.value)
+
+    def kmer_frequencies(self, sequences, k=4, return_counts=False):
+        """chb_kmer_frequencies: sequences = list of bytes / str, one per contig."""
+        bs = [s.encode() if isinstance(s, str) else bytes(s) for s in sequences]
+        dim = self._lib.chb_kmer_dim(int(k))
+        if dim <= 0:
+            raise ChbError(self._lib.chb_last_error().decode())
+        offsets = np.zeros(len(bs) + 1, dtype=np.int64)
+        if bs:
+            offsets[1:] = np.cumsum([len(b) for b in bs])
+        freq = np.zeros((len(bs), dim), dtype=np.float64)
+        counts = np.zeros((len(bs), dim), dtype=np.uint32) if return_counts else None
+        check(self._lib.chb_kmer_frequencies(self._h, b"".join(bs), offsets, len(bs), int(k), freq.reshape(-1),
+                                              counts.ctypes.data_as(C.c_void_p) if counts is not None else None))
+        return (freq, counts) if return_counts else freq
 
     def fit_stats(self):
         out = np.zeros(4, dtype=np.int64)

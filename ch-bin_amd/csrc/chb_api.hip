@@ -120,6 +120,10 @@ struct DevBuf {
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
 };
 
 }  // namespace
@@ -1085,6 +1089,70 @@ int chb_comm_destroy(chb_ctx *h)
         (void)rccl()->CommDestroy(h->comm);
     }
     h->comm = nullptr; h->rank = 0; h->world = 1;
+    return CHB_OK;
+}
+
+int chb_kmer_dim(int k)
+{
+    const int n = kmer_canonical_table(k, nullptr);
+    return n > 0 ? n : fail(CHB_EUNSUPPORTED, "k must be in [1, 7]");
+}
+
+int chb_kmer_frequencies(chb_ctx *h, const unsigned char *seq, const int64_t *offsets, int64_t n, int k,
+                         double *freq_out, uint32_t *counts_out)
+{
+    if (!h || !offsets || !freq_out) return fail(CHB_EINVAL, "null argument");
+    if (n < 0 || n >= (1LL << 31)) return fail(CHB_EINVAL, "bad contig count");
+    std::vector<unsigned short> table;
+    const int dim = kmer_canonical_table(k, &table);
+    if (dim <= 0) return fail(CHB_EUNSUPPORTED, "k must be in [1, 7]");
+    if (n == 0) return CHB_OK;
+    if (offsets[0] != 0) return fail(CHB_EINVAL, "offsets[0] must be 0");
+    const int64_t total = offsets[n];
+    if (total > 0 && !seq) return fail(CHB_EINVAL, "seq is null");
+    HIPCHK(hipSetDevice(h->dev));
+    // one work item per kmer_chunk_windows() windows of a contig
+    const int cw = kmer_chunk_windows();
+    std::vector<int> chunk_ptr((size_t)n + 1);
+    std::vector<long long> off64((size_t)n + 1);
+    int64_t items = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(CHB_EINVAL, "offsets must be non-decreasing");
+        chunk_ptr[(size_t)i] = (int)items;
+        const int64_t nwin = offsets[i + 1] - offsets[i] - k + 1;
+        if (nwin > 0) items += (nwin + cw - 1) / cw;
+        if (items >= (1LL << 31) - 1) return fail(CHB_EUNSUPPORTED, "too many bases for one call");
+        off64[(size_t)i] = offsets[i];
+    }
+    chunk_ptr[(size_t)n] = (int)items;
+    off64[(size_t)n] = total;
+    DevBuf<unsigned char> dseq;
+    DevBuf<long long> doff;
+    DevBuf<int> dptr;
+    DevBuf<unsigned short> dtab;
+    DevBuf<unsigned int> dcnt;
+    DevBuf<double> dfreq;
+    hipStream_t s = h->stream;
+    HIPCHK(dseq.ensure((size_t)std::max<int64_t>(total, 1) + 16));
+    HIPCHK(doff.ensure((size_t)n + 1));
+    HIPCHK(dptr.ensure((size_t)n + 1));
+    HIPCHK(dtab.ensure(table.size()));
+    HIPCHK(dcnt.ensure((size_t)n * dim));
+    HIPCHK(dfreq.ensure((size_t)n * dim));
+    if (total > 0) HIPCHK(hipMemcpyAsync(dseq.p, seq, (size_t)total, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(doff.p, off64.data(), sizeof(long long) * (n + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dptr.p, chunk_ptr.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dtab.p, table.data(), sizeof(unsigned short) * table.size(), hipMemcpyHostToDevice, s));
+    {
+        Timed t(h, "kmer_count", (double)total);
+        launch_kmer_count(dseq.p, doff.p, dptr.p, (int)n, (int)items, k, dim, dtab.p, dcnt.p, dfreq.p, s);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(freq_out, dfreq.p, sizeof(double) * (size_t)n * dim, hipMemcpyDeviceToHost, s));
+    if (counts_out)
+        HIPCHK(hipMemcpyAsync(counts_out, dcnt.p, sizeof(uint32_t) * (size_t)n * dim, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    dseq.release(); doff.release(); dptr.release(); dtab.release(); dcnt.release(); dfreq.release();
     return CHB_OK;
 }
 

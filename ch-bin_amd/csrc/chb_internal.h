@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace chb {
 
 constexpr int kMaxM = 16;       // CHB_MAX_NEIGHBORS
@@ -166,5 +168,16 @@ void launch_select_row(const int *labels, const double *row, int N, int c, int m
 void launch_argmin(const double *dist, const int *lab_old, const int *lab_prev, int pos_begin,
                    int pos_end, int B, int *lab_new, double *mind, int *first_change,
                    hipStream_t s);
+
+
+// ---- canonical k-mer frequency vectors (kmer_kernels.hip)
+// number of canonical k-mers (136 for k = 4); table[code] = column of the 2-bit k-mer code; -1: k unsupported
+int kmer_canonical_table(int k, std::vector<unsigned short> *table);
+int kmer_chunk_windows();
+// counts[n][ncanon] (zeroed here) and freq[n][ncanon] = counts / row sum; chunk_ptr[i] = first work
+// item of contig i (one item per kmer_chunk_windows() windows), n_items = their total
+void launch_kmer_count(const unsigned char *seq, const long long *offsets, const int *chunk_ptr, int n_contigs,
+                       int n_items, int k, int ncanon, const unsigned short *canon, unsigned int *counts,
+                       double *freq, hipStream_t s);
 
 }  // namespace chb

@@ -132,6 +132,22 @@ int chb_comm_unique_id(char *out128);
 int chb_comm_init(chb_ctx *h, const char *id128, int rank, int world);
 int chb_comm_destroy(chb_ctx *h);
 
+/* ---- feature assembly: canonical k-mer frequency vectors.
+ * Replaces the external seq2vec run of ch_bin/core/features/kmer_count.py:65-107 (and the
+ * normalisation of the deprecated kmer-counter path, kmer_count.py:57-59): row i = counts of the
+ * canonical k-mers (a k-mer and its reverse complement are one column) of contig i divided by
+ * their sum; k = 4 gives the 136 k-mer columns of features.csv (config/default.ini:10).
+ * Columns are ordered by the smaller 2-bit code (A<C<G<T) of the k-mer and its reverse complement;
+ * windows containing anything but A/C/G/T (either case) are skipped; a contig without a valid
+ * window yields a zero row.  seq2vec itself is not part of the reference tree: these two
+ * conventions are unpinned (they permute / do not change distances between rows). */
+/* number of columns for k (1 <= k <= 7), or a negative error code */
+int chb_kmer_dim(int k);
+/* seq: the contigs' bases back to back (host), offsets[n+1] their bounds; freq_out[n * dim] doubles;
+ * counts_out (optional) [n * dim] raw counts.  Needs a context only for its device and stream. */
+int chb_kmer_frequencies(chb_ctx *h, const unsigned char *seq, const int64_t *offsets, int64_t n, int k,
+                         double *freq_out, uint32_t *counts_out);
+
 /* ---- measurement: HIP-event timing of every kernel launch on the context's stream */
 int chb_profile_enable(chb_ctx *h, int on);
 int chb_profile_reset(chb_ctx *h);
@@ -142,7 +158,7 @@ int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *l
 /* counters of the last chb_fit_cluster call: [0]=batches [1]=rounds [2]=hull distances evaluated
  * (incl. speculative re-evaluation) [3]=hull distances the sequential loop needs (sweeps*n_move*B) */
 int chb_fit_stats(chb_ctx *h, int64_t *out4);
-/* diagnostic counters: "prefilter_enabled" (1 when the bf16 shortlist stage is active; the
+/* diagnostic counters: "prefilter_enabled" (1 when the fp16 shortlist stage is active; the
  * environment variable CHB_PREFILTER=0 selects the brute-force selection kernel instead),
  * "prefilter_overflow" (shortlists that overflowed and were recomputed by brute force since the
  * last chb_fit_begin) */

@@ -64,6 +64,10 @@ def lib():
         L.chbo_fit_cluster.argtypes = [_f64p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i64p,
                                        C.c_int64, C.c_int, C.c_int, C.c_void_p, _i64p, _i64p]
         L.chbo_fit_cluster.restype = C.c_int
+        L.chbo_kmer_dim.argtypes = [C.c_int, C.c_void_p]
+        L.chbo_kmer_dim.restype = C.c_int64
+        L.chbo_kmer_frequencies.argtypes = [C.c_char_p, _i64p, C.c_int64, C.c_int, _f64p, _i64p]
+        L.chbo_kmer_frequencies.restype = C.c_int
         _lib = L
     return _lib
 
@@ -181,3 +185,23 @@ def fit_cluster(X, B, initial_bins, perms, m, max_iter, dm=None, metric="convex"
                                         int(max_iter), None if dmp is None else dmp.ctypes.data, out,
                                         changed, METRICS[metric])
     return out, its, changed[:its]
+
+
+def kmer_dim(k):
+    """Number of canonical k-mers (kmer_count.py:65-107 output width; 136 for k = 4)."""
+    return int(lib().chbo_kmer_dim(int(k), None))
+
+
+def kmer_frequencies(seqs, k):
+    """seqs: list of bytes/str (one per contig) -> (freq [n, dim] f64, counts [n, dim] i64)."""
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offsets = np.zeros(len(bs) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(b) for b in bs])
+    dim = kmer_dim(k)
+    freq = np.zeros((len(bs), dim), dtype=np.float64)
+    counts = np.zeros((len(bs), dim), dtype=np.int64)
+    rc = lib().chbo_kmer_frequencies(b"".join(bs), offsets, len(bs), int(k), freq.reshape(-1) if len(bs) else freq,
+                                     counts.reshape(-1) if len(bs) else counts)
+    if rc != 0:
+        raise ValueError("unsupported k")
+    return freq, counts

@@ -1,0 +1,106 @@
+"""Feature assembly, CPU part: the oracle's k-mer restatement against a
+plain-Python count, the coverage normaliser against fixtures produced by the reference's own
+parse_coverages, the contig filter / split rule against its documented behaviour."""
+import itertools
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import chbin_amd  # noqa: E402,F401
+from chbin_amd.features import coverage, fasta, kmer_count, preprocess  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def _py_counts(seq, k):
+    labels = kmer_count.canonical_kmers(k)
+    col = {s: i for i, s in enumerate(labels)}
+    out = np.zeros(len(labels), dtype=np.int64)
+    s = seq.upper()
+    for p in range(len(s) - k + 1):
+        w = s[p:p + k]
+        if any(ch not in "ACGT" for ch in w):
+            continue
+        rc = "".join(COMP[ch] for ch in reversed(w))
+        out[col[min(w, rc)]] += 1
+    return out
+
+
+@pytest.mark.parametrize("k,dim", [(1, 2), (2, 10), (3, 32), (4, 136), (5, 512), (6, 2080)])
+def test_canonical_kmer_dimension(k, dim):
+    # 136 columns at k = 4 is what BASELINE.json's D = 136 (+ coverage columns) implies
+    assert O.kmer_dim(k) == dim == len(kmer_count.canonical_kmers(k))
+
+
+def test_oracle_kmer_counts_match_plain_python():
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGT"), size=n)) for n in (0, 3, 4, 5, 97, 1500)]
+    seqs += ["ACGTNNACGTacgtRYacg", "NNNN", "aaaaAAAAtttt", "ACG"]
+    for k in (1, 2, 4, 5):
+        freq, counts = O.kmer_frequencies(seqs, k)
+        for i, s in enumerate(seqs):
+            want = _py_counts(s, k)
+            assert np.array_equal(counts[i], want)
+            tot = want.sum()
+            assert np.array_equal(freq[i], want / tot if tot else np.zeros_like(freq[i]))
+    # a k-mer and its reverse complement share a column; palindromes count once
+    _, c = O.kmer_frequencies(["ACGT", "AAAA", "TTTT"], 4)
+    labels = kmer_count.canonical_kmers(4)
+    assert c[0, labels.index("ACGT")] == 1 and c[1, labels.index("AAAA")] == 1 and c[2, labels.index("AAAA")] == 1
+
+
+@pytest.mark.parametrize("fixture", ["coverages.npz", "coverages_multi.npz"])
+def test_parse_coverages_matches_reference_fixture(tmp_path, fixture):
+    g = np.load(os.path.join(GOLD, fixture))
+    path = tmp_path / "abund.tsv"
+    with open(path, "w") as fh:
+        for name, row in zip(g["names"], g["raw"]):
+            fh.write(str(name) + "\t" + "\t".join(repr(float(v)) for v in row) + "\n")
+    df = coverage.parse_coverages(path)
+    assert list(df["CONTIG_NAME"]) == [str(n) for n in g["names"]]
+    got = df.drop("CONTIG_NAME", axis=1).to_numpy(dtype=np.float64)
+    assert np.array_equal(got, g["normalised"])   # same pandas operations in the same order: bit-exact
+
+
+def _write_fasta(path, records):
+    with open(path, "w") as fh:
+        for ident, desc, seq in records:
+            fasta.write_record(fh, ident, seq, description=desc, width=70)
+
+
+def test_fasta_reader_and_length_filter(tmp_path):
+    recs = [("c1", "len=1200 cov=3", "ACGT" * 300), ("c2", "", "AC" * 100), ("c3", "x", "G" * 1000)]
+    src, dst = tmp_path / "in.fa", tmp_path / "out.fa"
+    _write_fasta(src, recs)
+    assert [(i, d, s) for i, d, s in fasta.read_fasta(src)] == recs
+    assert preprocess.get_contig_lengths(src) == {"c1": 1200, "c2": 200, "c3": 1000}
+    removed = preprocess.filter_short_contigs(src, dst, threshold=1000)        # preprocess.py:84: >= keeps
+    assert removed == ["c2"]
+    assert [(i, s) for i, _d, s in fasta.read_fasta(dst)] == [("c1", recs[0][2]), ("c3", recs[2][2])]
+
+
+@pytest.mark.parametrize("length,want", [(9000, [9000]), (10000, [10000]), (19999, [19999]), (20000, [10000, 10000]),
+                                         (25000, [10000, 15000]), (35000, [10000, 10000, 15000]),
+                                         (40000, [10000, 10000, 10000, 10000])])
+def test_split_rule_last_piece_absorbs_remainder(tmp_path, length, want):
+    # preprocess.py:17-35: pieces of split_len; the last one takes a remainder < split_len with it
+    seq = "".join(itertools.islice(itertools.cycle("ACGGT"), length))
+    src, dst = tmp_path / "in.fa", tmp_path / "out.fa"
+    _write_fasta(src, [("seed", "d", seq), ("other", "", seq)])
+    parents = preprocess.split_contigs(src, dst, ["seed"], split_len=10000)
+    out = list(fasta.read_fasta(dst))
+    seed_pieces = [s for i, _d, s in out if i.startswith("seed_S")]
+    assert [len(s) for s in seed_pieces] == want and "".join(seed_pieces) == seq
+    assert [i for i, _d, _s in out] == [f"seed_S{j}" for j in range(len(want))] + ["other_S0"]   # :62-63
+    assert all(d == "" for _i, d, _s in out)                                                     # description dropped
+    assert parents == {**{f"seed_S{j}": "seed" for j in range(len(want))}, "other_S0": "other"}
+
+
+def test_count_kmers_unknown_tool():
+    with pytest.raises(NotImplementedError):      # kmer_count.py:125
+        kmer_count.count_kmers("x.fa", ".", k=4, tool="jellyfish")
