@@ -108,35 +108,68 @@ __global__ __launch_bounds__(256) void fill_base_kernel(const int *labels, const
 // lab_old == nullptr selects the "everyone but myself" form used by chb_topm_per_bin:
 // code -(1<<30) - i, eligible iff query pos != i.
 
-__global__ void count_batch_kernel(const int *lab_prev, const int *lab_old, int K, int B, int *cnt)
+// CSR of the batch's own entries in ONE workgroup (K is a few thousand): LDS histogram, scan,
+// LDS cursors.  Entry codes: see chb_internal.h (TopmArgs::memb_code).
+__global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev, const int *lab_old, const int *bq,
+                                                            int K, int B, int *bin_ptr, int *pad_ptr, int *memb_id,
+                                                            int *memb_code)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= K) return;
-    const int a = lab_prev[i];
-    if (a >= 0 && a < B) atomicAdd(&cnt[a], 1);
-    if (lab_old) {
-        const int b = lab_old[i];
-        if (b >= 0 && b < B) atomicAdd(&cnt[b], 1);
+    extern __shared__ int sh[];   // [B] counts -> cursors, [1024] scan partials x 2
+    int *cnt = sh, *part = sh + B, *ppart = part + 1024;
+    const int tid = threadIdx.x;
+    for (int b = tid; b < B; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    for (int i = tid; i < K; i += 1024) {
+        const int a = lab_prev[i];
+        if (a >= 0 && a < B) atomicAdd(&cnt[a], 1);
+        if (lab_old) {
+            const int b = lab_old[i];
+            if (b >= 0 && b < B) atomicAdd(&cnt[b], 1);
+        }
     }
-}
-
-__global__ void fill_batch_kernel(const int *lab_prev, const int *lab_old, const int *bq, int K,
-                                  int B, int *cursor, int *memb_id, int *memb_code)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= K) return;
-    const int a = lab_prev[i];
-    if (a >= 0 && a < B) {
-        const int e = atomicAdd(&cursor[a], 1);
-        memb_id[e] = bq[i];
-        memb_code[e] = lab_old ? (i + 1) : (-(1 << 30) - i);
+    __syncthreads();
+    const int per = (B + 1023) / 1024;
+    const int b0 = min(B, tid * per), b1 = min(B, b0 + per);
+    int s = 0, sp = 0;
+    for (int b = b0; b < b1; ++b) { s += cnt[b]; sp += (cnt[b] + 31) / 32 * 32; }
+    part[tid] = s; ppart[tid] = sp;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, prun = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const int v = part[i], pv = ppart[i];
+            part[i] = run; ppart[i] = prun;
+            run += v; prun += pv;
+        }
     }
-    if (lab_old) {
-        const int b = lab_old[i];
-        if (b >= 0 && b < B) {
-            const int e = atomicAdd(&cursor[b], 1);
+    __syncthreads();
+    int run = part[tid], prun = ppart[tid];
+    for (int b = b0; b < b1; ++b) {
+        const int c = cnt[b];
+        bin_ptr[b] = run;
+        if (pad_ptr) pad_ptr[b] = prun;
+        cnt[b] = run;   // becomes the bin's cursor
+        run += c; prun += (c + 31) / 32 * 32;
+    }
+    if (tid == 1023) {
+        bin_ptr[B] = run;
+        if (pad_ptr) pad_ptr[B] = prun;
+    }
+    __syncthreads();
+    for (int i = tid; i < K; i += 1024) {
+        const int a = lab_prev[i];
+        if (a >= 0 && a < B) {
+            const int e = atomicAdd(&cnt[a], 1);
             memb_id[e] = bq[i];
-            memb_code[e] = -(i + 1);
+            memb_code[e] = lab_old ? (i + 1) : (-(1 << 30) - i);
+        }
+        if (lab_old) {
+            const int b = lab_old[i];
+            if (b >= 0 && b < B) {
+                const int e = atomicAdd(&cnt[b], 1);
+                memb_id[e] = bq[i];
+                memb_code[e] = -(i + 1);
+            }
         }
     }
 }
@@ -380,12 +413,9 @@ void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
                          hipStream_t s)
 {
-    launch_fill_i32(cnt, 0, B, s);
-    if (K > 0)
-        hipLaunchKernelGGL(count_batch_kernel, dim3((K + 255) / 256), dim3(256), 0, s, lab_prev, lab_old, K, B, cnt);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr);
-    if (K > 0)
-        hipLaunchKernelGGL(fill_batch_kernel, dim3((K + 255) / 256), dim3(256), 0, s, lab_prev, lab_old, bq, K, B, cursor, memb_id, memb_code);
+    (void)cnt; (void)cursor;   // (scratch of the former three-kernel form)
+    hipLaunchKernelGGL(bucket_batch_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 2048), s, lab_prev,
+                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code);
 }
 
 void launch_argmin(const double *dist, const int *lab_old, const int *lab_prev, int pos_begin,
