@@ -8,6 +8,7 @@ import numpy as np
 import pandas as pd
 
 from .clustering import fit_cluster
+from .clustering.dump_bins import dump_bins
 
 logger = logging.getLogger(__name__)
 
@@ -24,8 +25,8 @@ def perform_clustering(
 ) -> Path:
     """cli/clustering.py:19-99.  `in_mem_dist_matrix` (InMemDistMatrix) is accepted and both values
     are legal, but no N x N matrix is built: fit_cluster recomputes the distances it needs on the
-    GPU with cdist's rounding.  Writing bins/bin_{i}.fasta (dump_bins.py:8-29, needs Biopython) is
-    outside the accelerated path and skipped."""
+    GPU with cdist's rounding.  bins/bin_{i}.fasta (dump_bins.py:8-29) are written when `contig_fasta`
+    exists (the reference always has it; tests of the numeric path may pass a placeholder)."""
     operating_dir = Path(operating_dir)
     dist_bin_csv = operating_dir / "binning-assignment.csv"
     operating_dir.mkdir(parents=True, exist_ok=True)
@@ -65,8 +66,15 @@ def perform_clustering(
     parents, which = np.unique(table["PARENT_NAME"].to_numpy().astype(str), return_inverse=True)
     votes = np.zeros((len(parents), max(n_bins, 1)), dtype=np.int64)
     np.add.at(votes, (which, np.asarray(labels, dtype=np.int64)), 1)
-    pd.DataFrame({"CONTIG_NAME": parents, "BIN": votes.argmax(axis=1)}).to_csv(dist_bin_csv, index=False)
+    df_bins = pd.DataFrame({"CONTIG_NAME": parents, "BIN": votes.argmax(axis=1)})
+    df_bins.to_csv(dist_bin_csv, index=False)
     logger.info("Dumped binning assignment CSV at %s...", dist_bin_csv)
+
+    # cli/clustering.py:94-97
+    if contig_fasta is not None and Path(contig_fasta).is_file():
+        logger.info(">> Writing binned FASTA files...")
+        dump_bins(df_bins, Path(contig_fasta), operating_dir / "bins")
+        logger.info("Dumped binned FASTA files to %s...", operating_dir / "bins")
     return dist_bin_csv
 
 

@@ -6,6 +6,7 @@ from .distance_matrix import (  # noqa: F401
     create_in_mem_distance_matrix,
     find_nearest_from_cluster,
 )
+from .dump_bins import dump_bins  # noqa: F401
 from .hull_distance import (  # noqa: F401
     affine_hull_distance,
     affine_hull_distance_qp,

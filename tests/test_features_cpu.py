@@ -104,3 +104,18 @@ def test_split_rule_last_piece_absorbs_remainder(tmp_path, length, want):
 def test_count_kmers_unknown_tool():
     with pytest.raises(NotImplementedError):      # kmer_count.py:125
         kmer_count.count_kmers("x.fa", ".", k=4, tool="jellyfish")
+
+
+def test_dump_bins(tmp_path):
+    """dump_bins.py:8-29: one file per bin, records routed by id, unassigned records dropped."""
+    import pandas as pd
+    from chbin_amd.clustering import dump_bins
+    recs = [("a", "first", "ACGT" * 40), ("b", "", "GG" * 35), ("c", "x y", "T" * 10), ("d", "", "AC")]
+    src = tmp_path / "contigs.fa"
+    _write_fasta(src, recs)
+    out = tmp_path / "bins"
+    out.mkdir()
+    dump_bins(pd.DataFrame({"CONTIG_NAME": ["a", "b", "c"], "BIN": [2, 0, 2]}), src, out)
+    assert sorted(p.name for p in out.iterdir()) == ["bin_0.fasta", "bin_2.fasta"]
+    assert list(fasta.read_fasta(out / "bin_2.fasta")) == [recs[0], recs[2]]
+    assert list(fasta.read_fasta(out / "bin_0.fasta")) == [recs[1]]
