@@ -449,6 +449,295 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// m > 8 (the reference's function default is num_neighbors = 15, algorithm.py:17): a 16 x 16 Gram and
+// the solver's factor do not fit one lane's registers (the per-lane form above spills ~2 KB), so a
+// problem is spread over 16 lanes -- lane i owns vertex i, i.e. row i of Q and its weight alpha_i.
+//   phase 1: one v_mfma_f64_16x16x4_f64 tile per problem (16 vertices fill it exactly), four problems
+//     per wavefront one after the other, Gram rows handed to their lanes through LDS;
+//   phase 2: the same Wolfe iteration as min_norm_point<M>, with the reductions (value, entering
+//     vertex, ratio test) as 16-lane butterflies and the affine sub-problem solved through an
+//     incrementally maintained inverse with one matrix row per lane (see Inv16).
+// Groups follow their own control flow (all branches are uniform within a group of 16 lanes).
+
+__device__ __forceinline__ double group_sum16(double v)
+{
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 16);
+    return v;
+}
+// smallest key, ties to the lowest lane; key = +inf everywhere gives idx = -1
+__device__ __forceinline__ void group_argmin16(double key, int l16, double &kmin, int &idx)
+{
+    kmin = key;
+    idx = key < kInf ? l16 : -1;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        const double ok = __shfl_xor(kmin, off, 16);
+        const int oi = __shfl_xor(idx, off, 16);
+        if (oi >= 0 && (idx < 0 || ok < kmin || (ok == kmin && oi < idx))) { kmin = ok; idx = oi; }
+    }
+}
+
+// The affine sub-problem (Q_SS + s 11^T) b = 1, beta = b / sum(b) is solved through the explicit
+// inverse H of the lifted support Gram, kept up to date as vertices enter and leave (lane i holds
+// row i of H, zeros outside the support).  Entering / leaving is a bordering / Schur update whose
+// broadcasts are independent of each other -- a few shuffle rounds deep, where an elimination from
+// scratch is a 16-step dependent chain.  The pivot of the update is the Schur complement delta, the
+// same quantity whose collapse marks an affinely dependent support in solve_affine<M>.
+struct Inv16 {
+    double H[16];
+};
+
+// vertex v enters: false (and no change) when it is affinely dependent on the support
+__device__ __forceinline__ bool inv16_insert(Inv16 &I, const double (&Qr)[16], double s, unsigned &S, int v,
+                                             int l16, int gbase)
+{
+    // a_j = Q[v][j] + s for j in S (row v of Q lives on lane v); u = H a
+    double u = 0.0, a_own = 0.0, avv = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double aj = __shfl(Qr[j], gbase + v, 64) + s;
+        if ((S >> j) & 1u) u = fma(I.H[j], aj, u);
+        a_own = (j == l16) ? aj : a_own;
+        avv = (j == v) ? aj : avv;
+    }
+    const bool in = (S >> l16) & 1u;
+    double delta = avv - group_sum16(in ? a_own * u : 0.0);
+    if (!(delta > 1e-6 * avv)) {
+        // A small pivot is decided after one step of iterative refinement against the ORIGINAL rows
+        // of Q: the stored inverse carries an error of eps * cond, which must not leak into the
+        // test below (a dependent vertex has to come out at delta ~ eps * avv, as the Schur
+        // complement of a factorisation does).
+        double r = a_own;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double uj = __shfl(in ? u : 0.0, gbase + j, 64);
+            if ((S >> j) & 1u) r = fma(-(Qr[j] + s), uj, r);
+        }
+        r = in ? r : 0.0;
+        double du = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double rj = __shfl(r, gbase + j, 64);
+            if ((S >> j) & 1u) du = fma(I.H[j], rj, du);
+        }
+        u += du;
+        delta = avv - group_sum16(in ? a_own * u : 0.0);
+    }
+    if (!(delta > 1e-13 * avv)) return false;
+    const double inv = 1.0 / delta;
+    const double ui = in ? u : 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double uj = __shfl(ui, gbase + j, 64);
+        double h;
+        if (l16 == v) h = (j == v) ? inv : -uj * inv;                      // the new row
+        else h = (j == v) ? -ui * inv : fma(ui * inv, uj, I.H[j]);         // old rows + the new column
+        I.H[j] = h;
+    }
+    S |= 1u << v;
+    if (!in && l16 != v) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
+    }
+    return true;
+}
+
+// vertex r (in S) leaves
+__device__ __forceinline__ void inv16_remove(Inv16 &I, unsigned &S, int r, int l16, int gbase)
+{
+    double hrr = 0.0, own = 0.0;
+    double hr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        hr[j] = __shfl(I.H[j], gbase + r, 64);
+        hrr = (j == r) ? hr[j] : hrr;
+        own = (j == r) ? I.H[j] : own;
+    }
+    const double f = own / hrr;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) I.H[j] = (l16 == r || j == r) ? 0.0 : fma(-f, hr[j], I.H[j]);
+    S &= ~(1u << r);
+}
+
+// beta_l16 of the affine minimiser on the current support (0 outside); false if the weights do not sum > 0
+__device__ __forceinline__ bool inv16_beta(const Inv16 &I, double &beta)
+{
+    double b = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) b += I.H[j];
+    const double sum = group_sum16(b);
+    beta = b / sum;
+    return sum > 0.0;
+}
+
+template <bool INDEXED>
+__global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, const int *xq, const int *xhull,
+                                                        const int *xn, int xm, double *xdist, double *xalpha)
+{
+    __shared__ double sQ[4][4][16][17];   // [wavefront][problem][row][col], padded
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int grp = lane >> 4, l16 = lane & 15, gbase = lane & ~15;
+    const int m = INDEXED ? xm : a.m;
+    const int g = (blockIdx.x * 4 + w) * 4 + grp;   // my group's problem
+    const bool valid = g < nprob;
+    int n = 0, idm = -1, qid = 0;
+    size_t slot = 0;
+    if (valid) {
+        if (INDEXED) {
+            qid = xq[g];
+            n = xn[g];
+            if (l16 < n) idm = xhull[(size_t)g * m + l16];
+        } else {
+            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+            qid = a.bq[pos];
+            slot = (size_t)c * a.Kcap + pos;
+            n = a.lists.cnt[slot];
+            if (l16 < n) idm = a.lists.idx[slot * m + l16];
+        }
+    }
+    bool changed = valid;
+    if (!INDEXED && a.prev.idx != nullptr && valid)
+        changed = a.prev.cnt[slot] != n || (l16 < n && a.prev.idx[slot * m + l16] != idm);
+    const bool doit = ((__ballot(changed) >> (16 * grp)) & 0xFFFFull) != 0ull;   // else: keep the stored distance
+
+    // ---- phase 1: Gram of the shifted vertices, one matrix-core tile per problem
+    const int row = lane & 15, kq = lane >> 4;
+#pragma unroll 1
+    for (int p = 0; p < 4; ++p) {
+        const int np = __shfl(n, 16 * p, 64);
+        const bool go = __shfl(doit ? 1 : 0, 16 * p, 64) != 0 && np > 0;
+        if (!go) continue;   // wave-uniform
+        const int id = __shfl(idm, 16 * p + row, 64);
+        const int q = __shfl(qid, 16 * p, 64);
+        const bool live = id >= 0;
+        const double *vptr = a.X + (size_t)(live ? id : q) * a.Dp + 4 * kq;
+        const double *qptr = a.X + (size_t)q * a.Dp + 4 * kq;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < a.Dp; k0 += 32) {
+            double2 v[4], x[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kk = k0 + 16 * t + 4 * kq;
+                const bool in = kk < a.Dp;   // Dp % 8 == 0 and kk % 4 == 0: all 4 in range
+                v[2 * t] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t) : double2{0.0, 0.0};
+                v[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
+                x[2 * t] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t) : double2{0.0, 0.0};
+                x[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double y0 = v[t].x - x[t].x;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, acc, 0, 0, 0);
+                const double y1 = v[t].y - x[t].y;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, acc, 0, 0, 0);
+            }
+        }
+        // lane holds D[kq + 4 r][row]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sQ[w][p][kq + 4 * r][row] = acc[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wavefront's LDS writes have landed
+    if (!valid || !doit) return;
+
+    // ---- phase 2: one problem per 16-lane group
+    double Qr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Qr[j] = sQ[w][grp][l16][j];
+    const bool mine = l16 < n;
+    double alpha = 0.0, val = 0.0;
+    if (n <= 0) {
+        val = kInf;
+    } else {
+        double diag = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) diag = (j == l16) ? Qr[j] : diag;
+        double scale = mine ? diag : 0.0;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) scale = fmax(scale, __shfl_xor(scale, off, 16));
+        if (!(scale > 0.0)) {   // every vertex coincides with the query (or NaN input)
+            alpha = l16 == 0 ? 1.0 : 0.0;
+            val = scale == 0.0 ? 0.0 : scale;
+        } else if (a.metric == 0) {
+            double best;
+            int i0;
+            group_argmin16(mine ? diag : kInf, l16, best, i0);
+            unsigned S = 0u, banned = 0u;
+            Inv16 I;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
+            (void)inv16_insert(I, Qr, scale, S, i0, l16, gbase);   // a single vertex is always independent
+            alpha = l16 == i0 ? 1.0 : 0.0;
+            const double tol = 1.4210854715202004e-14 * scale;  // 64 eps * scale
+            for (int it = 0; it < 3 * 16 + 8; ++it) {
+                double gi = 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gi = fma(Qr[j], __shfl(alpha, gbase + j, 64), gi);
+                val = group_sum16(alpha * gi);
+                double gmin;
+                int jb;
+                group_argmin16((mine && !(((S | banned) >> l16) & 1u)) ? gi : kInf, l16, gmin, jb);
+                if (jb < 0 || !(gmin < val - tol)) break;
+                if (!inv16_insert(I, Qr, scale, S, jb, l16, gbase)) {
+                    banned |= 1u << jb;
+                    continue;
+                }
+                for (int mi = 0; mi <= 16; ++mi) {
+                    double beta;
+                    if (!inv16_beta(I, beta)) {   // (degenerate weights: give the vertex up)
+                        if ((S >> jb) & 1u) inv16_remove(I, S, jb, l16, gbase);
+                        banned |= 1u << jb;
+                        break;
+                    }
+                    const bool in = (S >> l16) & 1u;
+                    const bool bad = in && !(beta > 0.0);
+                    if (((__ballot(bad) >> (16 * grp)) & 0xFFFFull) == 0ull) {
+                        alpha = in ? beta : 0.0;
+                        break;
+                    }
+                    const double den = alpha - beta;
+                    double theta;
+                    int kr;
+                    group_argmin16(bad ? (den > 0.0 ? alpha / den : 0.0) : kInf, l16, theta, kr);
+                    const double vnew = alpha + theta * (beta - alpha);
+                    alpha = (in && l16 != kr) ? vnew : 0.0;
+                    inv16_remove(I, S, kr, l16, gbase);
+                    if (kr == jb) banned |= 1u << jb;
+                }
+            }
+            double gi = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gi = fma(Qr[j], __shfl(alpha, gbase + j, 64), gi);
+            val = group_sum16(alpha * gi);
+        } else {
+            // distance to the AFFINE hull: greedy maximal affinely independent subset (affine_min_norm)
+            unsigned S = 0u;
+            Inv16 I;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
+            for (int k = 0; k < n; ++k) (void)inv16_insert(I, Qr, scale, S, k, l16, gbase);
+            double beta = 0.0;
+            const bool okb = S != 0u && inv16_beta(I, beta);
+            alpha = (okb && ((S >> l16) & 1u)) ? beta : 0.0;
+            if (!okb) alpha = l16 == 0 ? 1.0 : 0.0;
+            double gi = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gi = fma(Qr[j], __shfl(alpha, gbase + j, 64), gi);
+            val = group_sum16(alpha * gi);
+        }
+    }
+    const double dist = n <= 0 ? kInf : sqrt(fmax(val, 0.0));
+    if (INDEXED) {
+        if (l16 == 0) xdist[g] = dist;
+        if (xalpha && l16 < m) xalpha[(size_t)g * m + l16] = alpha;
+    } else if (l16 == 0) {
+        const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+        a.dist[(size_t)pos * a.B + c] = dist;
+    }
+}
+
 template <int M, int WV, bool INDEXED>
 void launch_one(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull, const int *xn,
                 double *xdist, double *xalpha, hipStream_t s)
@@ -468,7 +757,9 @@ void dispatch(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull
     if (m <= 4) launch_one<4, 4, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
     else if (m <= 5) launch_one<5, 4, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
     else if (m <= 8) launch_one<8, 2, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
-    else launch_one<16, 1, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
+    else
+        hipLaunchKernelGGL((hull_qp16_kernel<INDEXED>), dim3((nprob + 15) / 16), dim3(256), 0, s, a, nprob, xq, xhull,
+                           xn, m, xdist, xalpha);
 }
 
 }  // namespace
