@@ -248,6 +248,21 @@ def main():
                              f"against the full N={N} (oracle/chb_oracle.c:chbo_sweep, {cdt:.1f} s); "
                              "labels of the sample verified identical to the GPU's",
                    "host_cpus": os.cpu_count()}
+            # same arithmetic on all the host cores this process may use: the sampled
+            # contigs are evaluated independently against the frozen seed-state labels, so this times
+            # the per-(contig, bin) work of a sweep in parallel; it is not itself a sequential sweep
+            try:
+                nthr = max(1, min(len(os.sched_getaffinity(0)), 16))   # the GPU box grants ~16 cores per GPU
+            except AttributeError:
+                nthr = max(1, min(os.cpu_count() or 1, 16))
+            if nthr > 1:
+                ids_mt = perms[0][:min(ns * nthr, n_move)]
+                t3 = time.perf_counter()
+                bb_mt, _ = O.eval_frozen_mt(X, B, initial, ids_mt, m, nthr)
+                mdt = time.perf_counter() - t3
+                cpu["all_cores"] = {"value": len(ids_mt) * B / mdt, "unit": "QP/s", "cores": nthr, "kind": "port",
+                                    "sample": f"{len(ids_mt)} contigs x all {B} bins against the full N={N}, frozen "
+                                              f"seed-state labels, OpenMP over contigs (chbo_eval_frozen_mt, {mdt:.1f} s)"}
 
         out = {
             "metric": "convex-hull QP distances/sec (+ end-to-end bin-assign wall-clock), N=100k D=136 B=64",

@@ -64,6 +64,9 @@ def lib():
         L.chbo_fit_cluster.argtypes = [_f64p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i64p,
                                        C.c_int64, C.c_int, C.c_int, C.c_void_p, _i64p, _i64p]
         L.chbo_fit_cluster.restype = C.c_int
+        L.chbo_eval_frozen_mt.argtypes = [_f64p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i64p, C.c_int64,
+                                          C.c_int, C.c_int, _i64p, _f64p]
+        L.chbo_eval_frozen_mt.restype = C.c_int64
         L.chbo_kmer_dim.argtypes = [C.c_int, C.c_void_p]
         L.chbo_kmer_dim.restype = C.c_int64
         L.chbo_kmer_frequencies.argtypes = [C.c_char_p, _i64p, C.c_int64, C.c_int, _f64p, _i64p]
@@ -205,3 +208,15 @@ def kmer_frequencies(seqs, k):
     if rc != 0:
         raise ValueError("unsupported k")
     return freq, counts
+
+
+def eval_frozen_mt(X, B, labels, ids, m, nthreads):
+    """Multi-threaded timing helper: strict-'>' argmin bin and distance of each contig in `ids`
+    against frozen labels (see chbo_eval_frozen_mt).  Returns (best_bin, best_dist)."""
+    X = _f64(X)
+    labels = _i64(labels)
+    ids = _i64(ids)
+    bb = np.zeros(len(ids), dtype=np.int64)
+    bd = np.zeros(len(ids), dtype=np.float64)
+    lib().chbo_eval_frozen_mt(X, X.shape[0], X.shape[1], int(B), labels, ids, len(ids), int(m), int(nthreads), bb, bd)
+    return bb, bd
