@@ -1,0 +1,51 @@
+"""Developer soak: random small configurations, HIP fit_cluster vs the CPU oracle (labels, sweep
+counts, per-sweep change counts must be identical).  usage: python tools/fuzz_fit.py [n_cases] [seed]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import chbin_amd  # noqa: E402,F401
+from chbin_amd import _lib, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ctx = _lib.default_context()
+bad = 0
+for t in range(n_cases):
+    N = int(rng.integers(200, 1800))
+    D = int(rng.choice([8, 24, 40, 100, 136, 137, 140, 143, 144, 145, 146, 160, 161, 200]))
+    B = int(rng.integers(1, 24))
+    m = int(rng.choice([1, 2, 3, 5, 5, 5, 8, 9, 15, 16]))
+    S = 1 if D < 140 else (5 if D < 146 else 10)
+    iters = int(rng.integers(1, 6))
+    batch = int(rng.choice([0, 1, 7, 64, 100, 257, 1000, 4096]))
+    sigma = float(rng.choice([1.5e-3, 4e-3, 9e-3]))
+    mix = float(rng.choice([0.0, 0.3, 0.6, 0.9]))
+    n_seed = int(rng.integers(1, 12))
+    metric = str(rng.choice(["convex", "convex", "convex", "affine"]))
+    if m > D or D < 24:
+        # m > D: the affine hull of > D generic points is the whole space, every distance is rounding
+        # noise.  Small D: the reference formula (scipy.linalg.orth with its default cutoff eps * max(m, D),
+        # restated in the oracle) can admit the pure-noise direction of the centred vertex matrix
+        # (DESIGN.md section 2), so there is no stable reference value to compare with.
+        metric = "convex"
+    X, initial, _ = synth.make_synthetic(N, D, B, S=min(S, max(D - 4, 1)), seed=int(rng.integers(1 << 30)), sigma=sigma,
+                                         mix=mix, n_seed=n_seed)
+    if rng.random() < 0.2 and m <= 8:   # (the oracle's nearest-PD / GI restatement crawls on rescaled 15-vertex hulls)
+        X = X * float(10.0 ** rng.integers(-6, 7))
+    perms = synth.draw_permutations(initial, iters, seed=int(rng.integers(1 << 30)))
+    print(f"[{t:3d}] N={N} D={D} B={B} m={m} iters={iters} batch={batch} ...", flush=True)
+    want, its_o, ch_o = O.fit_cluster(X, B, initial, perms, m, iters, metric=metric)
+    ctx.set_metric(metric)
+    ctx.set_samples(X)
+    got, its, ch = ctx.fit_cluster(B, initial, perms, m, iters, batch=batch)
+    ok = its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
+    bad += not ok
+    print(f"[{t:3d}] N={N} D={D} B={B} m={m} iters={iters} batch={batch} sigma={sigma} mix={mix} seeds={n_seed} "
+          f"{metric}: {'ok' if ok else 'MISMATCH'} (sweeps {its}/{its_o}, diff labels {int((got != want).sum())})", flush=True)
+ctx.set_metric("convex")
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
