@@ -1,5 +1,5 @@
 """Developer soak: random small configurations, HIP fit_cluster vs the CPU oracle (labels, sweep
-counts, per-sweep change counts must be identical).  usage: python tools/fuzz_fit.py [n_cases] [seed]"""
+counts, per-sweep change counts must be identical).  usage: python tools/fuzz_fit.py [n_cases] [seed] [big]   (big: bins of > 512 members, few bins)"""
 import os
 import sys
 
@@ -11,6 +11,7 @@ from chbin_amd import _lib, synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ctx = _lib.default_context()
 bad = 0
@@ -25,6 +26,11 @@ for t in range(n_cases):
     sigma = float(rng.choice([1.5e-3, 4e-3, 9e-3]))
     mix = float(rng.choice([0.0, 0.3, 0.6, 0.9]))
     n_seed = int(rng.integers(1, 12))
+    if big:
+        N = int(rng.integers(3000, 7000)); B = int(rng.integers(2, 7)); m = int(rng.choice([3, 5, 5, 8]))
+        iters = int(rng.integers(1, 4)); batch = int(rng.choice([0, 512, 2048])); n_seed = int(rng.integers(5, 40))
+        D = int(rng.choice([100, 136, 140, 146]))
+        S = 1 if D < 140 else (5 if D < 146 else 10)
     metric = str(rng.choice(["convex", "convex", "convex", "affine"]))
     if m > D or D < 24:
         # m > D: the affine hull of > D generic points is the whole space, every distance is rounding
