@@ -450,7 +450,7 @@ __device__ __forceinline__ void list_insert_desc(float (&l)[ML], float v)
 }
 
 template <int ML, bool UPD, int KS>
-__global__ __launch_bounds__(256, ML <= 8 ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
+__global__ __launch_bounds__(256, (ML <= 8 && KS == 9) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
                                                                          int bpw, int *flags64, int nqt64)
 {
     constexpr int CPR = 2 * KS;              // 16-byte chunks per shadow row
