@@ -25,6 +25,28 @@ __global__ void gather_labels_kernel(const int *labels, const int *bq, int K, in
     if (i < K) out[i] = labels[bq[i]];
 }
 
+// batch start: remember the members' labels and mark them as "in the batch at position i"
+__global__ void batch_open_kernel(const int *labels, int *inb, const int *bq, int K, int *lab_old)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) {
+        const int p = bq[i];
+        lab_old[i] = labels[p];
+        inb[p] = i;
+    }
+}
+
+// batch end (without the shadow refresh): final labels out, marks cleared
+__global__ void batch_close_kernel(int *labels, int *inb, const int *bq, const int *lab, int K)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) {
+        const int p = bq[i];
+        labels[p] = lab[i];
+        inb[p] = -1;
+    }
+}
+
 __global__ void scatter_labels_kernel(int *labels, const int *bq, const int *lab, int K)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -392,6 +414,14 @@ void launch_mark_batch(int *inb, const int *bq, int K, int set, hipStream_t s)
 void launch_gather_labels(const int *labels, const int *bq, int K, int *out, hipStream_t s)
 {
     if (K > 0) hipLaunchKernelGGL(gather_labels_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, bq, K, out);
+}
+void launch_batch_open(const int *labels, int *inb, const int *bq, int K, int *lab_old, hipStream_t s)
+{
+    if (K > 0) hipLaunchKernelGGL(batch_open_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, inb, bq, K, lab_old);
+}
+void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, int K, hipStream_t s)
+{
+    if (K > 0) hipLaunchKernelGGL(batch_close_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, inb, bq, lab, K);
 }
 void launch_scatter_labels(int *labels, const int *bq, const int *lab, int K, hipStream_t s)
 {

@@ -286,6 +286,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->n_active.ensure(1));
         HIPCHK(h->act_blk.ensure((K * B + 4095) / 4096 + 1));
         HIPCHK(h->flags64.ensure(B * ((K + kQTile - 1) / kQTile)));
+        launch_fill_i32(h->flags64.p, 0, (int)(B * ((K + kQTile - 1) / kQTile)), h->stream);   // kept zero by its consumer
         HIPCHK(h->overflow.ensure(1));
         HIPCHK(h->qn.ensure(K * B * 2));
         HIPCHK(h->pk.ensure((size_t)h->N + 32 * B, B, (size_t)h->Dz));
@@ -326,7 +327,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
                            h->memb_id.p, nullptr, h->stream);
         launch_bin_centers(h->X.p, h->D, h->Dp, h->memb_id.p, h->bin_ptr.p, h->B, h->centers.p, h->stream);
         launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
-                             h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, h->stream);
+                             h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, nullptr, nullptr, h->stream);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -341,8 +342,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
     h->K = K; h->q_lo = q_lo; h->q_hi = q_hi;
     h->round_in_batch = 0;
     hipStream_t s = h->stream;
-    launch_gather_labels(h->labels.p, h->bq.p, K, h->lab_old.p, s);
-    launch_mark_batch(h->inb.p, h->bq.p, K, 1, s);
+    launch_batch_open(h->labels.p, h->inb.p, h->bq.p, K, h->lab_old.p, s);
     {
         Timed t(h, "bucket", (double)h->N);
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
@@ -358,7 +358,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         // two-stage exact selection: bf16 matrix-core shortlist, exact fp64 on the shortlist,
         // brute force only for (query tile, bin) pairs whose shortlist overflowed
         const int nq64 = (q_hi - q_lo + kQTile - 1) / kQTile;
-        launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
+        (void)nq64;   // (flags64 is all zero here: launch_topm_flagged clears what it serves)
         if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
         {
             Timed t(h, "query_norms", (double)(q_hi - q_lo) * h->B);
@@ -423,8 +423,6 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         if (h->use_prefilter && h->pf_update && h->shadow_ok && h->cand.p) {
             // batch members that can displace an entry of the base list: bf16 shortlist against
             // the exact m-th distance, exact rescoring seeded with the base list
-            const int nq64 = (hi - lo + kQTile - 1) / kQTile;
-            launch_fill_i32(h->flags64.p, 0, h->B * nq64, s);
             // (fit rounds only produce the "earlier" / "later" eligibility codes, which have the affine
             // form the shortlist kernel evaluates; chb_topm_per_bin's "not equal" code stays on launch_topm)
             launch_pack_centered(h->X.p, h->D, h->Dp, h->memb2_id.p, h->memb2_code.p, h->bin_ptr2.p, h->B, 2 * h->K,
@@ -501,11 +499,13 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
 int batch_commit_dev(chb_ctx *h, const int *final_dev)
 {
     hipStream_t s = h->stream;
-    launch_scatter_labels(h->labels.p, h->bq.p, final_dev, h->K, s);
-    launch_mark_batch(h->inb.p, h->bq.p, h->K, 0, s);
-    if (h->use_prefilter && h->shadow_ok && h->centers.p)   // their bin (hence their centre) changed
+    if (h->use_prefilter && h->shadow_ok && h->centers.p)
+        // final labels out, batch marks cleared, and the members' shadow rows recomputed against their
+        // new bin's centre: one launch
         launch_sample_shadow(h->X.p, h->D, h->Dp, h->bq.p, h->K, h->labels.p, h->B, h->centers.p, h->mu_g.p,
-                             h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, s);
+                             h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, final_dev, h->inb.p, s);
+    else
+        launch_batch_close(h->labels.p, h->inb.p, h->bq.p, final_dev, h->K, s);
     HIPCHK(hipGetLastError());
     h->batch_open = false;
     return CHB_OK;

@@ -37,7 +37,7 @@ struct TopmArgs {
 
 void launch_topm(const TopmArgs &a, hipStream_t s);
 // same, but only work items (bin, query tile of 64) whose flag is set run; the rest exit at once
-void launch_topm_flagged(const TopmArgs &a, const int *flags64, hipStream_t s);
+void launch_topm_flagged(const TopmArgs &a, int *flags64, hipStream_t s);   // (clears the flags it serves)
 
 // ---- two-stage exact selection (prefilter_kernels.hip + rescore in topm_kernels.hip)
 constexpr int kCandCap = 128;   // shortlist capacity per (bin, batch position)
@@ -64,9 +64,11 @@ void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, cons
                         double *centers, hipStream_t s);
 // member-side row of each listed sample relative to the centre of its current bin:
 // Zs[N][Dz], ms[N] = float4 {bias, rho, ||zh||^2, amax}
-void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, const int *labels,
+// (commit form: ids = the batch, new_lab[i] = final label of ids[i]: the kernel also writes it to
+// labels[] and clears the batch mark inb[] -- scatter, unmark and shadow refresh in one launch)
+void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, int *labels,
                           int B, const double *centers, const double *mu_g, double S, unsigned short *Zs,
-                          int Dz, void *ms, hipStream_t s);
+                          int Dz, void *ms, const int *new_lab, int *inb, hipStream_t s);
 // base members (CSR; P.pad_ptr from launch_bucket_base) -> padded pack (+ per-bin bounds)
 void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
                       int B, int rows_hint, const MemberPack &P, hipStream_t s);
@@ -143,6 +145,9 @@ void launch_fill_i32(int *p, int v, int n, hipStream_t s);
 void launch_mark_batch(int *inb, const int *bq, int K, int set, hipStream_t s);
 void launch_gather_labels(const int *labels, const int *bq, int K, int *out, hipStream_t s);
 void launch_scatter_labels(int *labels, const int *bq, const int *lab, int K, hipStream_t s);
+// batch start: lab_old[i] = labels[bq[i]], inb[bq[i]] = i;  batch end: labels[bq[i]] = lab[i], inb[bq[i]] = -1
+void launch_batch_open(const int *labels, int *inb, const int *bq, int K, int *lab_old, hipStream_t s);
+void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, int K, hipStream_t s);
 // CSR of all labelled samples outside the batch
 // (pad_ptr, optional: the same CSR with every bin padded to a multiple of 32 rows -> MemberPack)
 void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,

@@ -197,15 +197,22 @@ __device__ __forceinline__ float4 member_shadow_row(const double *x, const doubl
 // Per-sample member rows relative to the centre of the sample's CURRENT bin (labels[p] >= 0).
 // ids == nullptr: all samples 0..n-1; otherwise the n listed samples (the batch just committed).
 __global__ __launch_bounds__(256) void sample_shadow_kernel(const double *X, int D, int Dp, const int *ids,
-                                                            int n, const int *labels, int B,
+                                                            int n, int *labels, int B,
                                                             const double *centers, const double *mu_g, double S,
-                                                            unsigned short *Zs, int Dz, float4 *ms)
+                                                            unsigned short *Zs, int Dz, float4 *ms,
+                                                            const int *new_lab, int *inb)
 {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const int p = ids ? ids[i] : i;
-    const int c = labels[p];
+    int c;
+    if (new_lab) {   // batch commit: the sample's final label goes out, its batch mark is cleared
+        c = new_lab[i];
+        if (lane == 0) { labels[p] = c; inb[p] = -1; }
+    } else {
+        c = labels[p];
+    }
     if (c < 0 || c >= B) return;
     const float4 o = member_shadow_row(X + (size_t)p * Dp, centers + (size_t)c * Dp, mu_g, S, D, Dz, lane,
                                        Zs + (size_t)p * Dz);
@@ -821,13 +828,13 @@ void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, cons
     if (B > 0) hipLaunchKernelGGL(bin_center_kernel, dim3(B), dim3(256), 0, s, X, D, Dp, memb_id, bin_ptr, centers);
 }
 
-void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, const int *labels,
+void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, int *labels,
                           int B, const double *centers, const double *mu_g, double S, unsigned short *Zs,
-                          int Dz, void *ms, hipStream_t s)
+                          int Dz, void *ms, const int *new_lab, int *inb, hipStream_t s)
 {
     if (n > 0)
         hipLaunchKernelGGL(sample_shadow_kernel, dim3((n + 3) / 4), dim3(256), 0, s, X, D, Dp, ids, n, labels,
-                           B, centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms));
+                           B, centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms), new_lab, inb);
 }
 
 void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,

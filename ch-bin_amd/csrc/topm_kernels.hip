@@ -93,7 +93,7 @@ __device__ __forceinline__ void select_into(double (&s)[NC], const int (&mid)[NC
 // (chb_pairwise_distance); "bins" are then contiguous member ranges and bq is null.
 template <bool PW>
 __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int total, int pw_n,
-                                                   int pw_group, double *pw_out, const int *flags)
+                                                   int pw_group, double *pw_out, int *flags)
 {
     __shared__ __attribute__((aligned(16))) double sQ[2][kKChunk][kLdsStride];
     __shared__ __attribute__((aligned(16))) double sP[2][kKChunk][kLdsStride];
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
 
     if (nsteps > 0) { prefetch(); stash(0); }
     __syncthreads();
+    if (flags != nullptr && tid == 0) flags[W] = 0;   // every thread has read it (above the barrier): served
 
     int ct = 0, cc = 0;  // (tile, chunk) of the step being computed
     for (int step = 0; step < nsteps; ++step) {
@@ -389,10 +390,10 @@ void launch_topm(const TopmArgs &a, hipStream_t s)
     const int total = nqt * a.B;
     const int grid = ((total + 7) / 8) * 8;
     hipLaunchKernelGGL(tile_kernel<false>, dim3(grid), dim3(256), 0, s, a, nqt, total, 0, 0,
-                       (double *)nullptr, (const int *)nullptr);
+                       (double *)nullptr, (int *)nullptr);
 }
 
-void launch_topm_flagged(const TopmArgs &a, const int *flags64, hipStream_t s)
+void launch_topm_flagged(const TopmArgs &a, int *flags64, hipStream_t s)
 {
     const int nq = a.pos_end - a.pos_begin;
     if (nq <= 0 || a.B <= 0) return;
@@ -428,7 +429,7 @@ void launch_pairwise(const double *X, int N, int Dp, int r0, int r1, double *out
     const int total = nqt * ngroups;
     const int grid = ((total + 7) / 8) * 8;
     hipLaunchKernelGGL(tile_kernel<true>, dim3(grid), dim3(256), 0, s, a, nqt, total, N, group, out,
-                       (const int *)nullptr);
+                       (int *)nullptr);
 }
 
 }  // namespace chb
