@@ -45,6 +45,12 @@ def main():
     ap.add_argument("--same-gpu", action="store_true", help="dev only: all ranks on cuda:0")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the result: libraries that chat on fd 1 (RCCL prints a version
+    # banner when a communicator is created, gloo its peer counts) are sent to stderr instead
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
 
     import chbin_amd
@@ -284,7 +290,8 @@ def main():
             "prefilter": {"enabled": ctx.counter("prefilter_enabled"),
                           "shortlist_overflows_last_call": ctx.counter("prefilter_overflow")},
         }
-        print(json.dumps(out))
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
