@@ -457,7 +457,7 @@ __device__ __forceinline__ void list_insert_desc(float (&l)[ML], float v)
 }
 
 template <int ML, bool UPD, int KS>
-__global__ __launch_bounds__(256, (ML <= 8 && KS == 9) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
+__global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
                                                                          int bpw, int *flags64, int nqt64)
 {
     constexpr int CPR = 2 * KS;              // 16-byte chunks per shadow row
@@ -581,6 +581,20 @@ __global__ __launch_bounds__(256, (ML <= 8 && KS == 9) ? 4 : 3) void shortlist_k
     }
     const unsigned ent0 = ((unsigned)col << 27) | (unsigned)(4 * h);
 
+    // parked entries -> the queries' shortlists (entry = query of this wavefront, member offset in the
+    // bin); the per-query counters keep running, so the pool can be emptied in the middle of a bin
+#define CHB_SL_FLUSH()                                                                             \
+    {                                                                                              \
+        const int mb_ = a.bin_ptr[c];                                                              \
+        const int npark_ = wcnt < kPoolW ? wcnt : kPoolW;                                          \
+        for (int i = lane; i < npark_; i += 64) {                                                  \
+            const unsigned en = sPool[w * kPoolW + i];                                             \
+            const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));                     \
+            const int off = atomicAdd(&sCnt[32 * w + qc], 1);                                      \
+            if (off < kCandCap)                                                                    \
+                a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * kCandCap + off] = a.memb_id[mb_ + e]; \
+        }                                                                                          \
+    }
     int cbuf = 0, n_consumed = 0;
     for (int c = c0; c < c1; ++c) {
         const int row0 = a.P.pad_ptr[c];
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(256, (ML <= 8 && KS == 9) ? 4 : 3) void shortlist_k
         }
         if (h == 0) sCnt[32 * w + col] = 0;
         const bool tile_best = ntile >= a.tile_best_min;
-        int wcnt = 0;   // entries parked by this wavefront for this bin (wave-uniform)
+        int wcnt = 0;   // entries parked by this wavefront and not yet written out (wave-uniform)
 
         for (int sweep = UPD ? 1 : 0; sweep < 2; ++sweep) {
             const float rgs = (sweep ? rg : -rg) * (1.0f + kSlack);
@@ -723,6 +737,13 @@ __global__ __launch_bounds__(256, (ML <= 8 && KS == 9) ? 4 : 3) void shortlist_k
                         mx = nx;
                     }
                 } else {
+                    // make room (wave-uniform).  Only in the builds for m > 8 (update mode: ML = 2), whose
+                    // shortlists are long: in the 128-VGPR builds the extra code pushes query fragments into
+                    // scratch inside this loop
+                    if ((ML > 8 || (UPD && ML > 1)) && wcnt >= kPoolW / 2 && wcnt <= kPoolW) {
+                        CHB_SL_FLUSH()
+                        wcnt = 0;
+                    }
                     const unsigned ebase = ent0 + (unsigned)(ct * kPfP);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -745,16 +766,7 @@ __global__ __launch_bounds__(256, (ML <= 8 && KS == 9) ? 4 : 3) void shortlist_k
         }
 
         // ---- end of the bin: write the parked entries out
-        // entry -> (query of this wavefront, member offset in the bin)
-        const int mb = a.bin_ptr[c];
-        const int npark = wcnt < kPoolW ? wcnt : kPoolW;
-        for (int i = lane; i < npark; i += 64) {
-            const unsigned en = sPool[w * kPoolW + i];
-            const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));
-            const int off = atomicAdd(&sCnt[32 * w + qc], 1);
-            if (off < kCandCap)
-                a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * kCandCap + off] = a.memb_id[mb + e];
-        }
+        CHB_SL_FLUSH()
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
         if (qvalid && h == 0) {
@@ -765,6 +777,7 @@ __global__ __launch_bounds__(256, (ML <= 8 && KS == 9) ? 4 : 3) void shortlist_k
             }
         }
     }
+#undef CHB_SL_FLUSH
 #undef CHB_SL_ISSUE
 #undef CHB_SL_ISSUE_SEEK
 }
@@ -881,7 +894,8 @@ void launch_shortlist(const ShortlistArgs &a_, int *flags64, hipStream_t s)
     const int nq = a.pos_end - a.pos_begin;
     if (nq <= 0 || a.B <= 0) return;
     if (a.update) {
-        launch_sl<1, true>(a, flags64, s);
+        if (a.m <= 8) launch_sl<1, true>(a, flags64, s);
+        else launch_sl<2, true>(a, flags64, s);   // (ML is unused in update mode: 2 marks the m > 8 build)
     } else if (a.m <= 5) {
         launch_sl<5, false>(a, flags64, s);
     } else if (a.m <= 8) {
