@@ -13,18 +13,6 @@ __global__ void fill_i32_kernel(int *p, int v, int n)
     if (i < n) p[i] = v;
 }
 
-__global__ void mark_batch_kernel(int *inb, const int *bq, int K, int set)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < K) inb[bq[i]] = set ? i : -1;
-}
-
-__global__ void gather_labels_kernel(const int *labels, const int *bq, int K, int *out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < K) out[i] = labels[bq[i]];
-}
-
 // batch start: remember the members' labels and mark them as "in the batch at position i"
 __global__ void batch_open_kernel(const int *labels, int *inb, const int *bq, int K, int *lab_old)
 {
@@ -45,12 +33,6 @@ __global__ void batch_close_kernel(int *labels, int *inb, const int *bq, const i
         labels[p] = lab[i];
         inb[p] = -1;
     }
-}
-
-__global__ void scatter_labels_kernel(int *labels, const int *bq, const int *lab, int K)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < K) labels[bq[i]] = lab[i];
 }
 
 // ---- base members: every labelled sample that is not in the current batch
@@ -407,14 +389,6 @@ void launch_fill_i32(int *p, int v, int n, hipStream_t s)
 {
     if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
 }
-void launch_mark_batch(int *inb, const int *bq, int K, int set, hipStream_t s)
-{
-    if (K > 0) hipLaunchKernelGGL(mark_batch_kernel, dim3((K + 255) / 256), dim3(256), 0, s, inb, bq, K, set);
-}
-void launch_gather_labels(const int *labels, const int *bq, int K, int *out, hipStream_t s)
-{
-    if (K > 0) hipLaunchKernelGGL(gather_labels_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, bq, K, out);
-}
 void launch_batch_open(const int *labels, int *inb, const int *bq, int K, int *lab_old, hipStream_t s)
 {
     if (K > 0) hipLaunchKernelGGL(batch_open_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, inb, bq, K, lab_old);
@@ -422,10 +396,6 @@ void launch_batch_open(const int *labels, int *inb, const int *bq, int K, int *l
 void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, int K, hipStream_t s)
 {
     if (K > 0) hipLaunchKernelGGL(batch_close_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, inb, bq, lab, K);
-}
-void launch_scatter_labels(int *labels, const int *bq, const int *lab, int K, hipStream_t s)
-{
-    if (K > 0) hipLaunchKernelGGL(scatter_labels_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, bq, lab, K);
 }
 
 void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,

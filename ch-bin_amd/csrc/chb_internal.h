@@ -142,9 +142,6 @@ void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const 
 
 // label / bucket helpers
 void launch_fill_i32(int *p, int v, int n, hipStream_t s);
-void launch_mark_batch(int *inb, const int *bq, int K, int set, hipStream_t s);
-void launch_gather_labels(const int *labels, const int *bq, int K, int *out, hipStream_t s);
-void launch_scatter_labels(int *labels, const int *bq, const int *lab, int K, hipStream_t s);
 // batch start: lab_old[i] = labels[bq[i]], inb[bq[i]] = i;  batch end: labels[bq[i]] = lab[i], inb[bq[i]] = -1
 void launch_batch_open(const int *labels, int *inb, const int *bq, int K, int *lab_old, hipStream_t s);
 void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, int K, hipStream_t s);
