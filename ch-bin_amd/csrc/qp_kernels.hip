@@ -23,7 +23,7 @@
 #include <math.h>
 
 #ifndef CHB_QP_UNROLL
-#define CHB_QP_UNROLL 2
+#define CHB_QP_UNROLL 1
 #endif
 
 namespace chb {
@@ -325,8 +325,28 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
 #pragma unroll
             for (int e = 0; e < NP; ++e) acc[e] = 0.0;
             if (n > 0) {
+                // 32 features per step as 16-byte loads (lane l16: features 2 l16, 2 l16 + 1), then the
+                // remaining < 32 features one double per lane
+                const int Dmain = a.Dp & ~31;
 #pragma unroll CHB_QP_UNROLL
-                for (int k = l16; k < a.Dp; k += 16) {
+                for (int k = 2 * l16; k < Dmain; k += 32) {
+                    const double2 xk = *reinterpret_cast<const double2 *>(xrow + k);
+                    double2 y[M];
+#pragma unroll
+                    for (int v = 0; v < M; ++v) {
+                        const double2 pv = *reinterpret_cast<const double2 *>(vrow[v] + k);
+                        y[v] = double2{pv.x - xk.x, pv.y - xk.y};
+                    }
+#pragma unroll
+                    for (int i = 0; i < M; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) {
+                            double acc_ij = acc[Sym<M>::at(i, j)];
+                            acc_ij = fma(y[i].x, y[j].x, acc_ij);
+                            acc[Sym<M>::at(i, j)] = fma(y[i].y, y[j].y, acc_ij);
+                        }
+                }
+                for (int k = Dmain + l16; k < a.Dp; k += 16) {
                     const double xk = xrow[k];
                     double y[M];
 #pragma unroll
