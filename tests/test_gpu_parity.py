@@ -332,7 +332,7 @@ def test_full_size_fixed_point_property(ctx, O):
 # ------------------------------------------------------------------ two-stage selection
 
 def _brute_ctx():
-    """A second context with the bf16 shortlist stage disabled (brute-force selection)."""
+    """A second context with the fp16 shortlist stage disabled (brute-force selection)."""
     from chbin_amd import _lib
     old = os.environ.get("CHB_PREFILTER")
     os.environ["CHB_PREFILTER"] = "0"
@@ -392,6 +392,32 @@ def test_shortlist_stage_equals_brute_force(ctx, O, kind):
         for c in range(B):
             want_idx = O.find_nearest_from_cluster(c, cur, row, m)
             assert np.array_equal(got[0][qi, c, :len(want_idx)], want_idx)
+
+
+@pytest.mark.parametrize("N,D,B,m", [(20000, 136, 500, 5), (12000, 140, 64, 15), (9000, 146, 3, 8)])
+def test_fit_two_stage_equals_brute_force_selection(O, N, D, B, m):
+    """Whole fits with the two-stage selection against the same fits with CHB_PREFILTER=0 (brute-force
+    selection kernel) at sizes the oracle cannot replay: many small bins, long lists (m = 15, where
+    the shortlist pool is emptied mid-bin and overflow fallbacks occur), few huge bins."""
+    from chbin_amd import _lib
+    S = 1 if D <= 136 else (5 if D == 140 else 10)
+    X, initial, _ = _synth(N, D, B, S=S, seed=3, sigma=3e-3, mix=0.3, n_seed=3)
+    perms = _perms(initial, 3)
+    a = _lib.Context(0)
+    try:
+        assert a.counter("prefilter_enabled") == 1
+        a.set_samples(X)
+        la, ia, ca = a.fit_cluster(B, initial, perms, m, 3)
+    finally:
+        a.close()
+    b = _brute_ctx()
+    try:
+        assert b.counter("prefilter_enabled") == 0
+        b.set_samples(X)
+        lb, ib, cb = b.fit_cluster(B, initial, perms, m, 3)
+    finally:
+        b.close()
+    assert ia == ib and np.array_equal(ca, cb) and np.array_equal(la, lb)
 
 
 # ------------------------------------------------------------------ clustering-stage driver (8f-1)
