@@ -405,15 +405,15 @@ def test_fit_two_stage_equals_brute_force_selection(O, N, D, B, m):
     perms = _perms(initial, 3)
     a = _lib.Context(0)
     try:
-        assert a.counter("prefilter_enabled") == 1
         a.set_samples(X)
+        assert a.counter("prefilter_enabled") == 1
         la, ia, ca = a.fit_cluster(B, initial, perms, m, 3)
     finally:
         a.close()
     b = _brute_ctx()
     try:
-        assert b.counter("prefilter_enabled") == 0
         b.set_samples(X)
+        assert b.counter("prefilter_enabled") == 0
         lb, ib, cb = b.fit_cluster(B, initial, perms, m, 3)
     finally:
         b.close()
