@@ -151,8 +151,9 @@ int chb_kmer_frequencies(chb_ctx *h, const unsigned char *seq, const int64_t *of
 /* ---- measurement: HIP-event timing of every kernel launch on the context's stream */
 int chb_profile_enable(chb_ctx *h, int on);
 int chb_profile_reset(chb_ctx *h);
-/* kernel: "prefilter" | "rescore" | "topm_fallback" | "topm_base" | "topm_update" | "hull_qp" |
- * "argmin" | "bucket" | "pairwise" */
+/* kernel: "prefilter" | "prefilter_update" | "rescore" | "rescore_update" | "query_norms" |
+ * "topm_fallback" | "topm_base" | "topm_update" | "hull_qp" | "argmin" | "bucket" | "pairwise" |
+ * "kmer_count" */
 int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *launches,
                     double *work_units);
 /* counters of the last chb_fit_cluster call: [0]=batches [1]=rounds [2]=hull distances evaluated

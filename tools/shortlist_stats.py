@@ -1,4 +1,4 @@
-"""Developer probe: shortlist lengths of the bf16 prefilter (base stage, last batch).
+"""Developer probe: shortlist lengths of the fp16 shortlist stage (base stage, last batch).
 Run with CHB_PF_UPDATE=0 so that the update stage does not overwrite the candidate buffers."""
 import os
 import sys
