@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=300)
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="dev: no per-kernel HIP events in the timed steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (dev: gloo)")
     ap.add_argument("--same-gpu", action="store_true", help="dev only: all ranks on cuda:0")
     args = ap.parse_args()
@@ -118,7 +119,7 @@ def main():
     for _ in range(args.warmup):
         labels1 = one_step()
     ctx.profile_reset()
-    ctx.profile_enable(True)
+    ctx.profile_enable(not args.no_kernel_events)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -134,7 +135,7 @@ def main():
     value = qp_per_step * args.steps / dt
 
     prof = {k: ctx.profile_get(k) for k in ("prefilter", "rescore", "prefilter_update", "rescore_update", "query_norms",
-                                            "topm_fallback", "topm_base", "topm_update", "hull_qp", "argmin",
+                                            "topm_fallback", "topm_base", "topm_update", "hull_qp", "slow_path", "argmin",
                                             "bucket")}
     stats = ctx.fit_stats()
 
@@ -181,7 +182,7 @@ def main():
                          "bytes_per_pair": bytes_pair,
                          "note": "gather of the shortlisted rows (fp64, 8*D bytes each), unfused sequential "
                                  "sums; no-reuse model, rows come largely out of L2 / Infinity Cache"})
-        for name in ("prefilter_update", "rescore_update", "query_norms", "topm_fallback", "argmin", "bucket"):
+        for name in ("prefilter_update", "rescore_update", "query_norms", "topm_fallback", "slow_path", "argmin", "bucket"):
             p = prof[name]
             if p["launches"]:
                 kern.append({"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,

@@ -103,7 +103,6 @@ class Context:
         check(lib.chb_create(int(device), C.byref(self._h)))
         self._lib = lib
         self.device = int(device)
-        self._samples_key = None
         self.N = self.D = 0
 
     def close(self):
@@ -131,19 +130,18 @@ class Context:
             raise ValueError("samples must be a 2-D array")
         check(self._lib.chb_set_samples(self._h, X, X.shape[0], X.shape[1]))
         self.N, self.D = X.shape
-        self._samples_key = None
 
     def set_samples_cached(self, X):
-        """Upload only if this is not the array that is already resident."""
-        key = (X.__array_interface__["data"][0], X.shape, X.strides, str(X.dtype))
-        if key != self._samples_key:
-            self.set_samples(X)
-            self._samples_key = key
+        """Kept for the callers' sake; it ALWAYS uploads.  (It used to skip the upload when the
+        array's address / shape / dtype matched the previous call, but the mirror functions hand it
+        `np.ascontiguousarray(...)` temporaries whose address is recycled by the next call, and a
+        caller may also change `samples` in place: both made the GPU work on stale data.  An upload
+        is milliseconds next to a sweep.)"""
+        self.set_samples(X)
 
     def set_samples_device(self, ptr, N, D):
         check(self._lib.chb_set_samples_device(self._h, C.c_void_p(int(ptr)), int(N), int(D)))
         self.N, self.D = int(N), int(D)
-        self._samples_key = None
 
     # ---- entry points
     def pairwise_distance(self, r0=0, r1=None):

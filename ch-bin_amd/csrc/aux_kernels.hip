@@ -63,12 +63,14 @@ __global__ __launch_bounds__(256) void scan_kernel(const int *cnt, int B, int *b
     part[threadIdx.x] = s; ppart[threadIdx.x] = sp;
     __syncthreads();
     if (threadIdx.x == 0) {
+        const int nparts = (B + per - 1) / per;   // (threads beyond own no bin)
         int run = 0, prun = 0;
-        for (int i = 0; i < 256; ++i) {
+        for (int i = 0; i < nparts; ++i) {
             const int v = part[i], pv = ppart[i];
             part[i] = run; ppart[i] = prun;
             run += v; prun += pv;
         }
+        for (int i = nparts; i < 256; ++i) { part[i] = run; ppart[i] = prun; }
     }
     __syncthreads();
     int run = part[threadIdx.x], prun = ppart[threadIdx.x];
@@ -116,11 +118,15 @@ __global__ __launch_bounds__(256) void fill_base_kernel(const int *labels, const
 // LDS cursors.  Entry codes: see chb_internal.h (TopmArgs::memb_code).
 __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev, const int *lab_old, const int *bq,
                                                             int K, int B, int *bin_ptr, int *pad_ptr, int *memb_id,
-                                                            int *memb_code)
+                                                            int *memb_code, int *first_change, int *n_slow)
 {
     extern __shared__ int sh[];   // [B] counts -> cursors, [1024] scan partials x 2
     int *cnt = sh, *part = sh + B, *ppart = part + 1024;
     const int tid = threadIdx.x;
+    if (tid == 0) {   // the round's scalars
+        if (first_change) *first_change = K;
+        if (n_slow) *n_slow = 0;
+    }
     for (int b = tid; b < B; b += 1024) cnt[b] = 0;
     __syncthreads();
     for (int i = tid; i < K; i += 1024) {
@@ -139,12 +145,15 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
     part[tid] = s; ppart[tid] = sp;
     __syncthreads();
     if (tid == 0) {
+        // (threads beyond ceil(B / per) own no bin: the serial part stays as short as the bin count)
+        const int nparts = (B + per - 1) / per;
         int run = 0, prun = 0;
-        for (int i = 0; i < 1024; ++i) {
+        for (int i = 0; i < nparts; ++i) {
             const int v = part[i], pv = ppart[i];
             part[i] = run; ppart[i] = prun;
             run += v; prun += pv;
         }
+        for (int i = nparts; i < 1024; ++i) { part[i] = run; ppart[i] = prun; }
     }
     __syncthreads();
     int run = part[tid], prun = ppart[tid];
@@ -229,6 +238,34 @@ __global__ __launch_bounds__(256) void guess_kernel(const double *list_d, const 
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) {
             const double od = __shfl_xor(best, off, 16);
+            const int oc = __shfl_xor(bc, off, 16);
+            if (oc >= 0 && (od < best || (od == best && (bc < 0 || oc < bc)))) { best = od; bc = oc; }
+        }
+        if (g < 0) g = bc;
+    }
+    if (valid && l16 == 0) lab_prev[pos] = g;
+}
+
+// the same kind of guess from the shortlist stage's bounds near[bin][Kcap] of the m-th nearest distance:
+// the bin whose m-th nearest member is closest
+__global__ __launch_bounds__(256) void guess_near_kernel(const float *near, const int *lab_old, int p0, int K, int B,
+                                                         int Kcap, int *lab_prev)
+{
+    const int l16 = threadIdx.x & 15;
+    const int pos = p0 + blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool valid = pos < K;
+    int g = valid ? lab_old[pos] : 0;
+    if (__ballot(valid && g < 0) != 0ull) {
+        float best = INFINITY;
+        int bc = -1;
+        if (valid && g < 0)
+            for (int c = l16; c < B; c += 16) {
+                const float d = near[(size_t)c * Kcap + pos];
+                if (d < best) { best = d; bc = c; }
+            }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            const float od = __shfl_xor(best, off, 16);
             const int oc = __shfl_xor(bc, off, 16);
             if (oc >= 0 && (od < best || (od == best && (bc < 0 || oc < bc)))) { best = od; bc = oc; }
         }
@@ -360,6 +397,13 @@ void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old,
         hipLaunchKernelGGL(guess_kernel, dim3((p1 - p0 + 15) / 16), dim3(256), 0, s, list_d, list_cnt, lab_old, p0, p1, B, m, Kcap, lab_prev);
 }
 
+void launch_guess_near(const float *near, const int *lab_old, int p0, int p1, int B, int Kcap, int *lab_prev,
+                       hipStream_t s)
+{
+    if (p1 > p0)
+        hipLaunchKernelGGL(guess_near_kernel, dim3((p1 - p0 + 15) / 16), dim3(256), 0, s, near, lab_old, p0, p1, B, Kcap, lab_prev);
+}
+
 void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,
                          hipStream_t s)
 {
@@ -411,11 +455,11 @@ void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cn
 
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
-                         hipStream_t s)
+                         int *first_change, int *n_slow, hipStream_t s)
 {
     (void)cnt; (void)cursor;   // (scratch of the former three-kernel form)
     hipLaunchKernelGGL(bucket_batch_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 2048), s, lab_prev,
-                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code);
+                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow);
 }
 
 void launch_argmin(const double *dist, const int *lab_old, const int *lab_prev, int pos_begin,

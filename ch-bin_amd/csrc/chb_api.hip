@@ -189,9 +189,15 @@ struct chb_ctx {
     DevBuf<double> centers;
     int Dz = 0;
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
-    bool pf_base = true, pf_update = true;   // developer switches (CHB_PF_BASE / CHB_PF_UPDATE)
+    bool pf_base = true, pf_update = true;   // developer switches (CHB_PF_BASE / CHB_PF_UPDATE; -DCHB_DEV_KNOBS builds only)
     DevBuf<int> cand, cand_cnt, flags64, overflow;
     DevBuf<int> active, n_active, act_blk;
+    // fused selection + hull distance (m <= 5): batch-entry candidates of this / the previous round,
+    // the base stage's tau (bound of the m-th nearest distance), the exact path's work list
+    bool fused = false, allow_fused = true;
+    bool lists_valid = false;   // the open batch was started with need_lists (chb_topm_per_bin)
+    DevBuf<int> candu[2], candu_cnt[2], slow, n_slow;
+    DevBuf<float> tau;
     // scratch for the indexed / explicit-point entry points
     DevBuf<int> xq, xhull, xcnt;
     DevBuf<double> xdist, xalpha, xpts;
@@ -291,6 +297,15 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->qn.ensure(K * B * 2));
         HIPCHK(h->pk.ensure((size_t)h->N + 32 * B, B, (size_t)h->Dz));
         HIPCHK(h->pk2.ensure(2 * K + 32 * B, B, (size_t)h->Dz));
+        if (h->fused) {
+            for (int i = 0; i < 2; ++i) {
+                HIPCHK(h->candu[i].ensure(K * B * (size_t)kCandCapU));
+                HIPCHK(h->candu_cnt[i].ensure(K * B));
+            }
+            HIPCHK(h->slow.ensure(K * B));
+            HIPCHK(h->n_slow.ensure(1));
+            HIPCHK(h->tau.ensure(K * B));
+        }
     }
     h->Kcap = Kcap;
     return CHB_OK;
@@ -304,6 +319,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     if (m < 1 || m > CHB_MAX_NEIGHBORS)
         return fail(CHB_EUNSUPPORTED, "num_neighbors must be in [1, 16]");
     h->B = (int)B; h->m = m;
+    h->fused = h->allow_fused && h->use_prefilter && h->shadow_ok && h->pf_base && h->pf_update && fused_supported(m);
     std::vector<int> lab((size_t)h->N);
     for (int64_t i = 0; i < h->N; ++i) {
         const int64_t v = initial[i];
@@ -336,9 +352,12 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     return CHB_OK;
 }
 
-// bq already holds the K sample indices (device)
-int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
+// bq already holds the K sample indices (device).  need_lists: the caller wants the exact base lists
+// L0 (chb_topm_per_bin); the fit loop of the fused path (m <= 5) works on the shortlists directly.
+int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
 {
+    const bool fusedp = h->fused && !need_lists;
+    h->lists_valid = !fusedp;
     h->K = K; h->q_lo = q_lo; h->q_hi = q_hi;
     h->round_in_batch = 0;
     hipStream_t s = h->stream;
@@ -355,7 +374,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
     a.in = Lists{nullptr, nullptr, nullptr};
     a.out = h->L0();
     if (h->use_prefilter && h->pf_base && h->shadow_ok && h->cand.p) {
-        // two-stage exact selection: bf16 matrix-core shortlist, exact fp64 on the shortlist,
+        // two-stage exact selection: fp16 matrix-core shortlist, exact fp64 on the shortlist,
         // brute force only for (query tile, bin) pairs whose shortlist overflowed
         const int nq64 = (q_hi - q_lo + kQTile - 1) / kQTile;
         (void)nq64;   // (flags64 is all zero here: launch_topm_flagged clears what it serves)
@@ -377,18 +396,24 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi)
         pa.bq = h->bq.p; pa.pos_begin = q_lo; pa.pos_end = q_hi;
         pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p; pa.update = false;
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
-        pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
+        pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.cand_cap = kCandCap; pa.overflow = h->overflow.p;
+        if (fusedp) pa.tau_out = h->tau.p;
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
             launch_shortlist(pa, h->flags64.p, s);
         }
-        RescoreArgs ra{};
-        ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = q_lo; ra.pos_end = q_hi;
-        ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
-        ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.out = h->L0();
-        {
+        if (!fusedp) {
+            RescoreArgs ra{};
+            ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = q_lo; ra.pos_end = q_hi;
+            ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
+            ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.cand_cap = kCandCap; ra.out = h->L0();
             Timed t(h, "rescore", (double)(q_hi - q_lo) * h->B);
             launch_rescore(ra, s);
+        } else {
+            // overflowed (query tile, bin) pairs: the brute-force kernel's exact top-m becomes the shortlist
+            a.out = Lists{nullptr, nullptr, nullptr};
+            a.cand_out = h->cand.p; a.cand_cnt_out = h->cand_cnt.p; a.cand_cap = kCandCap;
+            a.tau_out = h->tau.p; a.S = h->shadow_scale;
         }
         {
             Timed t(h, "topm_fallback", 0.0);
@@ -408,20 +433,82 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
 {
     hipStream_t s = h->stream;
     const int lo = std::max(active, h->q_lo), hi = h->q_hi;
-    launch_fill_i32(h->first_change.p, h->K, 1, s);
+    if (hi <= lo) launch_fill_i32(h->first_change.p, h->K, 1, s);
+    const bool fusedp = h->fused && h->lists_valid == false;
     if (hi > lo) {
         {
             Timed t(h, "bucket", (double)h->K);
             launch_bucket_batch(h->lab_prev.p, h->lab_old.p, h->bq.p, h->K, h->B, h->cnt2.p,
-                                h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, h->pk2.pad_ptr.p, s);
+                                h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, h->pk2.pad_ptr.p,
+                                h->first_change.p, fusedp ? h->n_slow.p : nullptr, s);
         }
         TopmArgs a{};
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = lo; a.pos_end = hi;
         a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;
         a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
         a.in = h->L0(); a.out = h->Lcur();
+        if (fusedp) {
+            // ---- fused path: shortlist of the batch's own entries against the base stage's tau, then
+            // selection + hull distance straight from the two shortlists
+            const int cur = h->round_in_batch & 1;
+            launch_pack_centered(h->X.p, h->D, h->Dp, h->memb2_id.p, h->memb2_code.p, h->bin_ptr2.p, h->B, 2 * h->K,
+                                 h->centers.p, h->mu_g.p, h->shadow_scale, h->Dz, h->pk2.view(), s);
+            ShortlistArgs pa{};
+            pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
+            pa.qn = reinterpret_cast<const float2 *>(h->qn.p);   // built at batch start
+            pa.P = h->pk2.view(); pa.Dz = h->Dz; pa.S = h->shadow_scale;
+            pa.bq = h->bq.p; pa.pos_begin = lo; pa.pos_end = hi;
+            pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.update = true;
+            pa.tau_in = h->tau.p;
+            pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
+            pa.cand = h->candu[cur].p; pa.cand_cnt = h->candu_cnt[cur].p; pa.cand_cap = kCandCapU;
+            pa.overflow = h->overflow.p;
+            {
+                Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
+                launch_shortlist(pa, h->flags64.p, s);
+            }
+            {
+                // overflowed pairs: exact top-m among the (eligible) batch entries as their shortlist
+                a.in = Lists{nullptr, nullptr, nullptr};
+                a.out = Lists{nullptr, nullptr, nullptr};
+                a.cand_out = h->candu[cur].p; a.cand_cnt_out = h->candu_cnt[cur].p; a.cand_cap = kCandCapU;
+                Timed t(h, "topm_fallback", 0.0);
+                launch_topm_flagged(a, h->flags64.p, s);
+            }
+            FusedArgs f{};
+            f.X = h->X.p; f.D = h->D; f.Dp = h->Dp; f.bq = h->bq.p; f.pos_begin = lo; f.pos_end = hi;
+            f.B = h->B; f.m = h->m; f.Kcap = h->Kcap;
+            f.cand = h->cand.p; f.cand_cnt = h->cand_cnt.p;
+            f.candu = h->candu[cur].p; f.candu_cnt = h->candu_cnt[cur].p;
+            if (h->round_in_batch > 0) { f.candp = h->candu[cur ^ 1].p; f.candp_cnt = h->candu_cnt[cur ^ 1].p; }
+            f.dist = h->dist.p; f.metric = h->metric; f.slow = h->slow.p; f.n_slow = h->n_slow.p;
+            {
+                Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
+                launch_hull_select_qp(f, s);
+            }
+            {
+                // the exact path for what the fused kernel left: cdist-rounded distances on both shortlists,
+                // (distance, index) order, then the list-based hull kernel
+                Timed t(h, "slow_path", 0.0);
+                RescoreArgs ra{};
+                ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = lo; ra.pos_end = hi;
+                ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
+                ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.cand_cap = kCandCap;
+                ra.cand2 = h->candu[cur].p; ra.cand2_cnt = h->candu_cnt[cur].p; ra.cand2_cap = kCandCapU;
+                ra.active = h->slow.p; ra.n_active = h->n_slow.p;
+                ra.out = h->L1();
+                launch_rescore(ra, s);
+                QpArgs q{};
+                q.X = h->X.p; q.D = h->D; q.Dp = h->Dp; q.bq = h->bq.p; q.pos_begin = lo; q.pos_end = hi;
+                q.B = h->B; q.m = h->m; q.Kcap = h->Kcap; q.lists = h->L1(); q.dist = h->dist.p;
+                q.prev = Lists{nullptr, nullptr, nullptr};
+                q.metric = h->metric;
+                q.active = h->slow.p; q.n_active = h->n_slow.p;
+                launch_hull_qp(q, s);
+            }
+        } else {
         if (h->use_prefilter && h->pf_update && h->shadow_ok && h->cand.p) {
-            // batch members that can displace an entry of the base list: bf16 shortlist against
+            // batch members that can displace an entry of the base list: fp16 shortlist against
             // the exact m-th distance, exact rescoring seeded with the base list
             // (fit rounds only produce the "earlier" / "later" eligibility codes, which have the affine
             // form the shortlist kernel evaluates; chb_topm_per_bin's "not equal" code stays on launch_topm)
@@ -435,7 +522,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.update = true;
             pa.seed = h->L0();
             pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
-            pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.overflow = h->overflow.p;
+            pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.cand_cap = kCandCap; pa.overflow = h->overflow.p;
             {
                 Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
                 launch_shortlist(pa, h->flags64.p, s);
@@ -446,7 +533,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             RescoreArgs ra{};
             ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = lo; ra.pos_end = hi;
             ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
-            ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p;
+            ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.cand_cap = kCandCap;
             ra.active = h->active.p; ra.n_active = h->n_active.p;
             ra.in = h->L0(); ra.out = h->Lcur();
             // pairs without any candidate keep the base list
@@ -479,6 +566,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
             launch_hull_qp(q, s);
         }
+        }   // list-based paths
         {
             Timed t(h, "argmin", (double)(hi - lo));
             launch_argmin(h->dist.p, h->lab_old.p, h->lab_prev.p, lo, hi, h->B, h->lab_new.p,
@@ -544,8 +632,13 @@ int chb_create(int device_id, chb_ctx **out)
     h->dev = device_id;
     if (const char *e = getenv("CHB_PREFILTER")) h->use_prefilter = atoi(e) != 0;
     if (const char *e = getenv("CHB_FORCE_GATHER")) h->force_gather = atoi(e) != 0;
+    // CHB_FUSED=0: m <= 5 also takes the list-based path (exact rescoring of every shortlist, then the hull
+    // kernel); like CHB_PREFILTER=0 a switch to the slower, independent formulation for the tests' A/B checks
+    if (const char *e = getenv("CHB_FUSED")) h->allow_fused = atoi(e) != 0;
+#ifdef CHB_DEV_KNOBS   // developer builds only (tools/): the product library reads no tuning knob
     if (const char *e = getenv("CHB_PF_BASE")) h->pf_base = atoi(e) != 0;
     if (const char *e = getenv("CHB_PF_UPDATE")) h->pf_update = atoi(e) != 0;
+#endif
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
@@ -570,6 +663,8 @@ int chb_destroy(chb_ctx *h)
     h->colsum_part.release(); h->rmax.release(); h->pk.release(); h->pk2.release(); h->qn.release();
     h->centers.release();
     h->active.release(); h->n_active.release(); h->act_blk.release();
+    for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
+    h->slow.release(); h->n_slow.release(); h->tau.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
     return CHB_OK;
@@ -683,7 +778,7 @@ int chb_batch_begin(chb_ctx *h, const int64_t *perm_slice, int64_t K, int64_t q_
     std::vector<int> v = to_i32(perm_slice, (size_t)K);
     HIPCHK(hipMemcpyAsync(h->bq.p, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return batch_begin_dev(h, (int)K, (int)q_lo, (int)q_hi);
+    return batch_begin_dev(h, (int)K, (int)q_lo, (int)q_hi, false);
 }
 
 int chb_batch_round(chb_ctx *h, const int64_t *lab_prev, int64_t active, int64_t *lab_new,
@@ -718,7 +813,8 @@ int chb_batch_guess(chb_ctx *h, int64_t *guess)
     HIPCHK(hipSetDevice(h->dev));
     const int lo = h->q_lo, hi = h->q_hi;
     if (hi <= lo) return CHB_OK;
-    launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, lo, hi, h->B, h->m, h->Kcap, h->lab_prev.p, h->stream);
+    if (h->fused && !h->lists_valid) launch_guess_near(h->tau.p, h->lab_old.p, lo, hi, h->B, h->Kcap, h->lab_prev.p, h->stream);
+    else launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, lo, hi, h->B, h->m, h->Kcap, h->lab_prev.p, h->stream);
     HIPCHK(hipGetLastError());
     std::vector<int> g((size_t)(hi - lo));
     HIPCHK(hipMemcpyAsync(g.data(), h->lab_prev.p + lo, sizeof(int) * (hi - lo), hipMemcpyDeviceToHost, h->stream));
@@ -799,6 +895,7 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
             int64_t members = (it == 0) ? assigned0 + t0 : N;
             int K = (int)std::min<int64_t>(Kmax, n_move - t0);
             if (members < K) K = (int)std::max<int64_t>(std::min<int64_t>(64, n_move - t0), members);
+            K = std::min(K, Kmax);   // (the floor of 64 above must not exceed a caller's smaller batch: buffers hold Kmax)
             HIPCHK(hipMemcpyAsync(h->bq.p, h->perm.p + t0, sizeof(int) * K, hipMemcpyDeviceToDevice, s));
             h->hint_base_members = (double)((it == 0) ? assigned0 + t0 : labelled - K);
             h->hint_batch_entries = (double)((it == 0) ? K : 2 * K);
@@ -808,11 +905,12 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
             const bool xchg = h->comm != nullptr && (world > 1 || h->force_gather);
             const int C = (K + world - 1) / world;
             const int q_lo = std::min(K, h->rank * C), q_hi = std::min(K, q_lo + C);
-            rc = batch_begin_dev(h, K, q_lo, q_hi);
+            rc = batch_begin_dev(h, K, q_lo, q_hi, false);
             if (rc) return rc;
             // starting labels of the rounds: last sweep's label, or for still-unlabelled contigs
             // (sweep 1) the bin of the nearest outside member
-            launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, q_lo, q_hi, h->B, h->m, h->Kcap, h->lab_prev.p, s);
+            if (h->fused && !h->lists_valid) launch_guess_near(h->tau.p, h->lab_old.p, q_lo, q_hi, h->B, h->Kcap, h->lab_prev.p, s);
+            else launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, q_lo, q_hi, h->B, h->m, h->Kcap, h->lab_prev.p, s);
             if (xchg)
                 NCCLCHK(rccl()->AllGather(h->lab_prev.p + h->rank * C, h->lab_prev.p, (size_t)C, ncclInt32, h->comm, s));
             int active = 0;
@@ -891,11 +989,11 @@ int chb_topm_per_bin(chb_ctx *h, const int64_t *labels, int64_t B, int m, const 
         while (t0 + K < Q && K < Kmax && seen.insert(query_idx[t0 + K]).second) ++K;
         std::vector<int> v = to_i32(query_idx + t0, (size_t)K);
         HIPCHK(hipMemcpyAsync(h->bq.p, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, s));
-        rc = batch_begin_dev(h, K, 0, K);
+        rc = batch_begin_dev(h, K, 0, K, true);
         if (rc) return rc;
         // every other query of the chunk is an ordinary member: code "pos != i"
         launch_bucket_batch(h->lab_old.p, nullptr, h->bq.p, K, h->B, h->cnt2.p, h->bin_ptr2.p,
-                            h->cursor2.p, h->memb2_id.p, h->memb2_code.p, nullptr, s);
+                            h->cursor2.p, h->memb2_id.p, h->memb2_code.p, nullptr, nullptr, nullptr, s);
         TopmArgs a{};
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = 0; a.pos_end = K;
         a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;
@@ -1214,6 +1312,29 @@ int chb_counter(chb_ctx *h, const char *name, int64_t *out)
         }
         return CHB_OK;
     }
+    if (!strncmp(name, "shortlist_le", 12)) {   // "shortlist_le<N>_last_batch": pairs of the last batch with <= N candidates
+        const int lim = atoi(name + 12);
+        if (h->cand_cnt.p && h->K > 0) {
+            std::vector<int> v((size_t)h->Kcap * h->B);
+            HIPCHK(hipMemcpyAsync(v.data(), h->cand_cnt.p, sizeof(int) * v.size(), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            int64_t n = 0;
+            for (int c = 0; c < h->B; ++c)
+                for (int i = 0; i < h->K; ++i) n += v[(size_t)c * h->Kcap + i] <= lim;
+            *out = n;
+        }
+        return CHB_OK;
+    }
+    if (!strcmp(name, "slow_pairs_last_round")) {   // pairs the fused kernel left to the exact path
+        if (h->n_slow.p && h->fused) {
+            int v = 0;
+            HIPCHK(hipMemcpyAsync(&v, h->n_slow.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            *out = v;
+        }
+        return CHB_OK;
+    }
+    if (!strcmp(name, "fused_enabled")) { *out = h->fused ? 1 : 0; return CHB_OK; }
     if (!strcmp(name, "last_batch_k")) { *out = h->K; return CHB_OK; }
     if (!strcmp(name, "prefilter_enabled")) { *out = (h->use_prefilter && h->shadow_ok) ? 1 : 0; return CHB_OK; }
     return fail(CHB_EINVAL, "unknown counter");

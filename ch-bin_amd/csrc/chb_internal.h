@@ -32,7 +32,12 @@ struct TopmArgs {
                            // code <= -(1<<30): eligible iff query pos != -(1<<30)-code
     int B, m, Kcap;
     Lists in;            // in.d == nullptr: start from empty lists
-    Lists out;
+    Lists out;           // out.d == nullptr: no list output
+    // optional (fused selection path): the exact top-m as a candidate list, [slot][cand_cap] / [slot]
+    int *cand_out = nullptr, *cand_cnt_out = nullptr;
+    int cand_cap = 0;
+    float *tau_out = nullptr;    // [slot] exact m-th distance x S, rounded up (+inf: fewer than m members)
+    double S = 1.0;
 };
 
 void launch_topm(const TopmArgs &a, hipStream_t s);
@@ -41,6 +46,7 @@ void launch_topm_flagged(const TopmArgs &a, int *flags64, hipStream_t s);   // (
 
 // ---- two-stage exact selection (prefilter_kernels.hip + rescore in topm_kernels.hip)
 constexpr int kCandCap = 128;   // shortlist capacity per (bin, batch position)
+constexpr int kCandCapU = 32;   // same for the batch's own entries in the fused selection path (m <= 8)
 
 // fp16 shadow data of the shortlist stage (prefilter_kernels.hip explains the quantities).
 // Members of all bins, grouped by bin, every bin padded to a multiple of 32 rows:
@@ -94,8 +100,13 @@ struct ShortlistArgs {
     bool update;               // update mode: the batch's own entries, fixed tau from `seed`
     Lists seed;
     int B, m, Kcap;
-    int *cand;       // [B][Kcap][kCandCap] sample indices
+    int *cand;       // [B][Kcap][cand_cap] sample indices
     int *cand_cnt;   // [B][Kcap]
+    int cand_cap;    // kCandCap or kCandCapU
+    // base mode, optional output per (bin, position): an upper bound of the m-th smallest distance in
+    // shadow units (+inf: fewer than m members)
+    float *tau_out;
+    const float *tau_in;   // update mode: tau per (bin, position) instead of `seed` (nullptr: use seed)
     int *overflow;   // [1] number of (bin, position) pairs whose shortlist overflowed
     float gamma;         // accumulation error factor g (set by launch_shortlist)
     int tile_best_min;   // bins with at least this many tiles learn tau from per-tile bests (ditto)
@@ -111,6 +122,10 @@ struct RescoreArgs {
     int B, m, Kcap;
     const int *cand;
     const int *cand_cnt;
+    int cand_cap;         // row length of cand
+    const int *cand2;     // optional second candidate source per pair (the batch's own entries) ...
+    const int *cand2_cnt;
+    int cand2_cap;
     const int *active;    // non-null: only these pairs (index = (pos - pos_begin) * B + bin) ...
     const int *n_active;  // ... *n_active of them; everything else in `out` must already hold `in`
     Lists in;    // in.d == nullptr: start from empty lists
@@ -132,8 +147,35 @@ struct QpArgs {
                    // vertex lists keep their distance
     double *dist;  // [Kcap][B]
     int metric;    // 0 convex hull (hull_distance.py:7-35), 1 affine hull (hull_distance.py:38-87)
+    const int *active;    // non-null: only these pairs (index = (pos - pos_begin) * B + bin), ...
+    const int *n_active;  // ... *n_active of them (device side); `prev` is then ignored
 };
 void launch_hull_qp(const QpArgs &a, hipStream_t s);
+
+// Fused selection + hull distance (m <= 8): per (position, bin) pair the candidates of the shortlist
+// stage (base members + this round's batch entries) are gathered ONCE; their full shifted Gram gives
+// both the squared distances (diagonal) that pick the m nearest and the m x m Gram of the hull QP.
+// Pairs with more than the kernel's candidate capacity, or whose m-th / (m+1)-th candidates are too
+// close to be ordered without cdist's exact rounding, are appended to `slow` for the exact path
+// (rescore_kernel + hull_qp_kernel on that list).
+struct FusedArgs {
+    const double *X;
+    int D, Dp;
+    const int *bq;
+    int pos_begin, pos_end;
+    int B, m, Kcap;
+    const int *cand;  const int *cand_cnt;    // base candidates [slot][kCandCap]
+    const int *candu; const int *candu_cnt;   // this round's batch-entry candidates [slot][kCandCapU]
+    const int *candp; const int *candp_cnt;   // previous round's (nullptr: none): a pair whose batch-entry
+                                              // candidate set did not change keeps its distance
+    double *dist;     // [Kcap][B]
+    int metric;
+    int *slow;        // pair indices (pos - pos_begin) * B + bin
+    int *n_slow;      // zeroed by the caller
+};
+// false: m not supported by the fused kernel (caller uses the list-based path)
+bool fused_supported(int m);
+void launch_hull_select_qp(const FusedArgs &a, hipStream_t s);
 
 // explicit problems: query sample q[p], hull_idx[p][m_max] compacted, hull_cnt[p] vertices
 void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,
@@ -150,15 +192,20 @@ void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, in
 void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
                         int *cursor, int *memb_id, int *pad_ptr, hipStream_t s);
 // CSR of the batch's own members: earlier positions under lab_prev, later positions under lab_old
+// (also starts the round's scalars: *first_change = K, *n_slow = 0 where the pointers are non-null)
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
-                         hipStream_t s);
+                         int *first_change, int *n_slow, hipStream_t s);
 // first position in [p0,K) whose label changed (atomicMin into *first_change)
 void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,
                          hipStream_t s);
 // round-0 label guess: lab_old where >= 0, else bin of the nearest outside member
 void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old, int p0, int p1,
                   int B, int m, int Kcap, int *lab_prev, hipStream_t s);
+// same from the shortlist stage's bounds tau[bin][Kcap] of the m-th nearest distance (+inf: fewer than m
+// members): the bin with the smallest one
+void launch_guess_near(const float *tau, const int *lab_old, int p0, int p1, int B, int Kcap, int *lab_prev,
+                       hipStream_t s);
 // active[] = the pairs (pos - pos_begin) * B + bin whose cand_cnt is positive, *n_active their number
 // (blk_cnt: scratch, one int per 4096 pairs)
 void launch_compact_active(const int *cand_cnt, int pos_begin, int pos_end, int B, int Kcap, int *blk_cnt,

@@ -470,6 +470,7 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *sPool = reinterpret_cast<unsigned *>(smem + NBUF * BUFB);   // [4][kPoolW]
     int *sCnt = reinterpret_cast<int *>(sPool + 4 * kPoolW);              // [kPfQ]
+    float *sTau = reinterpret_cast<float *>(sCnt + kPfQ);                 // [kPfQ] tau of the bin (parked: no register)
 
     // consecutive workgroups alternate over the 8 XCDs: give each XCD a contiguous range of work
     // items (bins-major), so that the member tiles of a bin stay in one L2
@@ -591,8 +592,8 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
             const unsigned en = sPool[w * kPoolW + i];                                             \
             const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));                     \
             const int off = atomicAdd(&sCnt[32 * w + qc], 1);                                      \
-            if (off < kCandCap)                                                                    \
-                a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * kCandCap + off] = a.memb_id[mb_ + e]; \
+            if (off < a.cand_cap)                                                                  \
+                a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * a.cand_cap + off] = a.memb_id[mb_ + e]; \
         }                                                                                          \
     }
     int cbuf = 0, n_consumed = 0;
@@ -616,11 +617,16 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
         float thr_s = -INFINITY;
         // sweep 1 admits a member iff its accumulator >= thr2  (t <= C2, t = -2 acc)
         float thr2 = qvalid ? -FLT_MAX : INFINITY;
-        if (UPD && qvalid && a.seed.cnt[slot] >= m) {
-            // exact m-th distance so far, in shadow units
-            const float tau = round_up_f32(a.seed.d[slot * m + m - 1] * a.S) * (1.0f + kSlack);
-            const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
-            thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
+        if (UPD && qvalid) {
+            // the m-th distance among the base members in shadow units: exact from the list `seed`, or
+            // the upper bound the base stage left in tau_in (+inf: fewer than m base members)
+            float tau = INFINITY;
+            if (a.tau_in != nullptr) tau = a.tau_in[slot];
+            else if (a.seed.cnt[slot] >= m) tau = round_up_f32(a.seed.d[slot * m + m - 1] * a.S) * (1.0f + kSlack);
+            if (tau < INFINITY) {
+                const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+                thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
+            }
         }
         if (h == 0) sCnt[32 * w + col] = 0;
         const bool tile_best = ntile >= a.tile_best_min;
@@ -639,13 +645,17 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
                     list_insert_desc<ML>(mg, i >= ML - m ? o : -INFINITY);   // (not the pinned slots twice)
                 }
                 const float ms = mg[ML - 1];
+                float tau = INFINITY;
                 if (qvalid && ms > -INFINITY) {
                     // tau = m-th smallest upper bound; at least m members are provably within it
                     const float thr = -2.0f * ms;
-                    const float tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
+                    tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
                     const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
                     thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
                 }
+                // for the fused selection path: tau bounds the m-th distance among these members -- the update
+                // stage's threshold and (smallest over the bins) the label guess
+                if (h == 0) sTau[32 * w + col] = tau;
             }
             for (int ct = 0; ct < ntile; ++ct) {
                 wait_vmcnt(n_issued - n_consumed > 1 ? n_w : 0);   // my pieces of this tile have landed
@@ -770,8 +780,9 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
         if (qvalid && h == 0) {
-            a.cand_cnt[slot] = ccount < kCandCap ? ccount : kCandCap;
-            if (ccount > kCandCap || wcnt > kPoolW) {
+            a.cand_cnt[slot] = ccount < a.cand_cap ? ccount : a.cand_cap;
+            if (!UPD && a.tau_out != nullptr) a.tau_out[slot] = sTau[32 * w + col];
+            if (ccount > a.cand_cap || wcnt > kPoolW) {
                 atomicAdd(a.overflow, 1);
                 flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
             }
@@ -784,7 +795,7 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
 
 static size_t shortlist_lds_bytes(int ks, int ml)
 {
-    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)4 * shortlist_pool_entries(ml) * 4 + kPfQ * 4;
+    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)4 * shortlist_pool_entries(ml) * 4 + 2 * kPfQ * 4;
 }
 
 template <int ML, bool UPD>
@@ -794,11 +805,13 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
     const int nqt = (nq + kPfQ - 1) / kPfQ;
     const int nqt64 = (nq + kQTile - 1) / kQTile;
     // bins per workgroup: long tile streams per workgroup, but enough workgroups for the 256 CUs x 4
-    static int env_bpw = -2;
-    if (env_bpw == -2) { const char *e = getenv("CHB_SL_BPW"); env_bpw = e ? atoi(e) : 0; }
     const long long units = (long long)nqt * a.B;
     int bpw = (int)std::max<long long>(1, units / (UPD ? 1024 : 2048));
+#ifdef CHB_DEV_KNOBS
+    static int env_bpw = -2;
+    if (env_bpw == -2) { const char *e = getenv("CHB_SL_BPW"); env_bpw = e ? atoi(e) : 0; }
     if (env_bpw > 0) bpw = env_bpw;
+#endif
     bpw = std::min(bpw, a.B);
     const int nchunk = (a.B + bpw - 1) / bpw;
     const int total = nqt * nchunk;
@@ -885,12 +898,17 @@ void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_b
 void launch_shortlist(const ShortlistArgs &a_, int *flags64, hipStream_t s)
 {
     ShortlistArgs a = a_;
+    // The accumulation-error factor is part of the proof that the shortlist contains the exact
+    // top-m: the product library takes it from the constant only.
+    a.gamma = kGamma; a.tile_best_min = 16;
+#ifdef CHB_DEV_KNOBS   // developer builds (tools/): never below kGamma
     {
         static float g = -1.f; static int tb = -1;
-        if (g < 0.f) { const char *e = getenv("CHB_SL_GAMMA"); g = e ? (float)atof(e) : kGamma; }
+        if (g < 0.f) { const char *e = getenv("CHB_SL_GAMMA"); g = e ? std::max((float)atof(e), kGamma) : kGamma; }
         if (tb < 0) { const char *e = getenv("CHB_SL_TILEBEST"); tb = e ? atoi(e) : 16; }
         a.gamma = g; a.tile_best_min = tb;
     }
+#endif
     const int nq = a.pos_end - a.pos_begin;
     if (nq <= 0 || a.B <= 0) return;
     if (a.update) {

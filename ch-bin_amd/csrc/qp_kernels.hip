@@ -6,21 +6,23 @@
 //
 // The QP min ||sum_a alpha_a x_a - x||^2 over the simplex is the minimum-norm point of
 // conv{y_a = x_a - x}.  It is solved in Gram space:
-//   phase 1 (fp64 matrix core): every lane streams one hull-vertex row, forms y_a = x_a - x, and
-//     v_mfma_f64_16x16x4_f64 accumulates the shifted Gram Q_ab = <y_a, y_b> of 16/M problems per
-//     tile (no cross-lane reduction); the diagonal blocks go to LDS.  ~64 problems per wavefront.
-//   phase 2 (one problem per lane): Wolfe's minimum-norm-point active-set method on the m x m Gram
-//     held in registers (fixed-size, mask-driven, fully unrolled so nothing is dynamically
-//     indexed); affine sub-problems by LDL^T of the lifted Gram Q_SS + s*11^T, which is positive
-//     definite exactly when the support is affinely independent -- so duplicate / collinear
-//     vertices (singular 2XX^T, the case the reference repairs with nearest-PD jitter and a cvxopt
-//     fallback) need no special handling.
+//   phase 1: the shifted Gram Q_ab = <y_a, y_b>.  m <= 8: 16 lanes per problem, fp64 vector FMAs over
+//     interleaved feature pairs, one reduce-scatter (hull_qp_kernel).  m > 8: one
+//     v_mfma_f64_16x16x4_f64 tile per problem (hull_qp16_kernel).
+//   phase 2: Wolfe's minimum-norm-point active-set method.  m <= 8: one problem per lane on the m x m
+//     Gram held in registers (fixed-size, mask-driven, fully unrolled so nothing is dynamically
+//     indexed); m > 8: one problem per 16 lanes.  Affine sub-problems by LDL^T (or an updated inverse)
+//     of the lifted Gram Q_SS + s*11^T, which is positive definite exactly when the support is
+//     affinely independent -- so duplicate / collinear vertices (singular 2XX^T, the case the
+//     reference repairs with nearest-PD jitter and a cvxopt fallback) need no special handling.
 //   distance = sqrt(alpha^T Q alpha).
 // The result is the same projection distance the reference's QP defines (unique even when alpha
 // is not); agreement with the CPU oracle's Goldfarb-Idnani restatement is ~1e-13 relative.
 #include "chb_internal.h"
 
 #include <math.h>
+
+#include <algorithm>
 
 #ifndef CHB_QP_UNROLL
 #define CHB_QP_UNROLL 1
@@ -234,16 +236,6 @@ __device__ __forceinline__ double affine_min_norm(const double (&Q)[Sym<M>::NP],
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
-// INDEXED = false: problems are (batch position, bin) pairs whose vertices come from the top-m
-// lists.  INDEXED = true: explicit (query sample, compacted vertex index list, count) problems.
-//
-// Phase 1 maps the shifted Gram onto the fp64 matrix core: v_mfma_f64_16x16x4_f64 computes
-// D = A(16x4) * B(4x16) + C with lane l supplying A[l&15][l>>4] and B[l>>4][l&15] -- for a Gram
-// A = Y and B = Y^T are the SAME register.  The 16 rows of a tile are the vertices of 16/M
-// consecutive problems (3 problems of 5 vertices at the default AlgoNumNeighbors); the diagonal
-// M x M blocks of the 16x16 product are their Gram matrices, and the k-reduction over the feature
-// dimension happens inside the MFMA accumulator: no cross-lane reduction at all.  Each lane streams
-// ONE vertex row (every 4th feature), 8 loads in flight per operand.
 // Sum v[e] over the 16 lanes of a group and leave entry e = l16 on lane l16: a reduce-scatter in
 // four halving steps (15 exchanges instead of the 64 of sixteen butterfly reductions).
 __device__ __forceinline__ double reduce_scatter16(const double (&v)[16], int l16)
@@ -259,27 +251,27 @@ __device__ __forceinline__ double reduce_scatter16(const double (&v)[16], int l1
     return (b1 ? t2[1] : t2[0]) + __shfl_xor(b1 ? t2[0] : t2[1], 1, 64);
 }
 
+// INDEXED = false: problems are (batch position, bin) pairs whose vertices come from the top-m
+// lists.  INDEXED = true: explicit (query sample, compacted vertex index list, count) problems.
 template <int M, int WAVES, bool INDEXED>
 __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(QpArgs a, int nprob, const int *xq,
                                                               const int *xhull, const int *xn,
                                                               int xm, double *xdist, double *xalpha)
 {
     constexpr int NP = Sym<M>::NP;
-    constexpr bool VGRAM = M <= 8;   // Gram by vector FMAs (16 lanes per problem) instead of the matrix core
-    constexpr int PPT = 16 / M;    // problems per MFMA tile
-    constexpr int NT = 64 / PPT;   // tiles per wavefront
-    constexpr int PPW = VGRAM ? 64 : PPT * NT;  // problems per wavefront (one per lane in phase 2)
+    static_assert(M <= 8, "m > 8 runs on hull_qp16_kernel");
+    constexpr int PPW = 64;        // problems per wavefront (one per lane in phase 2)
     __shared__ double sQ[WAVES][NP][64];
     __shared__ int sN[WAVES][64];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int g0 = (blockIdx.x * WAVES + w) * PPW;
-    if (g0 >= nprob) return;
     const int m = INDEXED ? xm : a.m;
-    const int row = lane & 15, kq = lane >> 4;
-    const int rp = row / M, rv = row - rp * M;
+    // active mode: the problems are the listed pairs (device-side count), walked grid-stride
+    const int *act = INDEXED ? nullptr : a.active;
+    if (act != nullptr) nprob = *a.n_active;
 
-    if constexpr (VGRAM) {
+    for (int g0 = (blockIdx.x * WAVES + w) * PPW; g0 < nprob; g0 += (int)gridDim.x * WAVES * PPW) {
+    {
         // 16 lanes per problem, lane l16 over the features k = l16 (mod 16): every row is read in
         // full 128-byte lines, each lane accumulates all M (M + 1) / 2 products of its features, and
         // a reduce-scatter leaves one finished Gram entry per lane.  For M <= 8 this beats the
@@ -297,7 +289,8 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
                     n = xn[g];
                     if (l16 < n) idm = xhull[(size_t)g * m + l16];
                 } else {
-                    const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+                    const int pr = act ? act[g] : g;
+                    const int pos = a.pos_begin + pr / a.B, c = pr - (pr / a.B) * a.B;
                     qid = a.bq[pos];
                     slot = (size_t)c * a.Kcap + pos;
                     n = a.lists.cnt[slot];
@@ -305,7 +298,7 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
                 }
             }
             bool changed = valid;
-            if (!INDEXED && a.prev.idx != nullptr && valid)
+            if (!INDEXED && a.prev.idx != nullptr && act == nullptr && valid)
                 changed = a.prev.cnt[slot] != n || (l16 < n && a.prev.idx[slot * m + l16] != idm);
             const bool doit = ((__ballot(changed) >> (16 * grp)) & 0xFFFFull) != 0ull;
             const double *vrow[M];
@@ -367,85 +360,17 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
             }
             if (l16 == 0) sN[w][pl] = n;
         }
-    } else
-    for (int t = 0; t < NT; ++t) {
-        const int gt = g0 + t * PPT;
-        if (gt >= nprob) break;
-        const int g = gt + rp;
-        const bool valid = rp < PPT && g < nprob;
-        int n = 0, id = 0, qid = 0;
-        if (valid) {
-            if (INDEXED) {
-                qid = xq[g];
-                n = xn[g];
-                if (rv < n) id = xhull[(size_t)g * m + rv];
-            } else {
-                const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
-                qid = a.bq[pos];
-                const size_t slot = (size_t)c * a.Kcap + pos;
-                n = a.lists.cnt[slot];
-                if (rv < n) id = a.lists.idx[slot * m + rv];
-            }
-        }
-        const bool live = valid && rv < n;
-        if (!INDEXED && a.prev.idx != nullptr) {
-            // skip the tile when every one of its problems has the vertex list of the previous round
-            bool changed = false;
-            if (valid) {
-                const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
-                const size_t slot = (size_t)c * a.Kcap + pos;
-                changed = a.prev.cnt[slot] != n || (rv < n && a.prev.idx[slot * m + rv] != id);
-            }
-            if (!__any(changed)) {
-                if (valid && rv == 0) sN[w][t * PPT + rp] = -1;   // keep the stored distance
-                continue;
-            }
-        }
-        // The Gram sum over features is order-free, so feature k is assigned to MFMA step / k-slot
-        // as k = 16 t + 4 kq + s: every lane then reads 32 contiguous bytes per 4 steps and the 4
-        // lanes of a row cover one full 128-byte line.
-        const double *vptr = a.X + (size_t)id * a.Dp + 4 * kq;
-        const double *qptr = a.X + (size_t)qid * a.Dp + 4 * kq;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < a.Dp; k0 += 32) {
-            double2 v[4], x[4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int kk = k0 + 16 * t + 4 * kq;
-                const bool in = live && kk < a.Dp;   // Dp % 8 == 0 and kk % 4 == 0: all 4 in range
-                v[2 * t] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t) : double2{0.0, 0.0};
-                v[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
-                x[2 * t] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t) : double2{0.0, 0.0};
-                x[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double y0 = v[s].x - x[s].x;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, acc, 0, 0, 0);
-                const double y1 = v[s].y - x[s].y;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, acc, 0, 0, 0);
-            }
-        }
-        // lane holds D[kq + 4r][row]; keep the lower triangles of the diagonal blocks
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = kq + 4 * r;
-            const int pi = i / M, vi = i - pi * M;
-            if (pi == rp && pi < PPT && vi >= rv && gt + pi < nprob)
-                sQ[w][Sym<M>::at(vi, rv)][t * PPT + pi] = acc[r];
-        }
-        if (valid && rv == 0) sN[w][t * PPT + rp] = n;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
 
     const int g = g0 + lane;
-    if (lane >= PPW || g >= nprob) return;
+    if (lane >= PPW || g >= nprob) continue;
     double Q[NP];
 #pragma unroll
     for (int e = 0; e < NP; ++e) Q[e] = sQ[w][e][lane];
     const int n = sN[w][lane];
-    if (n == -1) return;   // unchanged vertex list: a.dist already holds this distance
+    if (n == -1) continue;   // unchanged vertex list: a.dist already holds this distance
     double alpha[M];
     double dist;
     if (n <= 0) {
@@ -464,9 +389,380 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
                 if (v < m) xalpha[(size_t)g * m + v] = alpha[v];
         }
     } else {
-        const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+        const int pr = act ? act[g] : g;
+        const int pos = a.pos_begin + pr / a.B, c = pr - (pr / a.B) * a.B;
         a.dist[(size_t)pos * a.B + c] = dist;
     }
+    }   // grid-stride loop
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused selection + hull distance (FusedArgs in chb_internal.h).  16 lanes per (position, bin) pair as in
+// hull_qp_kernel, but over the pair's SHORTLIST (<= C candidates): one sweep over the candidate rows
+// accumulates the full C x C shifted Gram.  Its diagonal holds the squared distances of the candidates
+// (fp64, fused sums: within ~D eps of the exact value), which rank them; the m x m block of the m
+// nearest is the Gram of the hull QP -- no row is read twice.
+// Exactness of the selected SET: cdist's (sequentially rounded distance, index) order and this
+// kernel's order can only disagree between candidates whose squared distances agree to ~1e-14
+// relative; a pair whose m-th and (m+1)-th candidates are closer than kTieRel (1e-11) relative is
+// not decided here but handed to the exact path (`slow`).  The ORDER inside the selected set may
+// differ from cdist's on such near-ties inside the set; the hull distance does not depend on it
+// beyond rounding.
+constexpr double kTieRel = 1e-11;
+
+template <int CC, int NR>
+__device__ __forceinline__ void gram_rows(const double *X, int Dp, int qid, int idm, int gbase, int l16,
+                                          double (&r)[NR])
+{
+    constexpr int NP = CC * (CC + 1) / 2;
+    static_assert(NP <= 16 * NR, "result registers");
+    const double *xrow = X + (size_t)qid * Dp;
+    const double *vrow[CC];
+#pragma unroll
+    for (int v = 0; v < CC; ++v) {
+        const int idv = __shfl(idm, gbase + v, 64);
+        // a missing candidate reads the query row: y = 0, its Gram row / column stays 0 (never used)
+        vrow[v] = X + (size_t)(idv >= 0 ? idv : qid) * Dp;
+    }
+    double acc[NP];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) acc[e] = 0.0;
+    const int Dmain = Dp & ~31;
+#pragma unroll 1
+    for (int k = 2 * l16; k < Dmain; k += 32) {
+        const double2 xk = *reinterpret_cast<const double2 *>(xrow + k);
+        double2 y[CC];
+#pragma unroll
+        for (int v = 0; v < CC; ++v) {
+            const double2 pv = *reinterpret_cast<const double2 *>(vrow[v] + k);
+            y[v] = double2{pv.x - xk.x, pv.y - xk.y};
+        }
+#pragma unroll
+        for (int i = 0; i < CC; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double t = acc[i * (i + 1) / 2 + j];
+                t = fma(y[i].x, y[j].x, t);
+                acc[i * (i + 1) / 2 + j] = fma(y[i].y, y[j].y, t);
+            }
+    }
+    for (int k = Dmain + l16; k < Dp; k += 16) {
+        const double xk = xrow[k];
+        double y[CC];
+#pragma unroll
+        for (int v = 0; v < CC; ++v) y[v] = vrow[v][k] - xk;
+#pragma unroll
+        for (int i = 0; i < CC; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) acc[i * (i + 1) / 2 + j] = fma(y[i], y[j], acc[i * (i + 1) / 2 + j]);
+    }
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+        double v16[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v16[e] = 16 * t + e < NP ? acc[16 * t + e] : 0.0;
+        r[t] = 16 * t < NP ? reduce_scatter16(v16, l16) : 0.0;
+    }
+}
+
+#ifndef CHB_FUSED_C
+#define CHB_FUSED_C 7
+#endif
+#ifndef CHB_FUSED_OCC
+#define CHB_FUSED_OCC 3
+#endif
+#ifndef CHB_FUSED_WIDE
+#define CHB_FUSED_WIDE 16
+#endif
+constexpr int kFusedWide = CHB_FUSED_WIDE;   // widest shortlist the fused kernel takes (one candidate per lane of a group)
+
+// squared distances only: candidate v (v < 8) of every 16-lane group is the one held by lane gbase + v0 + v;
+// on return lane l16 < 8 holds the squared distance of candidate v0 + l16
+__device__ __forceinline__ double diag_rows8(const double *X, int Dp, int qid, int idm, int gbase, int l16, int v0)
+{
+    const double *xrow = X + (size_t)qid * Dp;
+    const double *vrow[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const int idv = __shfl(idm, gbase + v0 + v, 64);
+        vrow[v] = X + (size_t)(idv >= 0 ? idv : qid) * Dp;
+    }
+    double acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+    const int Dmain = Dp & ~31;
+#pragma unroll 1
+    for (int k = 2 * l16; k < Dmain; k += 32) {
+        const double2 xk = *reinterpret_cast<const double2 *>(xrow + k);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const double2 pv = *reinterpret_cast<const double2 *>(vrow[v] + k);
+            const double dx = pv.x - xk.x, dy = pv.y - xk.y;
+            acc[v] = fma(dy, dy, fma(dx, dx, acc[v]));
+        }
+    }
+    for (int k = Dmain + l16; k < Dp; k += 16) {
+        const double xk = xrow[k];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const double d = vrow[v][k] - xk;
+            acc[v] = fma(d, d, acc[v]);
+        }
+    }
+    return reduce_scatter16(acc, l16);
+}
+
+template <int M, int C, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kernel(FusedArgs a, int nprob)
+{
+    constexpr int NPM = Sym<M>::NP;            // Gram entries of the hull QP
+    constexpr int NPC = C * (C + 1) / 2;       // ... of the candidate Gram
+    constexpr int NR = (NPC + 15) / 16;
+    constexpr int NCLS = C - M + 1;            // classes of the one-sweep form: widths M, M + 1, ..., C
+    static_assert(C <= 8 && M <= C && C - M <= 3, "candidate Gram in registers");
+    __shared__ double sQ[WAVES][NPM][64];
+    __shared__ double sT[WAVES][4][NR * 16];   // candidate Gram of the group's pair
+    __shared__ double sTh[WAVES][4][2];        // squared distances of ranks m-1 and m
+    __shared__ int sSel[WAVES][4][16];         // candidate slot of each rank
+    __shared__ int sN[WAVES][64];
+    __shared__ int sOrd[WAVES][64];            // problem (lane) of each work position, narrow shortlists first
+    __shared__ int sSlowN, sSlowBase;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int grp = lane >> 4, l16 = lane & 15, gbase = lane & 48;
+    const int m = a.m;
+    if (threadIdx.x == 0) sSlowN = 0;
+    __syncthreads();
+    const int g0 = (blockIdx.x * WAVES + w) * 64;
+    unsigned long long slowmask = 0ull;        // problems of this wavefront left to the exact path
+
+    if (g0 < nprob) {
+        // ---- classification, one problem per lane
+        const int g = g0 + lane;
+        const bool valid = g < nprob;
+        int nb = 0, nu = 0, qid = 0;
+        size_t slot = 0;
+        bool changed = valid;
+        if (valid) {
+            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+            qid = a.bq[pos];
+            slot = (size_t)c * a.Kcap + pos;
+            nb = a.cand_cnt[slot];
+            if (a.candu != nullptr) nu = a.candu_cnt[slot];
+            // unchanged set of batch-entry candidates (the base candidates are fixed during a batch): keep
+            if (a.candp != nullptr && a.candp_cnt[slot] == nu) {
+                if (nu == 0) changed = false;
+                else if (nu <= 8) {
+                    bool same = true;
+                    for (int i = 0; i < nu; ++i) {
+                        const int u = a.candu[slot * kCandCapU + i];
+                        bool f = false;
+                        for (int j = 0; j < nu; ++j) f = f || a.candp[slot * kCandCapU + j] == u;
+                        same = same && f;
+                    }
+                    changed = !same;
+                }
+            }
+        }
+        const int n = nb + nu;
+        // class 0: nothing to compute here.  Classes 1 .. NCLS: ONE sweep over max(n, M) = M + k - 1 candidate
+        // rows (full candidate Gram).  Class NCLS + 1 (C < n <= 16): a distance sweep over all candidates,
+        // then a second sweep over the m selected rows (just read: they come out of L1 / L2).
+        int cls = 0;
+        if (changed && n > 0) {
+            if (n <= C) cls = n <= M ? 1 : n - M + 1;
+            else if (n <= kFusedWide) cls = NCLS + 1;
+        }
+        slowmask = __ballot(changed && n > kFusedWide);
+        sN[w][lane] = (changed && n == 0) ? 0 : -1;   // -1: distance kept / written later
+        int before = 0, nwork = 0, nnarrow = 0;
+#pragma unroll
+        for (int k = 1; k <= NCLS + 1; ++k) {
+            const unsigned long long mk = __ballot(cls == k);
+            if (cls == k) before = nwork + __popcll(mk & ((1ull << lane) - 1ull));
+            nwork += __popcll(mk);
+            if (k == NCLS) nnarrow = nwork;
+        }
+        if (cls > 0) sOrd[w][before] = lane;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+
+        // ---- 16 lanes per problem, four problems per pass, narrow shortlists first.
+        // (Shuffles stay outside any condition: a lane only delivers data while it is active.)
+        for (int p0 = 0; p0 < nnarrow; p0 += 4) {
+            const int op = p0 + grp;
+            const bool has = op < nnarrow;
+            const int pl = has ? sOrd[w][op] : 0;
+            const int n_s = __shfl(n, pl, 64);
+            const int n_g = has ? n_s : 0;
+            const int nb_g = __shfl(nb, pl, 64);
+            const int qid_g = __shfl(qid, pl, 64);
+            const int gg = g0 + pl;
+            const size_t slot_g = (size_t)(gg - (gg / a.B) * a.B) * a.Kcap + (a.pos_begin + gg / a.B);
+            int idm = -1;
+            if (l16 < n_g)
+                idm = l16 < nb_g ? a.cand[slot_g * kCandCap + l16] : a.candu[slot_g * kCandCapU + (l16 - nb_g)];
+            // the widest shortlist of the pass (the last problem: they are sorted)
+            const int cw = __builtin_amdgcn_readfirstlane(__shfl(n, sOrd[w][min(p0 + 3, nnarrow - 1)], 64));
+            double r[NR];
+            if (cw <= M) gram_rows<M, NR>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
+            else if (C >= M + 1 && cw == M + 1) gram_rows<(C >= M + 1 ? M + 1 : M), NR>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
+            else if (C >= M + 2 && cw == M + 2) gram_rows<(C >= M + 2 ? M + 2 : M), NR>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
+            else gram_rows<C, NR>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
+            bool tie = false;
+            if (has && n_g <= m) {
+                // every candidate is a hull vertex: the candidate Gram is the hull's (any vertex order)
+#pragma unroll
+                for (int t = 0; t < NR; ++t)
+                    if (16 * t + l16 < NPM) sQ[w][16 * t + l16][pl] = r[t];
+                if (l16 == 0) sN[w][pl] = n_g;
+            } else if (has) {
+#pragma unroll
+                for (int t = 0; t < NR; ++t) sT[w][grp][16 * t + l16] = r[t];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                // rank of my candidate by (squared distance, index); the ids come through LDS as well
+                // (no shuffle inside a condition)
+                if (l16 < C) sSel[w][grp][8 + l16] = idm;
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                const double sv = l16 < n_g ? sT[w][grp][l16 * (l16 + 3) / 2] : kInf;
+                int rank = 0;
+#pragma unroll
+                for (int u = 0; u < C; ++u) {
+                    const double su = sT[w][grp][u * (u + 3) / 2];
+                    const int iu = sSel[w][grp][8 + u];
+                    rank += (u < n_g && u != l16 && (su < sv || (su == sv && iu < idm))) ? 1 : 0;
+                }
+                if (l16 < n_g) {
+                    if (rank < m) sSel[w][grp][rank] = l16;
+                    if (rank == m - 1) sTh[w][grp][0] = sv;
+                    if (rank == m) sTh[w][grp][1] = sv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                const double t0 = sTh[w][grp][0], t1 = sTh[w][grp][1];
+                tie = !(t1 - t0 > kTieRel * t1);   // (also catches NaN)
+                if (!tie) {
+#pragma unroll
+                    for (int t = 0; 16 * t < NPM; ++t) {
+                        const int e = 16 * t + l16;   // entry (i, j) of the hull Gram, ranks i >= j
+                        int i = 0;
+#pragma unroll
+                        for (int q = 1; q < M; ++q) i += (q * (q + 1) / 2 <= e) ? 1 : 0;
+                        const int j = e - i * (i + 1) / 2;
+                        if (e < NPM) {
+                            double val = 0.0;
+                            if (i < m) {   // (j <= i)
+                                const int vi = sSel[w][grp][i], vj = sSel[w][grp][j];
+                                const int hi = vi > vj ? vi : vj, lo = vi > vj ? vj : vi;
+                                val = sT[w][grp][hi * (hi + 1) / 2 + lo];
+                            }
+                            sQ[w][e][pl] = val;
+                        }
+                    }
+                    if (l16 == 0) sN[w][pl] = m;
+                }
+            }
+            if (l16 == 0 && tie) slowmask |= 1ull << pl;
+        }
+
+        // ---- wide shortlists (C < n <= 16): distances first, then the Gram of the m selected rows
+        for (int p0 = nnarrow; p0 < nwork; p0 += 4) {
+            const int op = p0 + grp;
+            const bool has = op < nwork;
+            const int pl = has ? sOrd[w][op] : 0;
+            const int n_s = __shfl(n, pl, 64);
+            const int n_g = has ? n_s : 0;
+            const int nb_g = __shfl(nb, pl, 64);
+            const int qid_g = __shfl(qid, pl, 64);
+            const int gg = g0 + pl;
+            const size_t slot_g = (size_t)(gg - (gg / a.B) * a.B) * a.Kcap + (a.pos_begin + gg / a.B);
+            int idm = -1;
+            if (l16 < n_g)
+                idm = l16 < nb_g ? a.cand[slot_g * kCandCap + l16] : a.candu[slot_g * kCandCapU + (l16 - nb_g)];
+            int nmax = n_g;
+            nmax = max(nmax, __shfl_xor(nmax, 16, 64));
+            nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+            nmax = __builtin_amdgcn_readfirstlane(nmax);
+            double sv = diag_rows8(a.X, a.Dp, qid_g, idm, gbase, l16, 0);
+            if (nmax > 8) {
+                const double s_hi = diag_rows8(a.X, a.Dp, qid_g, idm, gbase, l16, 8);
+                const double moved = __shfl(s_hi, gbase + (l16 & 7), 64);
+                sv = l16 < 8 ? sv : moved;
+            }
+            if (l16 >= n_g) sv = kInf;
+            // rank by (squared distance, index) among the group's n_g candidates
+            int rank = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const double su = __shfl(sv, gbase + u, 64);
+                const int iu = __shfl(idm, gbase + u, 64);
+                rank += (u < n_g && u != l16 && (su < sv || (su == sv && iu < idm))) ? 1 : 0;
+            }
+            if (has && l16 < n_g) {
+                if (rank < m) sSel[w][grp][rank] = idm;
+                if (rank == m - 1) sTh[w][grp][0] = sv;
+                if (rank == m) sTh[w][grp][1] = sv;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            bool tie = false;
+            int idm2 = -1;
+            if (has) {   // (n_g > C >= m: both thresholds exist)
+                const double t0 = sTh[w][grp][0], t1 = sTh[w][grp][1];
+                tie = !(t1 - t0 > kTieRel * t1);
+                if (l16 < m) idm2 = sSel[w][grp][l16];
+            }
+            double r[NR];
+            gram_rows<M, NR>(a.X, a.Dp, qid_g, idm2, gbase, l16, r);
+            if (has && !tie) {
+#pragma unroll
+                for (int t = 0; t < NR; ++t)
+                    if (16 * t + l16 < NPM) sQ[w][16 * t + l16][pl] = r[t];
+                if (l16 == 0) sN[w][pl] = m;
+            }
+            if (l16 == 0 && tie) slowmask |= 1ull << pl;
+        }
+    }
+    // ---- the exact path's work list: one device-scope atomic per workgroup
+    unsigned long long sm = slowmask;   // classification bits on every lane, tie bits on lanes 0, 16, 32, 48
+    sm |= __shfl_xor(sm, 16, 64);
+    sm |= __shfl_xor(sm, 32, 64);
+    sm = __shfl(sm, 0, 64);
+    const int nsl = __popcll(sm);
+    int wbase = 0;
+    if (lane == 0 && nsl > 0) wbase = atomicAdd(&sSlowN, nsl);
+    __syncthreads();
+    if (threadIdx.x == 0) sSlowBase = sSlowN > 0 ? atomicAdd(a.n_slow, sSlowN) : 0;
+    __syncthreads();
+    wbase = __shfl(wbase, 0, 64) + sSlowBase;
+    if (nsl > 0 && ((sm >> lane) & 1ull)) {
+        const int before = __popcll(sm & ((1ull << lane) - 1ull));
+        a.slow[wbase + before] = g0 + lane;
+    }
+    if (g0 >= nprob) return;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+
+    // ---- phase 2: one problem per lane
+    const int g = g0 + lane;
+    if (g >= nprob) return;
+    const int n = sN[w][lane];
+    if (n == -1 || ((sm >> lane) & 1ull)) return;   // distance kept, or written by the exact path
+    double Q[NPM];
+#pragma unroll
+    for (int e = 0; e < NPM; ++e) Q[e] = sQ[w][e][lane];
+    double alpha[M];
+    double dist;
+    if (n <= 0) {
+        dist = kInf;
+    } else {
+        const double val = a.metric == 0 ? min_norm_point<M>(Q, n, alpha) : affine_min_norm<M>(Q, n, alpha);
+        dist = sqrt(fmax(val, 0.0));
+    }
+    const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+    a.dist[(size_t)pos * a.B + c] = dist;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -762,9 +1058,10 @@ template <int M, int WV, bool INDEXED>
 void launch_one(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull, const int *xn,
                 double *xdist, double *xalpha, hipStream_t s)
 {
-    constexpr int PPW = M <= 8 ? 64 : (16 / M) * (64 / (16 / M));
+    constexpr int PPW = 64;
     const int nwaves = (nprob + PPW - 1) / PPW;
-    const int grid = (nwaves + WV - 1) / WV;
+    int grid = (nwaves + WV - 1) / WV;
+    if (!INDEXED && a.active != nullptr) grid = std::min(grid, 256);   // listed pairs: grid-stride over *n_active
     hipLaunchKernelGGL((hull_qp_kernel<M, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a, nprob,
                        xq, xhull, xn, m, xdist, xalpha);
 }
@@ -788,6 +1085,17 @@ void launch_hull_qp(const QpArgs &a, hipStream_t s)
 {
     const int nprob = (a.pos_end - a.pos_begin) * a.B;
     dispatch<false>(a, nprob, a.m, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+bool fused_supported(int m) { return m >= 1 && m <= 5; }
+
+void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
+{
+    const int nprob = (a.pos_end - a.pos_begin) * a.B;
+    if (nprob <= 0) return;
+    constexpr int WV = 4;
+    const int grid = (nprob + 64 * WV - 1) / (64 * WV);
+    hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV>), dim3(grid), dim3(64 * WV), 0, s, a, nprob);
 }
 
 void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,

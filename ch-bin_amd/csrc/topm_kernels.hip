@@ -21,6 +21,8 @@
 #include <limits.h>
 #include <math.h>
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace chb {
@@ -257,11 +259,28 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
             const int qpos = pos0 + 4 * ty + i;
             if (qpos < a.pos_end) {
                 const size_t slot = (size_t)c * a.Kcap + qpos;
-                if (tx < m) {
-                    a.out.d[slot * m + tx] = tx < lc[i] ? ld[i] : kInf;
-                    a.out.idx[slot * m + tx] = tx < lc[i] ? li[i] : -1;
+                if (a.out.d != nullptr) {
+                    if (tx < m) {
+                        a.out.d[slot * m + tx] = tx < lc[i] ? ld[i] : kInf;
+                        a.out.idx[slot * m + tx] = tx < lc[i] ? li[i] : -1;
+                    }
+                    if (tx == 0) a.out.cnt[slot] = lc[i];
                 }
-                if (tx == 0) a.out.cnt[slot] = lc[i];
+                if (a.cand_out != nullptr) {
+                    // the exact top-m IS a valid shortlist (fused selection path)
+                    if (tx < lc[i]) a.cand_out[slot * a.cand_cap + tx] = li[i];
+                    if (tx == 0) a.cand_cnt_out[slot] = lc[i];
+                    const double e_m = __shfl(ld[i], m - 1, 16);
+                    if (tx == 0 && a.tau_out != nullptr) {
+                        float t = INFINITY;
+                        if (lc[i] >= m) {
+                            t = (float)(e_m * a.S);
+                            if ((double)t < e_m * a.S) t = nextafterf(t, INFINITY);
+                            t *= 1.0f + 1e-6f;
+                        }
+                        a.tau_out[slot] = t;
+                    }
+                }
             }
         }
     }
@@ -288,24 +307,23 @@ __global__ __launch_bounds__(64 * WAVES) void rescore_kernel(RescoreArgs a, int 
 
     const int lane = threadIdx.x & 63, gl = lane & (W - 1), gbase = lane & ~(W - 1), w = threadIdx.x >> 6;
     const int grp = lane / W;
-    int gidx = ((int)blockIdx.x * WAVES + w) * G + grp;
+    // active list: *n_active pairs, walked grid-stride (the grid is capped by the launcher)
+    if (a.active != nullptr) npairs = *a.n_active;
+    for (int wg0 = ((int)blockIdx.x * WAVES + w) * G; wg0 < npairs; wg0 += (int)gridDim.x * WAVES * G) {
+    const int gidx = wg0 + grp;
+    const bool pvalid = gidx < npairs;
     int pair = gidx;
-    bool pvalid;
-    if (a.active != nullptr) {
-        const int na = *a.n_active;
-        pvalid = gidx < na;
-        pair = pvalid ? a.active[gidx] : 0;
-        if (__builtin_amdgcn_readfirstlane(((int)blockIdx.x * WAVES + w) * G) >= na) return;
-    } else {
-        pvalid = gidx < npairs;
-    }
-    int pos = a.pos_begin, c = 0, cnt = 0;
+    if (a.active != nullptr) pair = pvalid ? a.active[gidx] : 0;
+    int pos = a.pos_begin, c = 0, cnt = 0, cnt1 = 0;
     if (pvalid) {
         pos = a.pos_begin + pair / a.B;
         c = pair - (pair / a.B) * a.B;
     }
     const size_t slot = (size_t)c * a.Kcap + pos;
-    if (pvalid) cnt = a.cand_cnt[slot];
+    if (pvalid) {
+        cnt1 = a.cand_cnt[slot];
+        cnt = cnt1 + (a.cand2 != nullptr ? a.cand2_cnt[slot] : 0);
+    }
     const int qid = a.bq[pos];
     const int m = a.m;
 
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES) void rescore_kernel(RescoreArgs a, int 
     for (int base = 0; base < cmax; base += W) {
         const int ci = base + gl;
         const bool have = ci < cnt;
-        const int id = have ? a.cand[slot * kCandCap + ci] : qid;
+        const int id = have ? (ci < cnt1 ? a.cand[slot * a.cand_cap + ci] : a.cand2[slot * a.cand2_cap + (ci - cnt1)]) : qid;
         const double *rp[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) rp[i] = a.X + (size_t)__shfl(id, srow + 8 * i, 64) * a.Dp + 2 * spc;
@@ -378,6 +396,7 @@ __global__ __launch_bounds__(64 * WAVES) void rescore_kernel(RescoreArgs a, int 
         }
         if (gl == 0) a.out.cnt[slot] = lc;
     }
+    }   // grid-stride loop
 }
 
 }  // namespace
@@ -408,12 +427,13 @@ void launch_rescore(const RescoreArgs &a, hipStream_t s)
 {
     const int npairs = (a.pos_end - a.pos_begin) * a.B;
     if (npairs <= 0) return;
+    const int cap = a.active != nullptr ? 512 : INT_MAX;   // listed pairs: grid-stride over *n_active
     if (a.m <= 8) {
         constexpr int WV = 2, PB = WV * 8;      // 8 pairs per wavefront
-        hipLaunchKernelGGL((rescore_kernel<8, WV>), dim3((npairs + PB - 1) / PB), dim3(64 * WV), 0, s, a, npairs);
+        hipLaunchKernelGGL((rescore_kernel<8, WV>), dim3(std::min((npairs + PB - 1) / PB, cap)), dim3(64 * WV), 0, s, a, npairs);
     } else {
         constexpr int WV = 4, PB = WV * 4;
-        hipLaunchKernelGGL((rescore_kernel<16, WV>), dim3((npairs + PB - 1) / PB), dim3(64 * WV), 0, s, a, npairs);
+        hipLaunchKernelGGL((rescore_kernel<16, WV>), dim3(std::min((npairs + PB - 1) / PB, cap)), dim3(64 * WV), 0, s, a, npairs);
     }
 }
 

@@ -33,7 +33,7 @@ def batch_schedule(n_move, batch, members0, first_sweep):
         members = members0 + t0 if first_sweep else 1 << 62
         K = min(kmax, n_move - t0)
         if members < K:
-            K = max(min(64, n_move - t0), members)
+            K = min(max(min(64, n_move - t0), members), kmax)
         out.append((t0, K))
         t0 += K
     return out

@@ -348,7 +348,7 @@ def _brute_ctx():
 
 @pytest.mark.parametrize("kind", ["offset", "tiny", "dups", "wide", "onehot", "bigbins"])
 def test_shortlist_stage_equals_brute_force(ctx, O, kind):
-    """The bf16 shortlist + exact rescoring must give bit-identical lists to the brute-force
+    """The fp16 shortlist + exact rescoring must give bit-identical lists to the brute-force
     kernel on data built to stress the error bounds and the overflow fallback."""
     assert ctx.counter("prefilter_enabled") == 1
     rng = np.random.default_rng(11)
@@ -476,7 +476,7 @@ def test_native_comm_exchange_path_world1(O):
 
 @pytest.mark.parametrize("N,D,B,m", [(400, 300, 3, 5), (300, 8, 1, 4), (900, 146, 40, 5), (64, 16, 2, 16)])
 def test_fit_cluster_odd_shapes(ctx, O, N, D, B, m):
-    """D > 256 (no bf16 shadow: brute-force selection), a single bin, many bins with few members
+    """D > 160 (no fp16 shadow: brute-force selection), a single bin, many bins with few members
     each, D = 146 (10 coverage columns: 10 MFMA k-steps), m = 16 with bins smaller than m."""
     S = 10 if D == 146 else 1
     X, initial, _ = _synth(N, D, B, S=S, seed=D + B, sigma=6e-3, mix=0.5, n_seed=3)
