@@ -189,9 +189,9 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
 
 // algorithm.py:47-60: min_distance = inf, min_cluster = current label; strict '>' so the lowest
 // bin wins ties and NaN never wins.
-__global__ void argmin_kernel(const double *dist, const int *lab_old, const int *lab_prev,
+__global__ void argmin_kernel(const double *dist, const int *lab_old, int *lab_prev,
                               int pos_begin, int pos_end, int B, int *lab_new, double *mind,
-                              int *first_change)
+                              int *first_change, int in_place)
 {
     const int pos = pos_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= pos_end) return;
@@ -205,6 +205,7 @@ __global__ void argmin_kernel(const double *dist, const int *lab_old, const int 
     lab_new[pos] = bc;
     mind[pos] = best;
     if (bc != lab_prev[pos]) atomicMin(first_change, pos);
+    if (in_place) lab_prev[pos] = bc;   // (each position is read and written by its own thread only)
 }
 
 __global__ void first_change_kernel(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change)
@@ -462,13 +463,13 @@ void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq,
                        lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow);
 }
 
-void launch_argmin(const double *dist, const int *lab_old, const int *lab_prev, int pos_begin,
-                   int pos_end, int B, int *lab_new, double *mind, int *first_change,
+void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int pos_begin,
+                   int pos_end, int B, int *lab_new, double *mind, int *first_change, bool in_place,
                    hipStream_t s)
 {
     const int n = pos_end - pos_begin;
     if (n > 0)
-        hipLaunchKernelGGL(argmin_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dist, lab_old, lab_prev, pos_begin, pos_end, B, lab_new, mind, first_change);
+        hipLaunchKernelGGL(argmin_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dist, lab_old, lab_prev, pos_begin, pos_end, B, lab_new, mind, first_change, in_place ? 1 : 0);
 }
 
 }  // namespace chb

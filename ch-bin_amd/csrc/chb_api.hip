@@ -171,6 +171,9 @@ struct chb_ctx {
     int K = 0, Kcap = 0, q_lo = 0, q_hi = 0;
     bool batch_open = false;
     DevBuf<int> bq, lab_old, lab_prev, lab_new, first_change;
+    int *bq_cur = nullptr;      // the open batch's sample indices: bq.p, or a window of perm (no copy)
+    int *fc_host = nullptr;     // pinned landing place of first_change
+    bool argmin_in_place = false;   // chb_fit_cluster without exchange: argmin also stores the label to lab_prev
     DevBuf<double> mind, dist;
     DevBuf<double> l0d, l1d, l2d;
     DevBuf<int> l0i, l1i, l0c, l1c, l2i, l2c;
@@ -361,14 +364,14 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
     h->K = K; h->q_lo = q_lo; h->q_hi = q_hi;
     h->round_in_batch = 0;
     hipStream_t s = h->stream;
-    launch_batch_open(h->labels.p, h->inb.p, h->bq.p, K, h->lab_old.p, s);
+    launch_batch_open(h->labels.p, h->inb.p, h->bq_cur, K, h->lab_old.p, s);
     {
         Timed t(h, "bucket", (double)h->N);
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
                            h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, s);
     }
     TopmArgs a{};
-    a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = q_lo; a.pos_end = q_hi;
+    a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = q_lo; a.pos_end = q_hi;
     a.bin_ptr = h->bin_ptr.p; a.memb_id = h->memb_id.p; a.memb_code = nullptr;
     a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
     a.in = Lists{nullptr, nullptr, nullptr};
@@ -381,7 +384,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
         {
             Timed t(h, "query_norms", (double)(q_hi - q_lo) * h->B);
-            launch_query_norms(h->X.p, h->D, h->Dp, h->bq.p, q_lo, q_hi, h->B, h->Kcap, h->centers.p,
+            launch_query_norms(h->X.p, h->D, h->Dp, h->bq_cur, q_lo, q_hi, h->B, h->Kcap, h->centers.p,
                                h->shadow_scale, h->qn.p, s);
         }
         // the members' shadow rows (relative to their bin's centre) gathered into padded CSR order
@@ -393,7 +396,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
         pa.qn = reinterpret_cast<const float2 *>(h->qn.p);
         pa.P = h->pk.view(); pa.Dz = h->Dz; pa.S = h->shadow_scale;
-        pa.bq = h->bq.p; pa.pos_begin = q_lo; pa.pos_end = q_hi;
+        pa.bq = h->bq_cur; pa.pos_begin = q_lo; pa.pos_end = q_hi;
         pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p; pa.update = false;
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
         pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.cand_cap = kCandCap; pa.overflow = h->overflow.p;
@@ -404,7 +407,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         }
         if (!fusedp) {
             RescoreArgs ra{};
-            ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = q_lo; ra.pos_end = q_hi;
+            ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq_cur; ra.pos_begin = q_lo; ra.pos_end = q_hi;
             ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
             ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.cand_cap = kCandCap; ra.out = h->L0();
             Timed t(h, "rescore", (double)(q_hi - q_lo) * h->B);
@@ -438,12 +441,12 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
     if (hi > lo) {
         {
             Timed t(h, "bucket", (double)h->K);
-            launch_bucket_batch(h->lab_prev.p, h->lab_old.p, h->bq.p, h->K, h->B, h->cnt2.p,
+            launch_bucket_batch(h->lab_prev.p, h->lab_old.p, h->bq_cur, h->K, h->B, h->cnt2.p,
                                 h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, h->pk2.pad_ptr.p,
                                 h->first_change.p, fusedp ? h->n_slow.p : nullptr, s);
         }
         TopmArgs a{};
-        a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = lo; a.pos_end = hi;
+        a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = lo; a.pos_end = hi;
         a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;
         a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
         a.in = h->L0(); a.out = h->Lcur();
@@ -457,7 +460,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
             pa.qn = reinterpret_cast<const float2 *>(h->qn.p);   // built at batch start
             pa.P = h->pk2.view(); pa.Dz = h->Dz; pa.S = h->shadow_scale;
-            pa.bq = h->bq.p; pa.pos_begin = lo; pa.pos_end = hi;
+            pa.bq = h->bq_cur; pa.pos_begin = lo; pa.pos_end = hi;
             pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.update = true;
             pa.tau_in = h->tau.p;
             pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
@@ -476,7 +479,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
                 launch_topm_flagged(a, h->flags64.p, s);
             }
             FusedArgs f{};
-            f.X = h->X.p; f.D = h->D; f.Dp = h->Dp; f.bq = h->bq.p; f.pos_begin = lo; f.pos_end = hi;
+            f.X = h->X.p; f.D = h->D; f.Dp = h->Dp; f.bq = h->bq_cur; f.pos_begin = lo; f.pos_end = hi;
             f.B = h->B; f.m = h->m; f.Kcap = h->Kcap;
             f.cand = h->cand.p; f.cand_cnt = h->cand_cnt.p;
             f.candu = h->candu[cur].p; f.candu_cnt = h->candu_cnt[cur].p;
@@ -491,7 +494,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
                 // (distance, index) order, then the list-based hull kernel
                 Timed t(h, "slow_path", 0.0);
                 RescoreArgs ra{};
-                ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = lo; ra.pos_end = hi;
+                ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq_cur; ra.pos_begin = lo; ra.pos_end = hi;
                 ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
                 ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.cand_cap = kCandCap;
                 ra.cand2 = h->candu[cur].p; ra.cand2_cnt = h->candu_cnt[cur].p; ra.cand2_cap = kCandCapU;
@@ -499,7 +502,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
                 ra.out = h->L1();
                 launch_rescore(ra, s);
                 QpArgs q{};
-                q.X = h->X.p; q.D = h->D; q.Dp = h->Dp; q.bq = h->bq.p; q.pos_begin = lo; q.pos_end = hi;
+                q.X = h->X.p; q.D = h->D; q.Dp = h->Dp; q.bq = h->bq_cur; q.pos_begin = lo; q.pos_end = hi;
                 q.B = h->B; q.m = h->m; q.Kcap = h->Kcap; q.lists = h->L1(); q.dist = h->dist.p;
                 q.prev = Lists{nullptr, nullptr, nullptr};
                 q.metric = h->metric;
@@ -518,7 +521,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
             pa.qn = reinterpret_cast<const float2 *>(h->qn.p);   // built at batch start
             pa.P = h->pk2.view(); pa.Dz = h->Dz; pa.S = h->shadow_scale;
-            pa.bq = h->bq.p; pa.pos_begin = lo; pa.pos_end = hi;
+            pa.bq = h->bq_cur; pa.pos_begin = lo; pa.pos_end = hi;
             pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.update = true;
             pa.seed = h->L0();
             pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
@@ -531,7 +534,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
                                       h->n_active.p, s);
             }
             RescoreArgs ra{};
-            ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq.p; ra.pos_begin = lo; ra.pos_end = hi;
+            ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq_cur; ra.pos_begin = lo; ra.pos_end = hi;
             ra.B = h->B; ra.m = h->m; ra.Kcap = h->Kcap;
             ra.cand = h->cand.p; ra.cand_cnt = h->cand_cnt.p; ra.cand_cap = kCandCap;
             ra.active = h->active.p; ra.n_active = h->n_active.p;
@@ -557,7 +560,7 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
             launch_topm(a, s);
         }
         QpArgs q{};
-        q.X = h->X.p; q.D = h->D; q.Dp = h->Dp; q.bq = h->bq.p; q.pos_begin = lo; q.pos_end = hi;
+        q.X = h->X.p; q.D = h->D; q.Dp = h->Dp; q.bq = h->bq_cur; q.pos_begin = lo; q.pos_end = hi;
         q.B = h->B; q.m = h->m; q.Kcap = h->Kcap; q.lists = h->Lcur(); q.dist = h->dist.p;
         // a (position, bin) whose vertex list is the one of the previous round keeps its distance
         q.prev = h->round_in_batch > 0 ? h->Lprev() : Lists{nullptr, nullptr, nullptr};
@@ -570,14 +573,15 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         {
             Timed t(h, "argmin", (double)(hi - lo));
             launch_argmin(h->dist.p, h->lab_old.p, h->lab_prev.p, lo, hi, h->B, h->lab_new.p,
-                          h->mind.p, h->first_change.p, s);
+                          h->mind.p, h->first_change.p, h->argmin_in_place, s);
         }
         h->stats[2] += (int64_t)(hi - lo) * h->B;
     }
     HIPCHK(hipGetLastError());
     if (first_change_host) {
-        HIPCHK(hipMemcpyAsync(first_change_host, h->first_change.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h->fc_host, h->first_change.p, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        *first_change_host = *h->fc_host;
     }
     h->stats[1] += 1;
     h->round_in_batch += 1;
@@ -590,10 +594,10 @@ int batch_commit_dev(chb_ctx *h, const int *final_dev)
     if (h->use_prefilter && h->shadow_ok && h->centers.p)
         // final labels out, batch marks cleared, and the members' shadow rows recomputed against their
         // new bin's centre: one launch
-        launch_sample_shadow(h->X.p, h->D, h->Dp, h->bq.p, h->K, h->labels.p, h->B, h->centers.p, h->mu_g.p,
+        launch_sample_shadow(h->X.p, h->D, h->Dp, h->bq_cur, h->K, h->labels.p, h->B, h->centers.p, h->mu_g.p,
                              h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, final_dev, h->inb.p, s);
     else
-        launch_batch_close(h->labels.p, h->inb.p, h->bq.p, final_dev, h->K, s);
+        launch_batch_close(h->labels.p, h->inb.p, h->bq_cur, final_dev, h->K, s);
     HIPCHK(hipGetLastError());
     h->batch_open = false;
     return CHB_OK;
@@ -640,6 +644,7 @@ int chb_create(int device_id, chb_ctx **out)
     if (const char *e = getenv("CHB_PF_UPDATE")) h->pf_update = atoi(e) != 0;
 #endif
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->fc_host, 64, hipHostMallocDefault);
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
     return CHB_OK;
@@ -666,6 +671,7 @@ int chb_destroy(chb_ctx *h)
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
     h->slow.release(); h->n_slow.release(); h->tau.release();
     (void)hipStreamDestroy(h->stream);
+    if (h->fc_host) (void)hipHostFree(h->fc_host);
     delete h;
     return CHB_OK;
 }
@@ -776,7 +782,8 @@ int chb_batch_begin(chb_ctx *h, const int64_t *perm_slice, int64_t K, int64_t q_
         if (perm_slice[i] < 0 || perm_slice[i] >= h->N) return fail(CHB_EINVAL, "perm entry out of range");
     if ((int)K > h->Kcap) { int rc = ensure_batch_buffers(h, (int)K); if (rc) return rc; }
     std::vector<int> v = to_i32(perm_slice, (size_t)K);
-    HIPCHK(hipMemcpyAsync(h->bq.p, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
+    h->bq_cur = h->bq.p;
+    HIPCHK(hipMemcpyAsync(h->bq_cur, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return batch_begin_dev(h, (int)K, (int)q_lo, (int)q_hi, false);
 }
@@ -790,6 +797,7 @@ int chb_batch_round(chb_ctx *h, const int64_t *lab_prev, int64_t active, int64_t
     const int K = h->K;
     std::vector<int> v = to_i32(lab_prev, (size_t)K);
     HIPCHK(hipMemcpyAsync(h->lab_prev.p, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
+    h->argmin_in_place = false;
     int rc = batch_round_dev(h, (int)active, nullptr);
     if (rc) return rc;
     const int lo = std::max((int)active, h->q_lo), hi = h->q_hi;
@@ -896,7 +904,7 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
             int K = (int)std::min<int64_t>(Kmax, n_move - t0);
             if (members < K) K = (int)std::max<int64_t>(std::min<int64_t>(64, n_move - t0), members);
             K = std::min(K, Kmax);   // (the floor of 64 above must not exceed a caller's smaller batch: buffers hold Kmax)
-            HIPCHK(hipMemcpyAsync(h->bq.p, h->perm.p + t0, sizeof(int) * K, hipMemcpyDeviceToDevice, s));
+            h->bq_cur = h->perm.p + t0;   // the batch's sample indices: a window of the sweep's permutation
             h->hint_base_members = (double)((it == 0) ? assigned0 + t0 : labelled - K);
             h->hint_batch_entries = (double)((it == 0) ? K : 2 * K);
             // multi-GPU: rank r evaluates positions [r*C, (r+1)*C) of the batch; the label slices
@@ -905,6 +913,7 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
             const bool xchg = h->comm != nullptr && (world > 1 || h->force_gather);
             const int C = (K + world - 1) / world;
             const int q_lo = std::min(K, h->rank * C), q_hi = std::min(K, q_lo + C);
+            h->argmin_in_place = !xchg;
             rc = batch_begin_dev(h, K, q_lo, q_hi, false);
             if (rc) return rc;
             // starting labels of the rounds: last sweep's label, or for still-unlabelled contigs
@@ -922,12 +931,15 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
                     NCCLCHK(rccl()->AllGather(h->lab_new.p + h->rank * C, h->lab_new.p, (size_t)C, ncclInt32, h->comm, s));
                     launch_fill_i32(h->first_change.p, K, 1, s);
                     launch_first_change(h->lab_new.p, h->lab_prev.p, active, K, h->first_change.p, s);
-                    HIPCHK(hipMemcpyAsync(&f, h->first_change.p, sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipMemcpyAsync(h->fc_host, h->first_change.p, sizeof(int), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipStreamSynchronize(s));
+                    f = *h->fc_host;
                 }
-                // positions [active, K) now carry this round's labels
-                HIPCHK(hipMemcpyAsync(h->lab_prev.p + active, h->lab_new.p + active,
-                                      sizeof(int) * (K - active), hipMemcpyDeviceToDevice, s));
+                // positions [active, K) now carry this round's labels (single rank: the argmin kernel has
+                // already written them to lab_prev)
+                if (xchg)
+                    HIPCHK(hipMemcpyAsync(h->lab_prev.p + active, h->lab_new.p + active,
+                                          sizeof(int) * (K - active), hipMemcpyDeviceToDevice, s));
                 if (f >= K) break;
                 active = f + 1;
                 if (active >= K) break;
@@ -988,14 +1000,15 @@ int chb_topm_per_bin(chb_ctx *h, const int64_t *labels, int64_t B, int m, const 
         int K = 0;
         while (t0 + K < Q && K < Kmax && seen.insert(query_idx[t0 + K]).second) ++K;
         std::vector<int> v = to_i32(query_idx + t0, (size_t)K);
-        HIPCHK(hipMemcpyAsync(h->bq.p, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, s));
+        h->bq_cur = h->bq.p;
+        HIPCHK(hipMemcpyAsync(h->bq_cur, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, s));
         rc = batch_begin_dev(h, K, 0, K, true);
         if (rc) return rc;
         // every other query of the chunk is an ordinary member: code "pos != i"
-        launch_bucket_batch(h->lab_old.p, nullptr, h->bq.p, K, h->B, h->cnt2.p, h->bin_ptr2.p,
+        launch_bucket_batch(h->lab_old.p, nullptr, h->bq_cur, K, h->B, h->cnt2.p, h->bin_ptr2.p,
                             h->cursor2.p, h->memb2_id.p, h->memb2_code.p, nullptr, nullptr, nullptr, s);
         TopmArgs a{};
-        a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq.p; a.pos_begin = 0; a.pos_end = K;
+        a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = 0; a.pos_end = K;
         a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;
         a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
         a.in = h->L0(); a.out = h->L1();

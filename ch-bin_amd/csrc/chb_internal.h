@@ -214,8 +214,9 @@ void launch_compact_active(const int *cand_cnt, int pos_begin, int pos_end, int 
 void launch_select_row(const int *labels, const double *row, int N, int c, int m, int *out_idx,
                        int *out_cnt, hipStream_t s);
 // strict-'>' argmin over bins (algorithm.py:57), first change position
-void launch_argmin(const double *dist, const int *lab_old, const int *lab_prev, int pos_begin,
-                   int pos_end, int B, int *lab_new, double *mind, int *first_change,
+// (in_place: also lab_prev[pos] = lab_new[pos], after the comparison)
+void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int pos_begin,
+                   int pos_end, int B, int *lab_new, double *mind, int *first_change, bool in_place,
                    hipStream_t s);
 
 

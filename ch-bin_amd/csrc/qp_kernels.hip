@@ -260,7 +260,6 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
 {
     constexpr int NP = Sym<M>::NP;
     static_assert(M <= 8, "m > 8 runs on hull_qp16_kernel");
-    constexpr int PPW = 64;        // problems per wavefront (one per lane in phase 2)
     __shared__ double sQ[WAVES][NP][64];
     __shared__ int sN[WAVES][64];
 
@@ -269,15 +268,19 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
     // active mode: the problems are the listed pairs (device-side count), walked grid-stride
     const int *act = INDEXED ? nullptr : a.active;
     if (act != nullptr) nprob = *a.n_active;
+    // a listed (usually short) problem set is spread as thinly as possible -- four problems per wavefront,
+    // one pass -- because a wavefront's sixteen passes are a serial chain of memory round trips
+    const int npass = act != nullptr ? 1 : 16;
+    const int ppw = 4 * npass;
 
-    for (int g0 = (blockIdx.x * WAVES + w) * PPW; g0 < nprob; g0 += (int)gridDim.x * WAVES * PPW) {
+    for (int g0 = (blockIdx.x * WAVES + w) * ppw; g0 < nprob; g0 += (int)gridDim.x * WAVES * ppw) {
     {
         // 16 lanes per problem, lane l16 over the features k = l16 (mod 16): every row is read in
         // full 128-byte lines, each lane accumulates all M (M + 1) / 2 products of its features, and
         // a reduce-scatter leaves one finished Gram entry per lane.  For M <= 8 this beats the
         // 16 x 16 matrix-core tile, most of which (the blocks between different problems) is waste.
         const int grp = lane >> 4, l16 = lane & 15;
-        for (int pass = 0; pass < 16; ++pass) {
+        for (int pass = 0; pass < npass; ++pass) {
             const int pl = pass * 4 + grp;
             const int g = g0 + pl;
             const bool valid = g < nprob;
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
 
     const int g = g0 + lane;
-    if (lane >= PPW || g >= nprob) continue;
+    if (lane >= ppw || g >= nprob) continue;
     double Q[NP];
 #pragma unroll
     for (int e = 0; e < NP; ++e) Q[e] = sQ[w][e][lane];
@@ -1061,7 +1064,7 @@ void launch_one(const QpArgs &a, int nprob, int m, const int *xq, const int *xhu
     constexpr int PPW = 64;
     const int nwaves = (nprob + PPW - 1) / PPW;
     int grid = (nwaves + WV - 1) / WV;
-    if (!INDEXED && a.active != nullptr) grid = std::min(grid, 256);   // listed pairs: grid-stride over *n_active
+    if (!INDEXED && a.active != nullptr) grid = std::min(16 * grid, 1024);   // listed pairs: grid-stride, 4 per wavefront
     hipLaunchKernelGGL((hull_qp_kernel<M, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a, nprob,
                        xq, xhull, xn, m, xdist, xalpha);
 }
