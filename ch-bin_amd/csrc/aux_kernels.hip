@@ -3,19 +3,22 @@
 #include "chb_internal.h"
 
 namespace chb {
+thread_local Gate g_gate;
 namespace {
 
 constexpr double kInf = __builtin_huge_val();
 
-__global__ void fill_i32_kernel(int *p, int v, int n)
+__global__ void fill_i32_kernel(int *p, int v, int n, Gate gate)
 {
+    CHB_GATE(gate);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
 
 // batch start: remember the members' labels and mark them as "in the batch at position i"
-__global__ void batch_open_kernel(const int *labels, int *inb, const int *bq, int K, int *lab_old)
+__global__ void batch_open_kernel(const int *labels, int *inb, const int *bq, int K, int *lab_old, Gate gate)
 {
+    CHB_GATE(gate);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < K) {
         const int p = bq[i];
@@ -37,8 +40,9 @@ __global__ void batch_close_kernel(int *labels, int *inb, const int *bq, const i
 
 // ---- base members: every labelled sample that is not in the current batch
 
-__global__ void count_base_kernel(const int *labels, const int *inb, int N, int B, int *cnt)
+__global__ void count_base_kernel(const int *labels, const int *inb, int N, int B, int *cnt, Gate gate)
 {
+    CHB_GATE(gate);
     extern __shared__ int hist[];
     for (int b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
     __syncthreads();
@@ -53,8 +57,10 @@ __global__ void count_base_kernel(const int *labels, const int *inb, int N, int 
 
 // bin_ptr / cursor = exclusive scan of cnt; pad_ptr (optional) = the same with every count rounded
 // up to a multiple of 32 (the padded layout of the shortlist stage).  One block of 256 threads.
-__global__ __launch_bounds__(256) void scan_kernel(const int *cnt, int B, int *bin_ptr, int *cursor, int *pad_ptr)
+__global__ __launch_bounds__(256) void scan_kernel(const int *cnt, int B, int *bin_ptr, int *cursor, int *pad_ptr,
+                                                    Gate gate)
 {
+    CHB_GATE(gate);
     __shared__ int part[256], ppart[256];
     const int per = (B + 255) / 256;
     const int b0 = min(B, (int)threadIdx.x * per), b1 = min(B, b0 + per);
@@ -87,8 +93,9 @@ __global__ __launch_bounds__(256) void scan_kernel(const int *cnt, int B, int *b
 
 // Block-aggregated fill: one global atomic per (block, bin) instead of one per sample.
 __global__ __launch_bounds__(256) void fill_base_kernel(const int *labels, const int *inb, int N, int B,
-                                                        int *cursor, int *memb_id)
+                                                        int *cursor, int *memb_id, Gate gate)
 {
+    CHB_GATE(gate);
     extern __shared__ int sh[];      // [B] local counts, then [B] block base offsets
     int *cnt = sh, *base = sh + B;
     for (int b = threadIdx.x; b < B; b += blockDim.x) cnt[b] = 0;
@@ -118,8 +125,9 @@ __global__ __launch_bounds__(256) void fill_base_kernel(const int *labels, const
 // LDS cursors.  Entry codes: see chb_internal.h (TopmArgs::memb_code).
 __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev, const int *lab_old, const int *bq,
                                                             int K, int B, int *bin_ptr, int *pad_ptr, int *memb_id,
-                                                            int *memb_code, int *first_change, int *n_slow)
+                                                            int *memb_code, int *first_change, int *n_slow, Gate gate)
 {
+    CHB_GATE(gate);
     extern __shared__ int sh[];   // [B] counts -> cursors, [1024] scan partials x 2
     int *cnt = sh, *part = sh + B, *ppart = part + 1024;
     const int tid = threadIdx.x;
@@ -191,8 +199,9 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
 // bin wins ties and NaN never wins.
 __global__ void argmin_kernel(const double *dist, const int *lab_old, int *lab_prev,
                               int pos_begin, int pos_end, int B, int *lab_new, double *mind,
-                              int *first_change, int in_place)
+                              int *first_change, int in_place, Gate gate)
 {
+    CHB_GATE(gate);
     const int pos = pos_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= pos_end) return;
     double best = kInf;
@@ -250,8 +259,9 @@ __global__ __launch_bounds__(256) void guess_kernel(const double *list_d, const 
 // the same kind of guess from the shortlist stage's bounds near[bin][Kcap] of the m-th nearest distance:
 // the bin whose m-th nearest member is closest
 __global__ __launch_bounds__(256) void guess_near_kernel(const float *near, const int *lab_old, int p0, int K, int B,
-                                                         int Kcap, int *lab_prev)
+                                                         int Kcap, int *lab_prev, Gate gate)
 {
+    CHB_GATE(gate);
     const int l16 = threadIdx.x & 15;
     const int pos = p0 + blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool valid = pos < K;
@@ -402,7 +412,7 @@ void launch_guess_near(const float *near, const int *lab_old, int p0, int p1, in
                        hipStream_t s)
 {
     if (p1 > p0)
-        hipLaunchKernelGGL(guess_near_kernel, dim3((p1 - p0 + 15) / 16), dim3(256), 0, s, near, lab_old, p0, p1, B, Kcap, lab_prev);
+        hipLaunchKernelGGL(guess_near_kernel, dim3((p1 - p0 + 15) / 16), dim3(256), 0, s, near, lab_old, p0, p1, B, Kcap, lab_prev, g_gate);
 }
 
 void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,
@@ -432,11 +442,11 @@ void launch_select_row(const int *labels, const double *row, int N, int c, int m
 
 void launch_fill_i32(int *p, int v, int n, hipStream_t s)
 {
-    if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+    if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n, g_gate);
 }
 void launch_batch_open(const int *labels, int *inb, const int *bq, int K, int *lab_old, hipStream_t s)
 {
-    if (K > 0) hipLaunchKernelGGL(batch_open_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, inb, bq, K, lab_old);
+    if (K > 0) hipLaunchKernelGGL(batch_open_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, inb, bq, K, lab_old, g_gate);
 }
 void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, int K, hipStream_t s)
 {
@@ -449,9 +459,9 @@ void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cn
     launch_fill_i32(cnt, 0, B, s);
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr);
-    hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * sizeof(int), s, labels, inb, N, B, cursor, memb_id);
+    hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt, g_gate);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr, g_gate);
+    hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * sizeof(int), s, labels, inb, N, B, cursor, memb_id, g_gate);
 }
 
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
@@ -460,7 +470,7 @@ void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq,
 {
     (void)cnt; (void)cursor;   // (scratch of the former three-kernel form)
     hipLaunchKernelGGL(bucket_batch_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 2048), s, lab_prev,
-                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow);
+                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow, g_gate);
 }
 
 void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int pos_begin,
@@ -469,7 +479,7 @@ void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int po
 {
     const int n = pos_end - pos_begin;
     if (n > 0)
-        hipLaunchKernelGGL(argmin_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dist, lab_old, lab_prev, pos_begin, pos_end, B, lab_new, mind, first_change, in_place ? 1 : 0);
+        hipLaunchKernelGGL(argmin_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dist, lab_old, lab_prev, pos_begin, pos_end, B, lab_new, mind, first_change, in_place ? 1 : 0, g_gate);
 }
 
 }  // namespace chb

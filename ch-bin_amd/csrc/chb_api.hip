@@ -172,7 +172,10 @@ struct chb_ctx {
     bool batch_open = false;
     DevBuf<int> bq, lab_old, lab_prev, lab_new, first_change;
     int *bq_cur = nullptr;      // the open batch's sample indices: bq.p, or a window of perm (no copy)
-    int *fc_host = nullptr;     // pinned landing place of first_change
+    int *fc_host = nullptr;     // pinned landing places of the two first_change slots
+    int *fc_cur = nullptr;      // first_change slot of the open batch (first_change.p + 0 / 1)
+    hipEvent_t fc_event[2] = {nullptr, nullptr};
+    bool speculate = true;      // CHB_SPECULATE=0: never enqueue the next batch ahead of the convergence test
     bool argmin_in_place = false;   // chb_fit_cluster without exchange: argmin also stores the label to lab_prev
     DevBuf<double> mind, dist;
     DevBuf<double> l0d, l1d, l2d;
@@ -267,7 +270,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->lab_old.ensure(K));
     HIPCHK(h->lab_prev.ensure(Kpad));
     HIPCHK(h->lab_new.ensure(Kpad));
-    HIPCHK(h->first_change.ensure(1));
+    HIPCHK(h->first_change.ensure(2));
+    h->fc_cur = h->first_change.p;
     HIPCHK(h->mind.ensure(Kpad));
     HIPCHK(h->dist.ensure(K * B));
     HIPCHK(h->l0d.ensure(K * B * m));
@@ -432,18 +436,18 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
 }
 
 // lab_prev (device) holds the labels of the previous round.  Evaluates [max(active,q_lo), q_hi).
-int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
+int batch_round_dev(chb_ctx *h, int active)
 {
     hipStream_t s = h->stream;
     const int lo = std::max(active, h->q_lo), hi = h->q_hi;
-    if (hi <= lo) launch_fill_i32(h->first_change.p, h->K, 1, s);
+    if (hi <= lo) launch_fill_i32(h->fc_cur, h->K, 1, s);
     const bool fusedp = h->fused && h->lists_valid == false;
     if (hi > lo) {
         {
             Timed t(h, "bucket", (double)h->K);
             launch_bucket_batch(h->lab_prev.p, h->lab_old.p, h->bq_cur, h->K, h->B, h->cnt2.p,
                                 h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, h->pk2.pad_ptr.p,
-                                h->first_change.p, fusedp ? h->n_slow.p : nullptr, s);
+                                h->fc_cur, fusedp ? h->n_slow.p : nullptr, s);
         }
         TopmArgs a{};
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = lo; a.pos_end = hi;
@@ -573,16 +577,11 @@ int batch_round_dev(chb_ctx *h, int active, int *first_change_host)
         {
             Timed t(h, "argmin", (double)(hi - lo));
             launch_argmin(h->dist.p, h->lab_old.p, h->lab_prev.p, lo, hi, h->B, h->lab_new.p,
-                          h->mind.p, h->first_change.p, h->argmin_in_place, s);
+                          h->mind.p, h->fc_cur, h->argmin_in_place, s);
         }
         h->stats[2] += (int64_t)(hi - lo) * h->B;
     }
     HIPCHK(hipGetLastError());
-    if (first_change_host) {
-        HIPCHK(hipMemcpyAsync(h->fc_host, h->first_change.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        *first_change_host = *h->fc_host;
-    }
     h->stats[1] += 1;
     h->round_in_batch += 1;
     return CHB_OK;
@@ -645,6 +644,8 @@ int chb_create(int device_id, chb_ctx **out)
 #endif
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->fc_host, 64, hipHostMallocDefault);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->fc_event[i], hipEventDisableTiming);
+    if (const char *ev = getenv("CHB_SPECULATE")) h->speculate = atoi(ev) != 0;
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
     return CHB_OK;
@@ -672,6 +673,7 @@ int chb_destroy(chb_ctx *h)
     h->slow.release(); h->n_slow.release(); h->tau.release();
     (void)hipStreamDestroy(h->stream);
     if (h->fc_host) (void)hipHostFree(h->fc_host);
+    for (int i = 0; i < 2; ++i) if (h->fc_event[i]) (void)hipEventDestroy(h->fc_event[i]);
     delete h;
     return CHB_OK;
 }
@@ -798,7 +800,7 @@ int chb_batch_round(chb_ctx *h, const int64_t *lab_prev, int64_t active, int64_t
     std::vector<int> v = to_i32(lab_prev, (size_t)K);
     HIPCHK(hipMemcpyAsync(h->lab_prev.p, v.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
     h->argmin_in_place = false;
-    int rc = batch_round_dev(h, (int)active, nullptr);
+    int rc = batch_round_dev(h, (int)active);
     if (rc) return rc;
     const int lo = std::max((int)active, h->q_lo), hi = h->q_hi;
     if (hi > lo) {
@@ -897,64 +899,143 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
         HIPCHK(h->perm.ensure((size_t)std::max<int64_t>(n_move, 1)));
         if (n_move)
             HIPCHK(hipMemcpyAsync(h->perm.p, p32.data(), sizeof(int) * n_move, hipMemcpyHostToDevice, s));
-        int64_t t0 = 0;
-        while (t0 < n_move) {
+        // ---- the batches of this sweep.  A batch = start (selection against the members outside it), a
+        // label guess, then rounds until the first changed position is past its end.  On one GPU the
+        // NEXT batch is enqueued while the first round's verdict is still on its way to the host: its
+        // kernels (and this batch's commit) carry a gate on that verdict and return at once if the round
+        // did not converge, in which case the remaining rounds run and the next batch is enqueued again.
+        // The stream never drains while rounds converge at once -- the common case after sweep 1's start;
+        // a failed guess switches the look-ahead off until a batch converges in one round again.
+        const int world = h->world;
+        const bool xchg = h->comm != nullptr && (world > 1 || h->force_gather);
+        const bool can_spec = h->speculate && h->fused && !xchg && min_dist_out == nullptr;
+        struct Geom { int64_t t0; int K, q_lo, q_hi, C; };
+        auto geom_at = [&](int64_t t0) {
             // sweep 1 starts from few labelled members: do not let a batch outnumber them
-            int64_t members = (it == 0) ? assigned0 + t0 : N;
+            const int64_t members = (it == 0) ? assigned0 + t0 : N;
             int K = (int)std::min<int64_t>(Kmax, n_move - t0);
             if (members < K) K = (int)std::max<int64_t>(std::min<int64_t>(64, n_move - t0), members);
             K = std::min(K, Kmax);   // (the floor of 64 above must not exceed a caller's smaller batch: buffers hold Kmax)
-            h->bq_cur = h->perm.p + t0;   // the batch's sample indices: a window of the sweep's permutation
-            h->hint_base_members = (double)((it == 0) ? assigned0 + t0 : labelled - K);
-            h->hint_batch_entries = (double)((it == 0) ? K : 2 * K);
             // multi-GPU: rank r evaluates positions [r*C, (r+1)*C) of the batch; the label slices
             // are exchanged with one in-place RCCL all-gather per round (KB-sized)
-            const int world = h->world;
-            const bool xchg = h->comm != nullptr && (world > 1 || h->force_gather);
             const int C = (K + world - 1) / world;
-            const int q_lo = std::min(K, h->rank * C), q_hi = std::min(K, q_lo + C);
-            h->argmin_in_place = !xchg;
-            rc = batch_begin_dev(h, K, q_lo, q_hi, false);
-            if (rc) return rc;
-            // starting labels of the rounds: last sweep's label, or for still-unlabelled contigs
-            // (sweep 1) the bin of the nearest outside member
-            if (h->fused && !h->lists_valid) launch_guess_near(h->tau.p, h->lab_old.p, q_lo, q_hi, h->B, h->Kcap, h->lab_prev.p, s);
-            else launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, q_lo, q_hi, h->B, h->m, h->Kcap, h->lab_prev.p, s);
+            const int q_lo = std::min(K, h->rank * C);
+            return Geom{t0, K, q_lo, std::min(K, q_lo + C), C};
+        };
+        // after a round's kernels: (multi-GPU: exchange) + first-changed position on its way to the host
+        auto finish_round = [&](const Geom &g, int active, int slot) -> int {
+            if (xchg) {
+                NCCLCHK(rccl()->AllGather(h->lab_new.p + h->rank * g.C, h->lab_new.p, (size_t)g.C, ncclInt32, h->comm, s));
+                launch_fill_i32(h->fc_cur, g.K, 1, s);
+                launch_first_change(h->lab_new.p, h->lab_prev.p, active, g.K, h->fc_cur, s);
+            }
+            HIPCHK(hipMemcpyAsync(h->fc_host + slot, h->fc_cur, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipEventRecord(h->fc_event[slot], s));
+            return CHB_OK;
+        };
+        auto wait_round = [&](const Geom &g, int active, int slot, int *f) -> int {
+            HIPCHK(hipEventSynchronize(h->fc_event[slot]));
+            *f = h->fc_host[slot];
+            // positions [active, K) now carry this round's labels (single rank: the argmin kernel has
+            // already written them to lab_prev)
             if (xchg)
-                NCCLCHK(rccl()->AllGather(h->lab_prev.p + h->rank * C, h->lab_prev.p, (size_t)C, ncclInt32, h->comm, s));
-            int active = 0;
-            for (;;) {
-                int f = K;
-                rc = batch_round_dev(h, active, xchg ? nullptr : &f);
+                HIPCHK(hipMemcpyAsync(h->lab_prev.p + active, h->lab_new.p + active,
+                                      sizeof(int) * (g.K - active), hipMemcpyDeviceToDevice, s));
+            return CHB_OK;
+        };
+        // batch start + guess + round 0, nothing read back
+        auto open_batch = [&](const Geom &g, int slot) -> int {
+            h->bq_cur = h->perm.p + g.t0;   // the batch's sample indices: a window of the sweep's permutation
+            h->fc_cur = h->first_change.p + slot;
+            h->hint_base_members = (double)((it == 0) ? assigned0 + g.t0 : labelled - g.K);
+            h->hint_batch_entries = (double)((it == 0) ? g.K : 2 * g.K);
+            h->argmin_in_place = !xchg;
+            int r = batch_begin_dev(h, g.K, g.q_lo, g.q_hi, false);
+            if (r) return r;
+            // starting labels of the rounds: last sweep's label, or for still-unlabelled contigs
+            // (sweep 1) the bin whose m-th nearest outside member is closest
+            if (h->fused && !h->lists_valid) launch_guess_near(h->tau.p, h->lab_old.p, g.q_lo, g.q_hi, h->B, h->Kcap, h->lab_prev.p, s);
+            else launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, g.q_lo, g.q_hi, h->B, h->m, h->Kcap, h->lab_prev.p, s);
+            if (xchg)
+                NCCLCHK(rccl()->AllGather(h->lab_prev.p + h->rank * g.C, h->lab_prev.p, (size_t)g.C, ncclInt32, h->comm, s));
+            r = batch_round_dev(h, 0);
+            if (r) return r;
+            return finish_round(g, 0, slot);
+        };
+        struct Snap {   // host-side batch state (the device side of a gated-off batch never changed)
+            int K, q_lo, q_hi, round_in_batch; bool lists_valid, batch_open; int *bq_cur, *fc_cur;
+            double hb, he; int64_t st[4];
+        };
+        auto save = [&]() {
+            Snap v{h->K, h->q_lo, h->q_hi, h->round_in_batch, h->lists_valid, h->batch_open, h->bq_cur, h->fc_cur,
+                   h->hint_base_members, h->hint_batch_entries, {0, 0, 0, 0}};
+            memcpy(v.st, h->stats, sizeof(v.st));
+            return v;
+        };
+        auto restore = [&](const Snap &v) {
+            h->K = v.K; h->q_lo = v.q_lo; h->q_hi = v.q_hi; h->round_in_batch = v.round_in_batch;
+            h->lists_valid = v.lists_valid; h->batch_open = v.batch_open; h->bq_cur = v.bq_cur; h->fc_cur = v.fc_cur;
+            h->hint_base_members = v.hb; h->hint_batch_entries = v.he;
+            memcpy(h->stats, v.st, sizeof(v.st));
+        };
+        struct GateReset { ~GateReset() { g_gate = Gate{}; } } gate_reset;   // (error returns inside the window)
+
+        int64_t t0 = 0;
+        bool inflight = false, spec_ok = can_spec;
+        int slot = 0;
+        while (t0 < n_move) {
+            const Geom g = geom_at(t0);
+            const int K = g.K;
+            if (!inflight) { rc = open_batch(g, slot); if (rc) return rc; }
+            const int64_t t1 = t0 + K;
+            const bool spec = spec_ok && t1 < n_move;
+            Snap snap{};
+            if (spec) {
+                snap = save();
+                g_gate = Gate{h->first_change.p + slot, K};   // "this batch's round 0 changed nothing"
+                rc = batch_commit_dev(h, h->lab_prev.p);
                 if (rc) return rc;
-                if (xchg) {
-                    NCCLCHK(rccl()->AllGather(h->lab_new.p + h->rank * C, h->lab_new.p, (size_t)C, ncclInt32, h->comm, s));
-                    launch_fill_i32(h->first_change.p, K, 1, s);
-                    launch_first_change(h->lab_new.p, h->lab_prev.p, active, K, h->first_change.p, s);
-                    HIPCHK(hipMemcpyAsync(h->fc_host, h->first_change.p, sizeof(int), hipMemcpyDeviceToHost, s));
-                    HIPCHK(hipStreamSynchronize(s));
-                    f = *h->fc_host;
+                rc = open_batch(geom_at(t1), slot ^ 1);
+                if (rc) return rc;
+                g_gate = Gate{};
+            }
+            int f = K;
+            rc = wait_round(g, 0, slot, &f);
+            if (rc) return rc;
+            if (f < K) {
+                // the guess was off at position f: everything enqueued behind the gate has skipped itself
+                if (spec) { restore(snap); spec_ok = false; }
+                int active = f + 1;
+                while (active < K) {
+                    rc = batch_round_dev(h, active);
+                    if (rc) return rc;
+                    rc = finish_round(g, active, slot);
+                    if (rc) return rc;
+                    rc = wait_round(g, active, slot, &f);
+                    if (rc) return rc;
+                    if (f >= K) break;
+                    active = f + 1;
                 }
-                // positions [active, K) now carry this round's labels (single rank: the argmin kernel has
-                // already written them to lab_prev)
-                if (xchg)
-                    HIPCHK(hipMemcpyAsync(h->lab_prev.p + active, h->lab_new.p + active,
-                                          sizeof(int) * (K - active), hipMemcpyDeviceToDevice, s));
-                if (f >= K) break;
-                active = f + 1;
-                if (active >= K) break;
+                inflight = false;
+            } else {
+                inflight = spec;   // the next batch's first round is already running
+                spec_ok = can_spec;
             }
             if (min_dist_out && xchg)
-                NCCLCHK(rccl()->AllGather(h->mind.p + h->rank * C, h->mind.p, (size_t)C, ncclFloat64, h->comm, s));
+                NCCLCHK(rccl()->AllGather(h->mind.p + h->rank * g.C, h->mind.p, (size_t)g.C, ncclFloat64, h->comm, s));
             if (min_dist_out) {
                 HIPCHK(hipMemcpyAsync(mind_host.data(), h->mind.p, sizeof(double) * K, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
                 for (int i = 0; i < K; ++i) min_dist_out[perm[t0 + i]] = mind_host[(size_t)i];
             }
-            rc = batch_commit_dev(h, h->lab_prev.p);
-            if (rc) return rc;
+            if (!inflight) {   // (otherwise the commit went out with the look-ahead)
+                rc = batch_commit_dev(h, h->lab_prev.p);
+                if (rc) return rc;
+            } else {
+                slot ^= 1;
+            }
             h->stats[0] += 1;
-            t0 += K;
+            t0 = t1;
         }
         h->stats[3] += n_move * (int64_t)h->B;
         HIPCHK(hipMemcpyAsync(cur.data(), h->labels.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));

@@ -7,6 +7,16 @@
 
 namespace chb {
 
+// Speculative continuation (chb_api.hip: chb_fit_cluster): the kernels of the next batch are enqueued
+// before the host knows whether the current batch's round has converged; they carry a gate and return at
+// once unless *flag >= need (flag = the current batch's first-changed position, need = its size).
+struct Gate {
+    const int *flag = nullptr;
+    int need = 0;
+};
+extern thread_local Gate g_gate;   // what every launch_* helper passes to its kernels
+#define CHB_GATE(g) do { if ((g).flag != nullptr && *(g).flag < (g).need) return; } while (0)
+
 constexpr int kMaxM = 16;       // CHB_MAX_NEIGHBORS
 constexpr int kQTile = 64;      // queries per workgroup tile
 constexpr int kPTile = 64;      // bin members per workgroup tile

@@ -200,8 +200,9 @@ __global__ __launch_bounds__(256) void sample_shadow_kernel(const double *X, int
                                                             int n, int *labels, int B,
                                                             const double *centers, const double *mu_g, double S,
                                                             unsigned short *Zs, int Dz, float4 *ms,
-                                                            const int *new_lab, int *inb)
+                                                            const int *new_lab, int *inb, Gate gate)
 {
+    CHB_GATE(gate);
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -234,8 +235,9 @@ __device__ __forceinline__ int bin_of_row(const int *pad_ptr, int B, int r)
 // 16 lanes per row.  Padding rows: zero features, bias = +inf (never selectable).
 __global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs, const float4 *ms, int Dz,
                                                         const int *memb_id, const int *bin_ptr,
-                                                        const int *pad_ptr, int B, MemberPack P)
+                                                        const int *pad_ptr, int B, MemberPack P, Gate gate)
 {
+    CHB_GATE(gate);
     const int total = pad_ptr[B];
     const int cpr = Dz >> 3;
     const int l16 = threadIdx.x & 15;
@@ -264,8 +266,9 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs
 __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int D, int Dp, const int *memb_id,
                                                             const int *memb_code, const int *bin_ptr,
                                                             const int *pad_ptr, const double *centers,
-                                                            const double *mu_g, double S, int Dz, MemberPack P)
+                                                            const double *mu_g, double S, int Dz, MemberPack P, Gate gate)
 {
+    CHB_GATE(gate);
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b0 = bin_ptr[c], cnt = bin_ptr[c + 1] - b0, r0 = pad_ptr[c];
@@ -298,8 +301,9 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
 
 // bb[c] = {largest rounding distance, largest ||zh|| (rounded up), largest ||zh||^2 + 2|<..>|, 0}
 // over the members of bin c; one block per bin
-__global__ __launch_bounds__(256) void bin_bounds_kernel(MemberPack P, const int *bin_ptr)
+__global__ __launch_bounds__(256) void bin_bounds_kernel(MemberPack P, const int *bin_ptr, Gate gate)
 {
+    CHB_GATE(gate);
     __shared__ float red[3][256];
     const int c = blockIdx.x;
     const int r0 = P.pad_ptr[c], cnt = bin_ptr[c + 1] - bin_ptr[c];
@@ -326,8 +330,9 @@ __global__ __launch_bounds__(256) void bin_bounds_kernel(MemberPack P, const int
 // feature scales away from underflow); each thread owns a 2 x 4 micro-tile.
 __global__ __launch_bounds__(256) void query_norms_kernel(const double *X, int D, int Dp, const int *bq,
                                                           int pos_begin, int pos_end, int B, int Kcap,
-                                                          const double *centers, double S, float2 *qn)
+                                                          const double *centers, double S, float2 *qn, Gate gate)
 {
+    CHB_GATE(gate);
     constexpr int KC = 16;
     __shared__ double xs[32][KC + 1], cs[64][KC + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -458,8 +463,9 @@ __device__ __forceinline__ void list_insert_desc(float (&l)[ML], float v)
 
 template <int ML, bool UPD, int KS>
 __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
-                                                                         int bpw, int *flags64, int nqt64)
+                                                                         int bpw, int *flags64, int nqt64, Gate gate)
 {
+    CHB_GATE(gate);
     constexpr int CPR = 2 * KS;              // 16-byte chunks per shadow row
     constexpr int ROWB = 32 * KS;            // bytes per shadow row
     constexpr int TILEB = kPfP * ROWB;       // one member tile
@@ -818,10 +824,10 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
     const int grid = ((total + 7) / 8) * 8;
     if (a.Dz == 144)
         hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(256), shortlist_lds_bytes(9, ML), s, a,
-                           nqt, nchunk, bpw, flags64, nqt64);
+                           nqt, nchunk, bpw, flags64, nqt64, g_gate);
     else
         hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(256), shortlist_lds_bytes(10, ML), s, a,
-                           nqt, nchunk, bpw, flags64, nqt64);
+                           nqt, nchunk, bpw, flags64, nqt64, g_gate);
 }
 
 }  // namespace
@@ -860,7 +866,7 @@ void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n,
 {
     if (n > 0)
         hipLaunchKernelGGL(sample_shadow_kernel, dim3((n + 3) / 4), dim3(256), 0, s, X, D, Dp, ids, n, labels,
-                           B, centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms), new_lab, inb);
+                           B, centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms), new_lab, inb, g_gate);
 }
 
 void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
@@ -870,8 +876,8 @@ void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const in
     const long long rows = (long long)rows_hint + 32LL * B;
     const int grid = (int)std::min<long long>((rows + 15) / 16, 16384);
     hipLaunchKernelGGL(pack_rows_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, Zs,
-                       reinterpret_cast<const float4 *>(ms), Dz, memb_id, bin_ptr, P.pad_ptr, B, P);
-    hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, P, bin_ptr);
+                       reinterpret_cast<const float4 *>(ms), Dz, memb_id, bin_ptr, P.pad_ptr, B, P, g_gate);
+    hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, P, bin_ptr, g_gate);
 }
 
 void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *memb_code,
@@ -882,8 +888,8 @@ void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, co
     int gy = ((rows_hint + 31 * B) / std::max(B, 1) + 15) / 16;   // ~4 entries per wavefront per bin
     gy = std::max(1, std::min(gy, 64));
     hipLaunchKernelGGL(pack_centered_kernel, dim3(B, gy), dim3(256), 0, s, X, D, Dp, memb_id, memb_code, bin_ptr,
-                       P.pad_ptr, centers, mu_g, S, Dz, P);
-    hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, P, bin_ptr);
+                       P.pad_ptr, centers, mu_g, S, Dz, P, g_gate);
+    hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, P, bin_ptr, g_gate);
 }
 
 void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
@@ -892,7 +898,7 @@ void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_b
     const int nq = pos_end - pos_begin;
     if (nq <= 0 || B <= 0) return;
     hipLaunchKernelGGL(query_norms_kernel, dim3((nq + 31) / 32, (B + 63) / 64), dim3(256), 0, s, X, D, Dp, bq,
-                       pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn));
+                       pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn), g_gate);
 }
 
 void launch_shortlist(const ShortlistArgs &a_, int *flags64, hipStream_t s)

@@ -256,8 +256,9 @@ __device__ __forceinline__ double reduce_scatter16(const double (&v)[16], int l1
 template <int M, int WAVES, bool INDEXED>
 __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(QpArgs a, int nprob, const int *xq,
                                                               const int *xhull, const int *xn,
-                                                              int xm, double *xdist, double *xalpha)
+                                                              int xm, double *xdist, double *xalpha, Gate gate)
 {
+    CHB_GATE(gate);
     constexpr int NP = Sym<M>::NP;
     static_assert(M <= 8, "m > 8 runs on hull_qp16_kernel");
     __shared__ double sQ[WAVES][NP][64];
@@ -516,8 +517,9 @@ __device__ __forceinline__ double diag_rows8(const double *X, int Dp, int qid, i
 }
 
 template <int M, int C, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kernel(FusedArgs a, int nprob)
+__global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kernel(FusedArgs a, int nprob, Gate gate)
 {
+    CHB_GATE(gate);
     constexpr int NPM = Sym<M>::NP;            // Gram entries of the hull QP
     constexpr int NPC = C * (C + 1) / 2;       // ... of the candidate Gram
     constexpr int NR = (NPC + 15) / 16;
@@ -1066,7 +1068,7 @@ void launch_one(const QpArgs &a, int nprob, int m, const int *xq, const int *xhu
     int grid = (nwaves + WV - 1) / WV;
     if (!INDEXED && a.active != nullptr) grid = std::min(16 * grid, 1024);   // listed pairs: grid-stride, 4 per wavefront
     hipLaunchKernelGGL((hull_qp_kernel<M, WV, INDEXED>), dim3(grid), dim3(64 * WV), 0, s, a, nprob,
-                       xq, xhull, xn, m, xdist, xalpha);
+                       xq, xhull, xn, m, xdist, xalpha, g_gate);
 }
 
 template <bool INDEXED>
@@ -1098,7 +1100,7 @@ void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
     if (nprob <= 0) return;
     constexpr int WV = 4;
     const int grid = (nprob + 64 * WV - 1) / (64 * WV);
-    hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV>), dim3(grid), dim3(64 * WV), 0, s, a, nprob);
+    hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
 }
 
 void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,

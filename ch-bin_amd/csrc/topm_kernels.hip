@@ -95,8 +95,9 @@ __device__ __forceinline__ void select_into(double (&s)[NC], const int (&mid)[NC
 // (chb_pairwise_distance); "bins" are then contiguous member ranges and bq is null.
 template <bool PW>
 __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int total, int pw_n,
-                                                   int pw_group, double *pw_out, int *flags)
+                                                   int pw_group, double *pw_out, int *flags, Gate gate)
 {
+    CHB_GATE(gate);
     __shared__ __attribute__((aligned(16))) double sQ[2][kKChunk][kLdsStride];
     __shared__ __attribute__((aligned(16))) double sP[2][kKChunk][kLdsStride];
     __shared__ int sMid[2][kPTile];
@@ -300,8 +301,9 @@ constexpr int kRsStride = 18;
 // W lanes per (position, bin) pair: 8 when the list fits 8 lanes (m <= 8: the shortlists average
 // ~7 candidates, so 16-lane groups would idle half their lanes), else 16.
 template <int W, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rescore_kernel(RescoreArgs a, int npairs)
+__global__ __launch_bounds__(64 * WAVES) void rescore_kernel(RescoreArgs a, int npairs, Gate gate)
 {
+    CHB_GATE(gate);
     constexpr int G = 64 / W;   // pairs per wavefront
     __shared__ __attribute__((aligned(16))) double slab[WAVES][64 + G][kRsStride];
 
@@ -409,7 +411,7 @@ void launch_topm(const TopmArgs &a, hipStream_t s)
     const int total = nqt * a.B;
     const int grid = ((total + 7) / 8) * 8;
     hipLaunchKernelGGL(tile_kernel<false>, dim3(grid), dim3(256), 0, s, a, nqt, total, 0, 0,
-                       (double *)nullptr, (int *)nullptr);
+                       (double *)nullptr, (int *)nullptr, g_gate);
 }
 
 void launch_topm_flagged(const TopmArgs &a, int *flags64, hipStream_t s)
@@ -420,7 +422,7 @@ void launch_topm_flagged(const TopmArgs &a, int *flags64, hipStream_t s)
     const int total = nqt * a.B;
     const int grid = ((total + 7) / 8) * 8;
     hipLaunchKernelGGL(tile_kernel<false>, dim3(grid), dim3(256), 0, s, a, nqt, total, 0, 0,
-                       (double *)nullptr, flags64);
+                       (double *)nullptr, flags64, g_gate);
 }
 
 void launch_rescore(const RescoreArgs &a, hipStream_t s)
@@ -430,10 +432,10 @@ void launch_rescore(const RescoreArgs &a, hipStream_t s)
     const int cap = a.active != nullptr ? 512 : INT_MAX;   // listed pairs: grid-stride over *n_active
     if (a.m <= 8) {
         constexpr int WV = 2, PB = WV * 8;      // 8 pairs per wavefront
-        hipLaunchKernelGGL((rescore_kernel<8, WV>), dim3(std::min((npairs + PB - 1) / PB, cap)), dim3(64 * WV), 0, s, a, npairs);
+        hipLaunchKernelGGL((rescore_kernel<8, WV>), dim3(std::min((npairs + PB - 1) / PB, cap)), dim3(64 * WV), 0, s, a, npairs, g_gate);
     } else {
         constexpr int WV = 4, PB = WV * 4;
-        hipLaunchKernelGGL((rescore_kernel<16, WV>), dim3(std::min((npairs + PB - 1) / PB, cap)), dim3(64 * WV), 0, s, a, npairs);
+        hipLaunchKernelGGL((rescore_kernel<16, WV>), dim3(std::min((npairs + PB - 1) / PB, cap)), dim3(64 * WV), 0, s, a, npairs, g_gate);
     }
 }
 
@@ -449,7 +451,7 @@ void launch_pairwise(const double *X, int N, int Dp, int r0, int r1, double *out
     const int total = nqt * ngroups;
     const int grid = ((total + 7) / 8) * 8;
     hipLaunchKernelGGL(tile_kernel<true>, dim3(grid), dim3(256), 0, s, a, nqt, total, N, group, out,
-                       (int *)nullptr);
+                       (int *)nullptr, g_gate);
 }
 
 }  // namespace chb
