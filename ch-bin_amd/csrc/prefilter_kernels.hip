@@ -54,6 +54,9 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+#ifndef CHB_SL_DMAREP
+#define CHB_SL_DMAREP 1   // developer experiment: issue every tile's DMA this many times
+#endif
 constexpr float kGamma = 2.5e-5f;
 constexpr float kSlack = 1e-6f;
 constexpr int kPfQ = 128;  // batch positions per workgroup (32 per wavefront)
@@ -420,7 +423,11 @@ __device__ __forceinline__ void wait_vmcnt(int n)   // n: wave-uniform
     else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
 // LDS accesses of the tile loop are issued from inline asm: while an LDS-DMA is in flight the
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
     }
     int n_w = 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) n_w += (w + 4 * j < KS) ? 1 : 0;
+    for (int j = 0; j < 3; ++j) n_w += (w + 4 * j < KS) ? CHB_SL_DMAREP : 0;
     n_w += (w == 3) ? 1 : 0;
     n_w += (UPD && w == 2) ? 1 : 0;
     const unsigned char *zall = reinterpret_cast<const unsigned char *>(a.P.Z);
@@ -551,6 +558,7 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
         unsigned char *dst_ = smem + ibuf * BUFB;                                                  \
         const size_t row_ = (size_t)irow0 + (size_t)it * kPfP;                                     \
         const unsigned char *src_ = zall + row_ * ROWB;                                            \
+        _Pragma("unroll") for (int rep_ = 0; rep_ < CHB_SL_DMAREP; ++rep_)                         \
         _Pragma("unroll") for (int j = 0; j < 3; ++j)                                              \
             if (w + 4 * j < KS)                                                                    \
                 __builtin_amdgcn_global_load_lds(src_ + src_off[j],                                \
