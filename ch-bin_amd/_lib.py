@@ -48,6 +48,8 @@ SIGNATURES = {
                                            C.POINTER(C.c_double), C.c_void_p]),
     "chb_fit_cluster": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, C.c_int64, C.c_int, C.c_int,
                                   C.c_int, _i64p, C.POINTER(C.c_int), _i64p, C.c_void_p]),
+    "chb_fit_cluster_ex": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, C.c_int64, C.c_int, C.c_int,
+                                     C.c_int, _i64p, C.POINTER(C.c_int), _i64p, C.c_void_p, C.c_void_p]),
     "chb_fit_begin": (C.c_int, [C.c_void_p, C.c_int64, _i64p, C.c_int]),
     "chb_batch_begin": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_int64, C.c_int64]),
     "chb_batch_guess": (C.c_int, [C.c_void_p, _i64p]),
@@ -208,6 +210,20 @@ class Context:
         res = (out, iters.value, changed[: iters.value])
         return res + (mind,) if want_min_dist else res
 
+    def fit_cluster_margins(self, B, initial_bins, perms, m, max_iter, batch=0):
+        """fit_cluster plus, per movable contig, runner-up minus winning hull distance at its last visit."""
+        initial = np.ascontiguousarray(initial_bins, dtype=np.int64)
+        perms = np.ascontiguousarray(perms, dtype=np.int64).reshape(max_iter, -1)
+        out = np.empty(self.N, dtype=np.int64)
+        changed = np.zeros(max(max_iter, 1), dtype=np.int64)
+        iters = C.c_int(0)
+        mind = np.empty(self.N, dtype=np.float64)
+        margin = np.empty(self.N, dtype=np.float64)
+        check(self._lib.chb_fit_cluster_ex(self._h, int(B), initial, perms, int(perms.shape[1]), int(m),
+                                           int(max_iter), int(batch), out, C.byref(iters), changed,
+                                           mind.ctypes.data, margin.ctypes.data))
+        return out, iters.value, margin
+
     # stepwise (multi-GPU driver)
     def fit_begin(self, B, initial_bins, m):
         check(self._lib.chb_fit_begin(self._h, int(B), np.ascontiguousarray(initial_bins, dtype=np.int64), int(m)))
@@ -248,7 +264,8 @@ class Context:
 
     # measurement
     def profile_enable(self, on=True):
-        check(self._lib.chb_profile_enable(self._h, 1 if on else 0))
+        """on: False / 0 off, True / 1 every kernel, 2 only the two dominant kernels."""
+        check(self._lib.chb_profile_enable(self._h, int(on)))
 
     def profile_reset(self):
         check(self._lib.chb_profile_reset(self._h))

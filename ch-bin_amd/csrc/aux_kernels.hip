@@ -198,21 +198,23 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
 // algorithm.py:47-60: min_distance = inf, min_cluster = current label; strict '>' so the lowest
 // bin wins ties and NaN never wins.
 __global__ void argmin_kernel(const double *dist, const int *lab_old, int *lab_prev,
-                              int pos_begin, int pos_end, int B, int *lab_new, double *mind,
+                              int pos_begin, int pos_end, int B, int *lab_new, double *mind, double *second,
                               int *first_change, int in_place, Gate gate)
 {
     CHB_GATE(gate);
     const int pos = pos_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= pos_end) return;
-    double best = kInf;
+    double best = kInf, runner = kInf;   // runner: smallest distance of any OTHER bin (for the margin report)
     int bc = lab_old[pos];
     const double *row = dist + (size_t)pos * B;
     for (int c = 0; c < B; ++c) {
         const double d = row[c];
-        if (best > d) { best = d; bc = c; }
+        if (best > d) { runner = best; best = d; bc = c; }
+        else if (runner > d) runner = d;
     }
     lab_new[pos] = bc;
     mind[pos] = best;
+    if (second != nullptr) second[pos] = runner;
     if (bc != lab_prev[pos]) atomicMin(first_change, pos);
     if (in_place) lab_prev[pos] = bc;   // (each position is read and written by its own thread only)
 }
@@ -474,12 +476,12 @@ void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq,
 }
 
 void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int pos_begin,
-                   int pos_end, int B, int *lab_new, double *mind, int *first_change, bool in_place,
+                   int pos_end, int B, int *lab_new, double *mind, double *second, int *first_change, bool in_place,
                    hipStream_t s)
 {
     const int n = pos_end - pos_begin;
     if (n > 0)
-        hipLaunchKernelGGL(argmin_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dist, lab_old, lab_prev, pos_begin, pos_end, B, lab_new, mind, first_change, in_place ? 1 : 0, g_gate);
+        hipLaunchKernelGGL(argmin_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dist, lab_old, lab_prev, pos_begin, pos_end, B, lab_new, mind, second, first_change, in_place ? 1 : 0, g_gate);
 }
 
 }  // namespace chb

@@ -177,7 +177,8 @@ struct chb_ctx {
     hipEvent_t fc_event[2] = {nullptr, nullptr};
     bool speculate = true;      // CHB_SPECULATE=0: never enqueue the next batch ahead of the convergence test
     bool argmin_in_place = false;   // chb_fit_cluster without exchange: argmin also stores the label to lab_prev
-    DevBuf<double> mind, dist;
+    DevBuf<double> mind, mind2, dist;   // winning hull distance, runner-up (margin report), all distances
+    bool want_margin = false;
     DevBuf<double> l0d, l1d, l2d;
     DevBuf<int> l0i, l1i, l0c, l1c, l2i, l2c;
     int round_in_batch = 0;   // rounds alternate between the list sets 1 and 2 (the other = previous)
@@ -208,7 +209,7 @@ struct chb_ctx {
     DevBuf<int> xq, xhull, xcnt;
     DevBuf<double> xdist, xalpha, xpts;
     // profiling
-    bool prof = false;
+    int prof = 0;   // 0 off, 1 every kernel, 2 only the two dominant ones (cheap enough for a timed region)
     std::map<std::string, ProfEntry> prof_acc;
     std::vector<Pending> pending;
     int64_t stats[4] = {0, 0, 0, 0};
@@ -232,7 +233,8 @@ struct Timed {
     chb_ctx *h;
     Pending p;
     bool on;
-    Timed(chb_ctx *h_, const char *name, double work) : h(h_), on(h_->prof)
+    Timed(chb_ctx *h_, const char *name, double work)
+        : h(h_), on(h_->prof == 1 || (h_->prof == 2 && (!strcmp(name, "prefilter") || !strcmp(name, "hull_qp"))))
     {
         if (!on) return;
         p.name = name; p.work = work;
@@ -273,6 +275,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->first_change.ensure(2));
     h->fc_cur = h->first_change.p;
     HIPCHK(h->mind.ensure(Kpad));
+    HIPCHK(h->mind2.ensure(Kpad));
     HIPCHK(h->dist.ensure(K * B));
     HIPCHK(h->l0d.ensure(K * B * m));
     HIPCHK(h->l1d.ensure(K * B * m));
@@ -577,7 +580,7 @@ int batch_round_dev(chb_ctx *h, int active)
         {
             Timed t(h, "argmin", (double)(hi - lo));
             launch_argmin(h->dist.p, h->lab_old.p, h->lab_prev.p, lo, hi, h->B, h->lab_new.p,
-                          h->mind.p, h->fc_cur, h->argmin_in_place, s);
+                          h->mind.p, h->want_margin ? h->mind2.p : nullptr, h->fc_cur, h->argmin_in_place, s);
         }
         h->stats[2] += (int64_t)(hi - lo) * h->B;
     }
@@ -663,7 +666,7 @@ int chb_destroy(chb_ctx *h)
                          &h->cursor, &h->memb_id, &h->cnt2, &h->bin_ptr2, &h->cursor2, &h->memb2_id,
                          &h->memb2_code, &h->perm, &h->xq, &h->xhull, &h->xcnt, &h->cand, &h->cand_cnt, &h->flags64, &h->overflow};
     for (auto *b : ib) b->release();
-    DevBuf<double> *db[] = {&h->X, &h->mind, &h->dist, &h->l0d, &h->l1d, &h->l2d, &h->xdist, &h->xalpha, &h->xpts};
+    DevBuf<double> *db[] = {&h->X, &h->mind, &h->mind2, &h->dist, &h->l0d, &h->l1d, &h->l2d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
     h->Gs.release(); h->Zs.release(); h->gq.release(); h->ms.release(); h->mu_g.release();
     h->colsum_part.release(); h->rmax.release(); h->pk.release(); h->pk2.release(); h->qn.release();
@@ -862,7 +865,19 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
                     int64_t n_move, int m, int max_iter, int batch, int64_t *labels_out,
                     int *iters_run, int64_t *changed_per_iter, double *min_dist_out)
 {
+    return chb_fit_cluster_ex(h, B, initial_bins, perms, n_move, m, max_iter, batch, labels_out, iters_run,
+                              changed_per_iter, min_dist_out, nullptr);
+}
+
+int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const int64_t *perms,
+                       int64_t n_move, int m, int max_iter, int batch, int64_t *labels_out,
+                       int *iters_run, int64_t *changed_per_iter, double *min_dist_out, double *margin_out)
+{
     if (!h || !initial_bins || !labels_out) return fail(CHB_EINVAL, "null argument");
+    if (margin_out && !min_dist_out) return fail(CHB_EINVAL, "margin_out needs min_dist_out");
+    if (margin_out && h->world > 1) return fail(CHB_EUNSUPPORTED, "margin report is single-GPU");
+    h->want_margin = margin_out != nullptr;
+    struct MarginOff { chb_ctx *h; ~MarginOff() { h->want_margin = false; } } margin_off{h};
     if (n_move > 0 && !perms) return fail(CHB_EINVAL, "perms is null");
     if (max_iter < 0 || n_move < 0 || n_move > h->N) return fail(CHB_EINVAL, "bad n_move/max_iter");
     HIPCHK(hipSetDevice(h->dev));
@@ -883,10 +898,14 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
 
     std::vector<int> prev((size_t)N), cur((size_t)N);
     for (int64_t i = 0; i < N; ++i) prev[(size_t)i] = initial_bins[i] < 0 ? -1 : (int)initial_bins[i];
-    std::vector<double> mind_host;
+    std::vector<double> mind_host, mind2_host;
     if (min_dist_out) {
         for (int64_t i = 0; i < N; ++i) min_dist_out[i] = NAN;
         mind_host.resize((size_t)Kmax);
+    }
+    if (margin_out) {
+        for (int64_t i = 0; i < N; ++i) margin_out[i] = NAN;
+        mind2_host.resize((size_t)Kmax);
     }
     int64_t assigned0 = 0;
     for (int64_t i = 0; i < N; ++i) assigned0 += prev[(size_t)i] >= 0;
@@ -1025,8 +1044,12 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
                 NCCLCHK(rccl()->AllGather(h->mind.p + h->rank * g.C, h->mind.p, (size_t)g.C, ncclFloat64, h->comm, s));
             if (min_dist_out) {
                 HIPCHK(hipMemcpyAsync(mind_host.data(), h->mind.p, sizeof(double) * K, hipMemcpyDeviceToHost, s));
+                if (margin_out)
+                    HIPCHK(hipMemcpyAsync(mind2_host.data(), h->mind2.p, sizeof(double) * K, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
                 for (int i = 0; i < K; ++i) min_dist_out[perm[t0 + i]] = mind_host[(size_t)i];
+                if (margin_out)
+                    for (int i = 0; i < K; ++i) margin_out[perm[t0 + i]] = mind2_host[(size_t)i] - mind_host[(size_t)i];
             }
             if (!inflight) {   // (otherwise the commit went out with the look-ahead)
                 rc = batch_commit_dev(h, h->lab_prev.p);
@@ -1352,7 +1375,7 @@ int chb_profile_enable(chb_ctx *h, int on)
 {
     if (!h) return fail(CHB_EINVAL, "null context");
     drain_profile(h);
-    h->prof = on != 0;
+    h->prof = on < 0 ? 0 : (on > 2 ? 1 : on);
     return CHB_OK;
 }
 

@@ -225,8 +225,9 @@ void launch_select_row(const int *labels, const double *row, int N, int c, int m
                        int *out_cnt, hipStream_t s);
 // strict-'>' argmin over bins (algorithm.py:57), first change position
 // (in_place: also lab_prev[pos] = lab_new[pos], after the comparison)
+// (second, optional: the smallest hull distance among the OTHER bins, i.e. the runner-up)
 void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int pos_begin,
-                   int pos_end, int B, int *lab_new, double *mind, int *first_change, bool in_place,
+                   int pos_end, int B, int *lab_new, double *mind, double *second, int *first_change, bool in_place,
                    hipStream_t s);
 
 

@@ -105,6 +105,13 @@ int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const in
                     int64_t n_move, int m, int max_iter, int batch, int64_t *labels_out,
                     int *iters_run, int64_t *changed_per_iter, double *min_dist_out);
 
+/* Same, additionally margin_out[N] (may be NULL; needs min_dist_out; single GPU): the runner-up bin's hull
+ * distance minus the winner's at each movable contig's last visit -- how far the argmin of
+ * algorithm.py:57 is from flipping (+inf when no other bin has a member, NaN for seeds). */
+int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const int64_t *perms,
+                       int64_t n_move, int m, int max_iter, int batch, int64_t *labels_out,
+                       int *iters_run, int64_t *changed_per_iter, double *min_dist_out, double *margin_out);
+
 /* ---- stepwise form of the same loop (one process per GPU; the host side exchanges labels
  * between ranks with RCCL/gloo between rounds).  Query slice [q_lo,q_hi) of each batch is the
  * part this rank evaluates; labels stay replicated on every rank. */
@@ -148,12 +155,15 @@ int chb_kmer_dim(int k);
 int chb_kmer_frequencies(chb_ctx *h, const unsigned char *seq, const int64_t *offsets, int64_t n, int k,
                          double *freq_out, uint32_t *counts_out);
 
-/* ---- measurement: HIP-event timing of every kernel launch on the context's stream */
+/* ---- measurement: HIP-event timing of kernel launches on the context's stream.
+ * on = 0 off, 1 every kernel, 2 only "prefilter" and "hull_qp" (the two that dominate a sweep: four
+ * event records per batch, cheap enough to leave on inside a timed region) */
 int chb_profile_enable(chb_ctx *h, int on);
 int chb_profile_reset(chb_ctx *h);
 /* kernel: "prefilter" | "prefilter_update" | "rescore" | "rescore_update" | "query_norms" |
- * "topm_fallback" | "topm_base" | "topm_update" | "hull_qp" | "argmin" | "bucket" | "pairwise" |
- * "kmer_count" */
+ * "topm_fallback" | "topm_base" | "topm_update" | "hull_qp" | "slow_path" | "argmin" | "bucket" |
+ * "pairwise" | "kmer_count".  For m <= 5 "hull_qp" is the fused selection + hull-distance kernel and
+ * "slow_path" the exact path for what it leaves over; "rescore*" then only appear for m > 5. */
 int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *launches,
                     double *work_units);
 /* counters of the last chb_fit_cluster call: [0]=batches [1]=rounds [2]=hull distances evaluated
