@@ -59,6 +59,7 @@ SIGNATURES = {
     "chb_comm_unique_id": (C.c_int, [C.c_char_p]),
     "chb_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "chb_comm_destroy": (C.c_int, [C.c_void_p]),
+    "chb_comm_init_hook": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "chb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "chb_profile_reset": (C.c_int, [C.c_void_p]),
     "chb_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
@@ -257,6 +258,25 @@ class Context:
 
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         check(self._lib.chb_comm_init(self._h, C.c_char_p(unique_id), int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+    def comm_init_hook(self, rank: int, world: int, allgather):
+        """The sharded C++ loop with a host-side exchange: allgather(send: np.uint8[bytes]) ->
+        np.uint8[world * bytes] (rank-major)."""
+        def _cb(_user, send, recv, nbytes):
+            try:
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                out = np.ascontiguousarray(allgather(src.copy()), dtype=np.uint8).reshape(-1)
+                if out.size != nbytes * world:
+                    return 1
+                C.memmove(recv, out.ctypes.data, out.size)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 2
+        self._hook_cb = self.ALLGATHER_FN(_cb)      # keep the trampoline alive
+        check(self._lib.chb_comm_init_hook(self._h, int(rank), int(world), C.cast(self._hook_cb, C.c_void_p), None))
         self.rank, self.world = int(rank), int(world)
 
     def comm_destroy(self):

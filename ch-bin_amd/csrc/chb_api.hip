@@ -216,6 +216,11 @@ struct chb_ctx {
     // multi-GPU: one context per process per GPU, RCCL communicator over all ranks
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    // host-staged exchange (chb_comm_init_hook): the same sharded loop with the all-gathers done by a
+    // caller-supplied function on host buffers -- MPI, gloo, pipes; also how two ranks can share one GPU
+    chb_allgather_fn hook = nullptr;
+    void *hook_user = nullptr;
+    std::vector<char> hook_send, hook_recv;
     bool force_gather = false;   // CHB_FORCE_GATHER=1: run the exchange path even with one rank (tests)
     // work-unit hints for the profile (pairs = queries x members streamed)
     double hint_base_members = 0.0, hint_batch_entries = 0.0;
@@ -226,6 +231,27 @@ struct chb_ctx {
     Lists Lcur() { return (round_in_batch & 1) ? L2() : L1(); }
     Lists Lprev() { return (round_in_batch & 1) ? L1() : L2(); }
 };
+
+// In-place all-gather of `count` elements per rank inside the device buffer `buf` (rank r's slice sits at
+// buf + r * count): RCCL on the context's stream, or the host-staged hook.
+static int exchange_all_gather(chb_ctx *h, void *buf, size_t count, size_t elem, ncclDataType_t dt)
+{
+    char *b = static_cast<char *>(buf);
+    if (h->hook != nullptr) {
+        const size_t bytes = count * elem;
+        h->hook_send.resize(bytes);
+        h->hook_recv.resize(bytes * (size_t)h->world);
+        HIPCHK(hipMemcpyAsync(h->hook_send.data(), b + (size_t)h->rank * bytes, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->hook(h->hook_user, h->hook_send.data(), h->hook_recv.data(), bytes) != 0)
+            return fail(CHB_EHIP, "the exchange hook reported a failure");
+        HIPCHK(hipMemcpyAsync(b, h->hook_recv.data(), bytes * (size_t)h->world, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));   // (hook_recv is reused by the next exchange)
+        return CHB_OK;
+    }
+    NCCLCHK(rccl()->AllGather(b + (size_t)h->rank * count * elem, b, count, dt, h->comm, h->stream));
+    return CHB_OK;
+}
 
 namespace {
 
@@ -886,7 +912,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     const int64_t N = h->N;
     for (int64_t i = 0; i < (int64_t)max_iter * n_move; ++i)
         if (perms[i] < 0 || perms[i] >= N) return fail(CHB_EINVAL, "perm entry out of range");
-    if (h->world > 1 && !h->comm) return fail(CHB_ESTATE, "world > 1 but chb_comm_init was not called");
+    if (h->world > 1 && !h->comm && !h->hook) return fail(CHB_ESTATE, "world > 1 but chb_comm_init was not called");
     // default batch: 8192 positions on one GPU, growing with sqrt(world): the batch-member
     // (update) work per rank is ~K^2/world, the per-rank grids ~K/world
     int Kmax = batch > 0 ? batch : 8192 * std::max(1, (int)std::lround(std::sqrt((double)h->world)));
@@ -926,7 +952,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         // The stream never drains while rounds converge at once -- the common case after sweep 1's start;
         // a failed guess switches the look-ahead off until a batch converges in one round again.
         const int world = h->world;
-        const bool xchg = h->comm != nullptr && (world > 1 || h->force_gather);
+        const bool xchg = (h->comm != nullptr || h->hook != nullptr) && (world > 1 || h->force_gather);
         const bool can_spec = h->speculate && h->fused && !xchg && min_dist_out == nullptr;
         struct Geom { int64_t t0; int K, q_lo, q_hi, C; };
         auto geom_at = [&](int64_t t0) {
@@ -944,7 +970,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         // after a round's kernels: (multi-GPU: exchange) + first-changed position on its way to the host
         auto finish_round = [&](const Geom &g, int active, int slot) -> int {
             if (xchg) {
-                NCCLCHK(rccl()->AllGather(h->lab_new.p + h->rank * g.C, h->lab_new.p, (size_t)g.C, ncclInt32, h->comm, s));
+                { const int r_ = exchange_all_gather(h, h->lab_new.p, (size_t)g.C, sizeof(int), ncclInt32); if (r_) return r_; }
                 launch_fill_i32(h->fc_cur, g.K, 1, s);
                 launch_first_change(h->lab_new.p, h->lab_prev.p, active, g.K, h->fc_cur, s);
             }
@@ -976,7 +1002,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             if (h->fused && !h->lists_valid) launch_guess_near(h->tau.p, h->lab_old.p, g.q_lo, g.q_hi, h->B, h->Kcap, h->lab_prev.p, s);
             else launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, g.q_lo, g.q_hi, h->B, h->m, h->Kcap, h->lab_prev.p, s);
             if (xchg)
-                NCCLCHK(rccl()->AllGather(h->lab_prev.p + h->rank * g.C, h->lab_prev.p, (size_t)g.C, ncclInt32, h->comm, s));
+                { const int r_ = exchange_all_gather(h, h->lab_prev.p, (size_t)g.C, sizeof(int), ncclInt32); if (r_) return r_; }
             r = batch_round_dev(h, 0);
             if (r) return r;
             return finish_round(g, 0, slot);
@@ -1041,7 +1067,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 spec_ok = can_spec;
             }
             if (min_dist_out && xchg)
-                NCCLCHK(rccl()->AllGather(h->mind.p + h->rank * g.C, h->mind.p, (size_t)g.C, ncclFloat64, h->comm, s));
+                { const int r_ = exchange_all_gather(h, h->mind.p, (size_t)g.C, sizeof(double), ncclFloat64); if (r_) return r_; }
             if (min_dist_out) {
                 HIPCHK(hipMemcpyAsync(mind_host.data(), h->mind.p, sizeof(double) * K, hipMemcpyDeviceToHost, s));
                 if (margin_out)
@@ -1295,9 +1321,22 @@ int chb_comm_init(chb_ctx *h, const char *id128, int rank, int world)
     return CHB_OK;
 }
 
+int chb_comm_init_hook(chb_ctx *h, int rank, int world, chb_allgather_fn fn, void *user)
+{
+    if (!h || !fn) return fail(CHB_EINVAL, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(CHB_EINVAL, "bad rank/world");
+    HIPCHK(hipSetDevice(h->dev));
+    if (h->comm && rccl()) { (void)rccl()->CommDestroy(h->comm); h->comm = nullptr; }
+    h->hook = fn; h->hook_user = user;
+    h->rank = rank; h->world = world;
+    h->Kcap = 0;
+    return CHB_OK;
+}
+
 int chb_comm_destroy(chb_ctx *h)
 {
     if (!h) return CHB_OK;
+    h->hook = nullptr; h->hook_user = nullptr;
     if (h->comm && rccl()) {
         (void)hipSetDevice(h->dev);
         (void)hipStreamSynchronize(h->stream);

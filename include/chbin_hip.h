@@ -22,6 +22,7 @@
 #ifndef CHBIN_HIP_H
 #define CHBIN_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -138,6 +139,12 @@ int chb_fit_labels(chb_ctx *h, int64_t *labels_out);
 int chb_comm_unique_id(char *out128);
 int chb_comm_init(chb_ctx *h, const char *id128, int rank, int world);
 int chb_comm_destroy(chb_ctx *h);
+/* The same sharded loop with the exchange done by the caller: fn(user, send, recv, bytes) must deliver the
+ * `bytes` of every rank's `send` into recv[rank * bytes ..] on every rank (an all-gather on HOST buffers;
+ * return 0 on success).  For transports other than RCCL (MPI, gloo, pipes) -- and the way two ranks can
+ * share one GPU, which RCCL refuses.  Called from inside chb_fit_cluster, between device synchronisations. */
+typedef int (*chb_allgather_fn)(void *user, const void *send, void *recv, size_t bytes);
+int chb_comm_init_hook(chb_ctx *h, int rank, int world, chb_allgather_fn fn, void *user);
 
 /* ---- feature assembly: canonical k-mer frequency vectors.
  * Replaces the external seq2vec run of ch_bin/core/features/kmer_count.py:65-107 (and the

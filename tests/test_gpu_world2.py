@@ -1,0 +1,90 @@
+"""World-size-2 run of the SHARDED C++ loop (chb_fit_cluster with q_lo/q_hi slices and all-gathers between
+rounds, csrc/chb_api.hip) on one GPU: two processes, one context each, exchange through the host-staged hook
+(chb_comm_init_hook) carried by gloo.  RCCL refuses two ranks on one device, so this is how the loop that the
+driver runs over RCCL on 8 GPUs is exercised with more than one rank before it gets there: same slices, same
+exchange points, same first-change logic -- only the transport differs."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+import torch
+import torch.distributed as dist
+import chbin_amd
+from chbin_amd import _lib, synth
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+def allgather(send):                      # np.uint8[bytes] -> np.uint8[world * bytes]
+    t = torch.from_numpy(send)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return torch.cat(outs).numpy()
+
+res = {}
+for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate([
+        (900, 136, 8, 5, 4, 6e-3, 0.6, 8, 200),        # overlapping bins: several rounds per batch
+        (3000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 0),   # SURVEY 8(d) generator
+        (700, 40, 6, 15, 3, 9e-3, 0.5, 20, 150)]):     # m = 15: list-based path
+    X, initial, _ = synth.make_synthetic(N, D, B, seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
+    perms = synth.draw_permutations(initial, iters, seed=0)
+    ctx = _lib.Context(0)
+    ctx.comm_init_hook(rank, world, allgather)
+    ctx.set_samples(X)
+    lab, its, ch, mind = ctx.fit_cluster(B, initial, perms, m, iters, batch=batch, want_min_dist=True)
+    st = ctx.fit_stats()
+    res[f"lab{case}"] = lab; res[f"its{case}"] = its; res[f"mind{case}"] = mind
+    res[f"evaluated{case}"] = st["hull_evaluated"]; res[f"needed{case}"] = st["hull_needed"]
+    res[f"rounds{case}"] = st["rounds"]
+    ctx.comm_destroy()
+    ctx.close()
+np.savez(out, **res)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_cpp_loop_world2_one_gpu():
+    from oracle import oracle as O
+    import chbin_amd
+    world = 2
+    with tempfile.TemporaryDirectory() as td:
+        script = os.path.join(td, "worker.py")
+        open(script, "w").write(WORKER)
+        port = str(29500 + os.getpid() % 2000)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, script, ROOT, str(r), str(world), port,
+                                   os.path.join(td, f"out{r}.npz")], env=env) for r in range(world)]
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        outs = [np.load(os.path.join(td, f"out{r}.npz")) for r in range(world)]
+    for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate([
+            (900, 136, 8, 5, 4, 6e-3, 0.6, 8, 200), (3000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 0),
+            (700, 40, 6, 15, 3, 9e-3, 0.5, 20, 150)]):
+        X, initial, _ = chbin_amd.synth.make_synthetic(N, D, B, seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
+        perms = chbin_amd.synth.draw_permutations(initial, iters, seed=0)
+        want, its_o, _ = O.fit_cluster(X, B, initial, perms, m, iters)
+        labels = initial.copy()
+        for k in range(its_o):
+            labels, md = O.sweep(X, B, labels, perms[k], m)
+        for r in range(world):
+            assert int(outs[r][f"its{case}"]) == its_o
+            assert np.array_equal(outs[r][f"lab{case}"], want)                       # every rank: the full result
+            assert np.allclose(outs[r][f"mind{case}"][perms[its_o - 1]], md, rtol=0, atol=1e-9)
+        # the ranks evaluated DISJOINT slices: together exactly what one rank alone would have evaluated
+        ev = [int(outs[r][f"evaluated{case}"]) for r in range(world)]
+        needed = int(outs[0][f"needed{case}"])
+        assert all(e > 0 for e in ev) and sum(ev) >= needed
+        assert max(ev) <= 0.75 * sum(ev)                                             # neither rank did (nearly) all of it
+        assert int(outs[0][f"rounds{case}"]) == int(outs[1][f"rounds{case}"])
