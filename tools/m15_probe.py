@@ -1,0 +1,26 @@
+"""Developer probe: m = 15 sweep timing, corral-overflow counts, parity against the oracle on a prefix."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import chbin_amd  # noqa: E402,F401
+from chbin_amd import _lib, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+N, D, B, m = 100000, 136, 64, int(sys.argv[1]) if len(sys.argv) > 1 else 15
+X, initial, true = synth.make_synthetic(N, D, B, seed=0)
+perms = synth.draw_permutations(initial, 3, seed=0)
+ctx = _lib.Context(0)
+ctx.set_samples(X)
+lab, _, _ = ctx.fit_cluster(B, initial, perms[:1], m, 1)
+t = time.perf_counter()
+for _ in range(3):
+    lab, _, _ = ctx.fit_cluster(B, initial, perms[:1], m, 1)
+dt = (time.perf_counter() - t) / 3
+print(f"m={m}: {dt*1e3:.2f} ms/sweep, slow pairs (last round) {ctx.counter('slow_pairs_last_round')}, overflow {ctx.counter('prefilter_overflow')}")
+ns = 40
+lab_o, _ = O.sweep(X, B, initial, perms[0][:ns], m)
+print("prefix parity:", np.array_equal(lab_o[perms[0][:ns]], lab[perms[0][:ns]]))
