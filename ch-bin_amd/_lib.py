@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CHBIN_LIB", os.path.join(_HERE, "libchbin_hip.so"))   # CHBIN_LIB: developer override
 
-CHB_MAX_NEIGHBORS = 16
+CHB_MAX_NEIGHBORS = 64
 
 _lib = None
 _lock = threading.Lock()

@@ -202,6 +202,7 @@ struct chb_ctx {
     // fused selection + hull distance (m <= 5): batch-entry candidates of this / the previous round,
     // the base stage's tau (bound of the m-th nearest distance), the exact path's work list
     bool fused = false, allow_fused = true;
+    bool pf_fit = false;        // this fit uses the shortlist stage (use_prefilter, D <= 160, m <= 16)
     bool lists_valid = false;   // the open batch was started with need_lists (chb_topm_per_bin)
     DevBuf<int> candu[2], candu_cnt[2], slow, n_slow;
     DevBuf<float> tau;
@@ -321,7 +322,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->cursor2.ensure(B));
     HIPCHK(h->memb2_id.ensure(2 * K));
     HIPCHK(h->memb2_code.ensure(2 * K));
-    if (h->use_prefilter && h->shadow_ok) {
+    if (h->pf_fit) {
         HIPCHK(h->cand.ensure(K * B * (size_t)kCandCap));
         HIPCHK(h->cand_cnt.ensure(K * B));
         HIPCHK(h->active.ensure(K * B));
@@ -353,9 +354,12 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     if (B <= 0) return fail(CHB_EINVAL, "num_clusters must be positive");
     if (B > 8192) return fail(CHB_EUNSUPPORTED, "more than 8192 bins (per-block LDS histograms of the CSR build)");
     if (m < 1 || m > CHB_MAX_NEIGHBORS)
-        return fail(CHB_EUNSUPPORTED, "num_neighbors must be in [1, 16]");
+        return fail(CHB_EUNSUPPORTED, "num_neighbors must be in [1, 64]");
     h->B = (int)B; h->m = m;
-    h->fused = h->allow_fused && h->use_prefilter && h->shadow_ok && h->pf_base && h->pf_update && fused_supported(m);
+    // the fp16 shortlist stage and the tuned kernels hold lists of up to 16 entries; beyond that the plain
+    // one-wavefront-per-problem kernels run (brute-force selection, LDS-resident solver)
+    h->pf_fit = h->use_prefilter && h->shadow_ok && m <= kMaxM;
+    h->fused = h->allow_fused && h->pf_fit && h->pf_base && h->pf_update && fused_supported(m);
     std::vector<int> lab((size_t)h->N);
     for (int64_t i = 0; i < h->N; ++i) {
         const int64_t v = initial[i];
@@ -370,7 +374,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     HIPCHK(h->bin_ptr.ensure((size_t)B + 1));
     HIPCHK(h->cursor.ensure((size_t)B));
     HIPCHK(h->memb_id.ensure((size_t)h->N));
-    if (h->use_prefilter && h->shadow_ok) {
+    if (h->pf_fit) {
         // Bin centres for the shortlist stage: the mean of each bin's initially labelled members
         // (the seeds), fixed for the whole fit -- any fixed point keeps the bounds valid, one near
         // the bin keeps them tight.  Then every labelled sample's shadow row against its own bin.
@@ -409,7 +413,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
     a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
     a.in = Lists{nullptr, nullptr, nullptr};
     a.out = h->L0();
-    if (h->use_prefilter && h->pf_base && h->shadow_ok && h->cand.p) {
+    if (h->pf_fit && h->pf_base && h->cand.p) {
         // two-stage exact selection: fp16 matrix-core shortlist, exact fp64 on the shortlist,
         // brute force only for (query tile, bin) pairs whose shortlist overflowed
         const int nq64 = (q_hi - q_lo + kQTile - 1) / kQTile;
@@ -457,7 +461,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         }
     } else {
         Timed t(h, "topm_base", (double)(q_hi - q_lo) * h->hint_base_members);
-        launch_topm(a, s);
+        if (h->m > kMaxM) launch_topm_generic(a, s); else launch_topm(a, s);
     }
     HIPCHK(hipGetLastError());
     h->batch_open = true;
@@ -543,7 +547,7 @@ int batch_round_dev(chb_ctx *h, int active)
                 launch_hull_qp(q, s);
             }
         } else {
-        if (h->use_prefilter && h->pf_update && h->shadow_ok && h->cand.p) {
+        if (h->pf_fit && h->pf_update && h->cand.p) {
             // batch members that can displace an entry of the base list: fp16 shortlist against
             // the exact m-th distance, exact rescoring seeded with the base list
             // (fit rounds only produce the "earlier" / "later" eligibility codes, which have the affine
@@ -590,7 +594,7 @@ int batch_round_dev(chb_ctx *h, int active)
             }
         } else {
             Timed t(h, "topm_update", (double)(hi - lo) * h->hint_batch_entries);
-            launch_topm(a, s);
+            if (h->m > kMaxM) launch_topm_generic(a, s); else launch_topm(a, s);
         }
         QpArgs q{};
         q.X = h->X.p; q.D = h->D; q.Dp = h->Dp; q.bq = h->bq_cur; q.pos_begin = lo; q.pos_end = hi;
@@ -600,7 +604,7 @@ int batch_round_dev(chb_ctx *h, int active)
         q.metric = h->metric;
         {
             Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
-            launch_hull_qp(q, s);
+            if (h->m > kMaxM) launch_hull_generic(q, s); else launch_hull_qp(q, s);
         }
         }   // list-based paths
         {
@@ -619,7 +623,7 @@ int batch_round_dev(chb_ctx *h, int active)
 int batch_commit_dev(chb_ctx *h, const int *final_dev)
 {
     hipStream_t s = h->stream;
-    if (h->use_prefilter && h->shadow_ok && h->centers.p)
+    if (h->pf_fit && h->centers.p)
         // final labels out, batch marks cleared, and the members' shadow rows recomputed against their
         // new bin's centre: one launch
         launch_sample_shadow(h->X.p, h->D, h->Dp, h->bq_cur, h->K, h->labels.p, h->B, h->centers.p, h->mu_g.p,
@@ -916,6 +920,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     // default batch: 8192 positions on one GPU, growing with sqrt(world): the batch-member
     // (update) work per rank is ~K^2/world, the per-rank grids ~K/world
     int Kmax = batch > 0 ? batch : 8192 * std::max(1, (int)std::lround(std::sqrt((double)h->world)));
+    if (m > kMaxM && batch <= 0) Kmax = std::min(Kmax, 512);   // the plain kernels: one wavefront per (contig, bin)
     if (Kmax > n_move) Kmax = (int)std::max<int64_t>(n_move, 1);
     rc = ensure_batch_buffers(h, Kmax);
     if (rc) return rc;
@@ -1144,7 +1149,7 @@ int chb_topm_per_bin(chb_ctx *h, const int64_t *labels, int64_t B, int m, const 
         a.in = h->L0(); a.out = h->L1();
         {
             Timed t(h, "topm_update", (double)K);
-            launch_topm(a, s);
+            if (h->m > kMaxM) launch_topm_generic(a, s); else launch_topm(a, s);
         }
         HIPCHK(hipGetLastError());
         const size_t nB = (size_t)h->B, nm = (size_t)m, cap = (size_t)h->Kcap;
@@ -1176,7 +1181,7 @@ static int hull_indexed(chb_ctx *h, const double *Xdev, int D, int Dp, int64_t n
                         const int64_t *query_idx, int64_t P, const int64_t *hull_idx, int m_max,
                         double *dist, double *alpha)
 {
-    if (m_max < 1 || m_max > CHB_MAX_NEIGHBORS) return fail(CHB_EUNSUPPORTED, "m_max must be in [1, 16]");
+    if (m_max < 1 || m_max > CHB_MAX_NEIGHBORS) return fail(CHB_EUNSUPPORTED, "m_max must be in [1, 64]");
     if (P <= 0) return CHB_OK;
     hipStream_t s = h->stream;
     // compact each vertex list (padding may sit anywhere at the ABI) and remember the slots
@@ -1205,8 +1210,12 @@ static int hull_indexed(chb_ctx *h, const double *Xdev, int D, int Dp, int64_t n
     HIPCHK(hipMemcpyAsync(h->xhull.p, hx.data(), sizeof(int) * P * m_max, hipMemcpyHostToDevice, s));
     {
         Timed t(h, "hull_qp", (double)P);
-        launch_hull_qp_indexed(Xdev, D, Dp, h->xq.p, h->xhull.p, h->xcnt.p, (int)P, m_max, h->metric, h->xdist.p,
-                               h->xalpha.p, s);
+        if (m_max > kMaxM)
+            launch_hull_generic_indexed(Xdev, D, Dp, h->xq.p, h->xhull.p, h->xcnt.p, (int)P, m_max, h->metric,
+                                        h->xdist.p, h->xalpha.p, s);
+        else
+            launch_hull_qp_indexed(Xdev, D, Dp, h->xq.p, h->xhull.p, h->xcnt.p, (int)P, m_max, h->metric, h->xdist.p,
+                                   h->xalpha.p, s);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(dist, h->xdist.p, sizeof(double) * P, hipMemcpyDeviceToHost, s));
@@ -1242,7 +1251,7 @@ int chb_hull_distance_points(chb_ctx *h, const double *x, const double *pts, int
     if (!h || !x || !dist || (m > 0 && !pts)) return fail(CHB_EINVAL, "null argument");
     if (m < 0 || D <= 0) return fail(CHB_EINVAL, "bad m or D");
     if (m == 0) { *dist = INFINITY; return CHB_OK; }
-    if (m > CHB_MAX_NEIGHBORS) return fail(CHB_EUNSUPPORTED, "more than 16 hull vertices");
+    if (m > CHB_MAX_NEIGHBORS) return fail(CHB_EUNSUPPORTED, "more than 64 hull vertices");
     HIPCHK(hipSetDevice(h->dev));
     const int Dp = (int)((D + kKChunk - 1) / kKChunk) * kKChunk;
     std::vector<double> rows((size_t)(m + 1) * Dp, 0.0);

@@ -17,7 +17,8 @@ struct Gate {
 extern thread_local Gate g_gate;   // what every launch_* helper passes to its kernels
 #define CHB_GATE(g) do { if ((g).flag != nullptr && *(g).flag < (g).need) return; } while (0)
 
-constexpr int kMaxM = 16;       // CHB_MAX_NEIGHBORS
+constexpr int kMaxM = 16;       // largest num_neighbors of the tuned kernels
+constexpr int kMaxMGeneric = 64; // CHB_MAX_NEIGHBORS: beyond kMaxM the plain one-wavefront-per-problem kernels run
 constexpr int kQTile = 64;      // queries per workgroup tile
 constexpr int kPTile = 64;      // bin members per workgroup tile
 constexpr int kKChunk = 8;      // feature columns staged per pipeline step
@@ -51,6 +52,8 @@ struct TopmArgs {
 };
 
 void launch_topm(const TopmArgs &a, hipStream_t s);
+// the same for 16 < m <= kMaxMGeneric: one wavefront per (bin, query), no tiling (slow; see topm_kernels.hip)
+void launch_topm_generic(const TopmArgs &a, hipStream_t s);
 // same, but only work items (bin, query tile of 64) whose flag is set run; the rest exit at once
 void launch_topm_flagged(const TopmArgs &a, int *flags64, hipStream_t s);   // (clears the flags it serves)
 
@@ -188,6 +191,12 @@ bool fused_supported(int m);
 void launch_hull_select_qp(const FusedArgs &a, hipStream_t s);
 
 // explicit problems: query sample q[p], hull_idx[p][m_max] compacted, hull_cnt[p] vertices
+// 16 < m <= kMaxMGeneric: one wavefront per problem, Gram and the solver's inverse in LDS (slow, see
+// qp_kernels.hip); same argument meaning as launch_hull_qp / launch_hull_qp_indexed
+void launch_hull_generic(const QpArgs &a, hipStream_t s);
+void launch_hull_generic_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,
+                                 const int *hull_cnt, int P, int m_max, int metric, double *dist,
+                                 double *alpha, hipStream_t s);
 void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,
                             const int *hull_cnt, int P, int m_max, int metric, double *dist,
                             double *alpha, hipStream_t s);

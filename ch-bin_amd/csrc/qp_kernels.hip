@@ -1059,6 +1059,266 @@ __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// num_neighbors > 16 (no cap in the reference: algorithm.py:17, cli/clustering.py:118-120): the plain form,
+// ONE wavefront per problem, up to 64 vertices.  Lane i owns vertex i: row i of the shifted Gram Q and of the
+// inverse H of the lifted support Gram (both in LDS, [64][65] doubles) and its weight alpha_i.  The same Wolfe
+// iteration and the same bordering / Schur updates as hull_qp16_kernel, with loops over the vertex count and
+// LDS rows where that kernel has 16-entry register arrays and shuffles.  Slow by design.
+constexpr int kGenN = 64, kGenLd = 65;
+
+struct GenLds {
+    double Q[kGenN][kGenLd];
+    double H[kGenN][kGenLd];
+    double va[kGenN], vu[kGenN];
+};
+
+__device__ __forceinline__ double wave_sum64(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// smallest key, ties to the lowest lane; all keys +inf gives idx = -1
+__device__ __forceinline__ void wave_argmin64(double key, int lane, double &kmin, int &idx)
+{
+    kmin = key;
+    idx = key < kInf ? lane : -1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ok = __shfl_xor(kmin, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        if (oi >= 0 && (idx < 0 || ok < kmin || (ok == kmin && oi < idx))) { kmin = ok; idx = oi; }
+    }
+}
+__device__ __forceinline__ void gen_sync()
+{
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+}
+
+// vertex v enters the support: false (and no change) when it is affinely dependent on it
+__device__ __forceinline__ bool gen_insert(GenLds &L, int n, double s, unsigned long long &S, int v, int lane)
+{
+    const bool in = (S >> lane) & 1ull;
+    const double a_own = (lane < n) ? L.Q[v][lane] + s : 0.0;
+    const double avv = L.Q[v][v] + s;
+    L.va[lane] = in ? a_own : 0.0;
+    gen_sync();
+    double u = 0.0;
+    if (in)
+        for (int j = 0; j < n; ++j) u = fma(L.H[lane][j], L.va[j], u);   // (H is zero outside the support)
+    double delta = avv - wave_sum64(in ? a_own * u : 0.0);
+    if (!(delta > 1e-6 * avv)) {
+        // small pivot: one step of iterative refinement against the original rows of Q (see inv16_insert)
+        L.vu[lane] = in ? u : 0.0;
+        gen_sync();
+        double r = a_own;
+        if (in)
+            for (int j = 0; j < n; ++j)
+                if ((S >> j) & 1ull) r = fma(-(L.Q[lane][j] + s), L.vu[j], r);
+        gen_sync();
+        L.vu[lane] = in ? r : 0.0;
+        gen_sync();
+        double du = 0.0;
+        if (in)
+            for (int j = 0; j < n; ++j) du = fma(L.H[lane][j], L.vu[j], du);
+        u += du;
+        delta = avv - wave_sum64(in ? a_own * u : 0.0);
+        gen_sync();
+    }
+    if (!(delta > 1e-13 * avv)) return false;
+    const double inv = 1.0 / delta;
+    L.vu[lane] = in ? u : 0.0;
+    gen_sync();
+    if (in) {
+        const double ui = u * inv;
+        for (int j = 0; j < n; ++j)
+            if ((S >> j) & 1ull) L.H[lane][j] = fma(ui, L.vu[j], L.H[lane][j]);
+        L.H[lane][v] = -ui;
+    }
+    if (lane == v) {
+        for (int j = 0; j < n; ++j) L.H[v][j] = ((S >> j) & 1ull) ? -L.vu[j] * inv : 0.0;
+        L.H[v][v] = inv;
+    }
+    S |= 1ull << v;
+    gen_sync();
+    return true;
+}
+
+// vertex r (in the support) leaves
+__device__ __forceinline__ void gen_remove(GenLds &L, int n, unsigned long long &S, int r, int lane)
+{
+    const bool in = (S >> lane) & 1ull;
+    const double hrr = L.H[r][r];
+    if (in && lane != r) {
+        const double f = L.H[lane][r] / hrr;
+        for (int j = 0; j < n; ++j)
+            if (j != r) L.H[lane][j] = fma(-f, L.H[r][j], L.H[lane][j]);
+        L.H[lane][r] = 0.0;
+    }
+    gen_sync();
+    if (lane == r)
+        for (int j = 0; j < n; ++j) L.H[r][j] = 0.0;
+    S &= ~(1ull << r);
+    gen_sync();
+}
+
+// weight of my vertex in the affine minimiser on the support; false if the weights do not sum > 0
+__device__ __forceinline__ bool gen_beta(GenLds &L, int n, unsigned long long S, int lane, double &beta)
+{
+    double b = 0.0;
+    if ((S >> lane) & 1ull)
+        for (int j = 0; j < n; ++j) b += L.H[lane][j];
+    const double sum = wave_sum64(b);
+    beta = b / sum;
+    return sum > 0.0;
+}
+
+template <bool INDEXED>
+__global__ __launch_bounds__(64) void hull_generic_kernel(QpArgs a, int nprob, const int *xq, const int *xhull,
+                                                        const int *xn, int xm, double *xdist, double *xalpha, Gate gate)
+{
+    CHB_GATE(gate);
+    extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
+    GenLds &L = *reinterpret_cast<GenLds *>(gen_smem);
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    if (g >= nprob) return;
+    const int m = INDEXED ? xm : a.m;
+    int n = 0, id = -1, qid = 0, pos = 0, c = 0;
+    if (INDEXED) {
+        qid = xq[g];
+        n = xn[g];
+        if (lane < n) id = xhull[(size_t)g * m + lane];
+    } else {
+        pos = a.pos_begin + g / a.B; c = g - (g / a.B) * a.B;
+        qid = a.bq[pos];
+        const size_t slot = (size_t)c * a.Kcap + pos;
+        n = a.lists.cnt[slot];
+        if (lane < n) id = a.lists.idx[slot * m + lane];
+        if (a.prev.idx != nullptr) {   // unchanged vertex list: keep the stored distance
+            const bool changed = a.prev.cnt[slot] != n || (lane < n && a.prev.idx[slot * m + lane] != id);
+            if (__ballot(changed) == 0ull) return;
+        }
+    }
+    const bool mine = lane < n;
+    double alpha = 0.0, val = kInf;
+    if (n > 0) {
+        // ---- shifted Gram: lane i computes row i (its own row against every vertex j <= i, mirrored)
+        const double *xrow = a.X + (size_t)qid * a.Dp;
+        const double *vi = a.X + (size_t)(mine ? id : qid) * a.Dp;
+        for (int j = 0; j < n; ++j) {
+            const int idj = __shfl(id, j, 64);
+            const double *vj = a.X + (size_t)idj * a.Dp;
+            double acc = 0.0;
+            for (int k = 0; k < a.Dp; ++k) {
+                const double xk = xrow[k];
+                acc = fma(vi[k] - xk, vj[k] - xk, acc);
+            }
+            if (mine) L.Q[lane][j] = acc;
+        }
+        for (int j = 0; j < kGenN; ++j) L.H[lane][j] = 0.0;
+        gen_sync();
+        const double diag = mine ? L.Q[lane][lane] : 0.0;
+        double scale = diag;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) scale = fmax(scale, __shfl_xor(scale, off, 64));
+        unsigned long long S = 0ull, banned = 0ull;
+        if (!(scale > 0.0)) {   // every vertex coincides with the query (or NaN input)
+            alpha = lane == 0 ? 1.0 : 0.0;
+            val = scale == 0.0 ? 0.0 : scale;
+        } else if (a.metric == 0) {
+            double best;
+            int i0;
+            wave_argmin64(mine ? diag : kInf, lane, best, i0);
+            (void)gen_insert(L, n, scale, S, i0, lane);   // a single vertex is always independent
+            alpha = lane == i0 ? 1.0 : 0.0;
+            const double tol = 1.4210854715202004e-14 * scale;  // 64 eps * scale
+            for (int it = 0; it < 3 * kGenN + 8; ++it) {
+                L.va[lane] = alpha;
+                gen_sync();
+                double gi = 0.0;
+                if (mine)
+                    for (int j = 0; j < n; ++j) gi = fma(L.Q[lane][j], L.va[j], gi);
+                val = wave_sum64(alpha * gi);
+                gen_sync();
+                double gmin;
+                int jb;
+                wave_argmin64((mine && !(((S | banned) >> lane) & 1ull)) ? gi : kInf, lane, gmin, jb);
+                if (jb < 0 || !(gmin < val - tol)) break;
+                if (!gen_insert(L, n, scale, S, jb, lane)) {
+                    banned |= 1ull << jb;
+                    continue;
+                }
+                for (int mi = 0; mi <= n; ++mi) {
+                    double beta;
+                    if (!gen_beta(L, n, S, lane, beta)) {   // (degenerate weights: give the vertex up)
+                        if ((S >> jb) & 1ull) gen_remove(L, n, S, jb, lane);
+                        banned |= 1ull << jb;
+                        break;
+                    }
+                    const bool in = (S >> lane) & 1ull;
+                    const bool bad = in && !(beta > 0.0);
+                    if (__ballot(bad) == 0ull) {
+                        alpha = in ? beta : 0.0;
+                        break;
+                    }
+                    const double den = alpha - beta;
+                    double theta;
+                    int kr;
+                    wave_argmin64(bad ? (den > 0.0 ? alpha / den : 0.0) : kInf, lane, theta, kr);
+                    const double vnew = alpha + theta * (beta - alpha);
+                    alpha = (in && lane != kr) ? vnew : 0.0;
+                    gen_remove(L, n, S, kr, lane);
+                    if (kr == jb) banned |= 1ull << jb;
+                }
+            }
+            L.va[lane] = alpha;
+            gen_sync();
+            double gi = 0.0;
+            if (mine)
+                for (int j = 0; j < n; ++j) gi = fma(L.Q[lane][j], L.va[j], gi);
+            val = wave_sum64(alpha * gi);
+        } else {
+            // distance to the AFFINE hull: greedy maximal affinely independent subset (affine_min_norm)
+            for (int k = 0; k < n; ++k) (void)gen_insert(L, n, scale, S, k, lane);
+            double beta = 0.0;
+            const bool okb = S != 0ull && gen_beta(L, n, S, lane, beta);
+            alpha = (okb && ((S >> lane) & 1ull)) ? beta : 0.0;
+            if (!okb) alpha = lane == 0 ? 1.0 : 0.0;
+            L.va[lane] = alpha;
+            gen_sync();
+            double gi = 0.0;
+            if (mine)
+                for (int j = 0; j < n; ++j) gi = fma(L.Q[lane][j], L.va[j], gi);
+            val = wave_sum64(alpha * gi);
+        }
+    }
+    const double dist = n <= 0 ? kInf : sqrt(fmax(val, 0.0));
+    if (INDEXED) {
+        if (lane == 0) xdist[g] = dist;
+        if (xalpha && lane < m) xalpha[(size_t)g * m + lane] = alpha;
+    } else if (lane == 0) {
+        a.dist[(size_t)pos * a.B + c] = dist;
+    }
+}
+
+template <bool INDEXED>
+void launch_generic(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull, const int *xn, double *xdist,
+                    double *xalpha, hipStream_t s)
+{
+    if (nprob <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hull_generic_kernel<INDEXED>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GenLds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((hull_generic_kernel<INDEXED>), dim3(nprob), dim3(64), sizeof(GenLds), s, a, nprob, xq, xhull, xn, m,
+                       xdist, xalpha, g_gate);
+}
+
 template <int M, int WV, bool INDEXED>
 void launch_one(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull, const int *xn,
                 double *xdist, double *xalpha, hipStream_t s)
@@ -1101,6 +1361,20 @@ void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
     constexpr int WV = 4;
     const int grid = (nprob + 64 * WV - 1) / (64 * WV);
     hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
+}
+
+void launch_hull_generic(const QpArgs &a, hipStream_t s)
+{
+    launch_generic<false>(a, (a.pos_end - a.pos_begin) * a.B, a.m, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+void launch_hull_generic_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,
+                                 const int *hull_cnt, int P, int m_max, int metric, double *dist,
+                                 double *alpha, hipStream_t s)
+{
+    QpArgs a{};
+    a.X = X; a.D = D; a.Dp = Dp; a.m = m_max; a.metric = metric;
+    launch_generic<true>(a, P, m_max, q, hull_idx, hull_cnt, dist, alpha, s);
 }
 
 void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,

@@ -401,7 +401,68 @@ __global__ __launch_bounds__(64 * WAVES) void rescore_kernel(RescoreArgs a, int 
     }   // grid-stride loop
 }
 
+// ---------------------------------------------------------------------------------------------
+// num_neighbors > 16 (the reference puts no cap on AlgoNumNeighbors: algorithm.py:17,
+// cli/clustering.py:118-120): a plain form of the same selection with no tiling at all -- one wavefront per
+// (bin, query), one member per lane, every lane sums its own row in feature order (cdist rounding), the list of
+// up to 64 entries lives one entry per lane.  Orders of magnitude slower than the tiled kernel; it exists so
+// that such a configuration runs instead of being refused.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void select_generic_kernel(TopmArgs a, int nq, Gate gate)
+{
+    CHB_GATE(gate);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long item = (long long)blockIdx.x * WAVES + w;
+    if (item >= (long long)nq * a.B) return;
+    const int c = (int)(item / nq), qpos = a.pos_begin + (int)(item - (long long)c * nq);
+    const size_t slot = (size_t)c * a.Kcap + qpos;
+    const int m = a.m;
+    const double *xq = a.X + (size_t)a.bq[qpos] * a.Dp;
+    double ld = kInf, tau = kInf;
+    int li = INT_MAX, lc = 0;
+    if (a.in.d != nullptr) {
+        lc = a.in.cnt[slot];
+        if (lane < lc) { ld = a.in.d[slot * m + lane]; li = a.in.idx[slot * m + lane]; }
+        if (lc >= m) tau = tau_from(a.in.d[slot * m + m - 1]);
+    }
+    const int mb = a.bin_ptr[c], nmem = a.bin_ptr[c + 1] - mb;
+    for (int base = 0; base < nmem; base += 64) {
+        const int e = base + lane;
+        bool ok = e < nmem;
+        const int mid = ok ? a.memb_id[mb + e] : 0;
+        if (ok && a.memb_code != nullptr) {
+            const int code = a.memb_code[mb + e];
+            if (code > 0) ok = qpos > code - 1;
+            else if (code <= -(1 << 30)) ok = qpos != -(1 << 30) - code;
+            else if (code < 0) ok = qpos < -code - 1;
+        }
+        const double *row = a.X + (size_t)mid * a.Dp;
+        double acc = 0.0;
+        for (int k = 0; k < a.Dp; ++k) {
+            const double df = xq[k] - row[k];
+            acc = acc + df * df;
+        }
+        double s1[1] = {ok ? acc : kInf};
+        const int id1[1] = {ok ? mid : INT_MAX};
+        select_into<64, 1>(s1, id1, ld, li, lc, tau, m, lane, 0);
+    }
+    if (a.out.d != nullptr && lane < m) {
+        a.out.d[slot * m + lane] = lane < lc ? ld : kInf;
+        a.out.idx[slot * m + lane] = lane < lc ? li : -1;
+    }
+    if (a.out.d != nullptr && lane == 0) a.out.cnt[slot] = lc;
+}
+
 }  // namespace
+
+void launch_topm_generic(const TopmArgs &a, hipStream_t s)
+{
+    const int nq = a.pos_end - a.pos_begin;
+    if (nq <= 0 || a.B <= 0) return;
+    constexpr int WV = 4;
+    const long long items = (long long)nq * a.B;
+    hipLaunchKernelGGL((select_generic_kernel<WV>), dim3((unsigned)((items + WV - 1) / WV)), dim3(64 * WV), 0, s, a, nq, g_gate);
+}
 
 void launch_topm(const TopmArgs &a, hipStream_t s)
 {

@@ -36,7 +36,9 @@ extern "C" {
 #define CHB_ESTATE (-4)    /* call sequence violated (e.g. no samples set) */
 #define CHB_EUNSUPPORTED (-5)
 
-#define CHB_MAX_NEIGHBORS 16 /* AlgoNumNeighbors supported by the kernels (default.ini:16 -> 5) */
+/* AlgoNumNeighbors supported (default.ini:16 -> 5, function default 15: algorithm.py:17).  The tuned kernels
+ * cover 1..16; 17..64 run on plain one-wavefront-per-problem kernels (much slower, same results). */
+#define CHB_MAX_NEIGHBORS 64
 
 typedef struct chb_ctx chb_ctx;
 

@@ -565,3 +565,137 @@ def test_fit_cluster_affine_metric(ctx, O, metric):
     np.random.seed(0)
     got = clustering.fit_cluster(X, 6, initial, None, num_neighbors=5, max_iterations=5, metric=metric)
     assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------ the solve_qp seam (a8 / a11)
+
+def test_solve_qp_reference_forms(ctx, O, golden_dir):
+    """solve_qp.py:96-132 with the two argument tuples hull_distance.py builds (:17-33 simplex form, :48-64
+    equality only), for every solver name the reference accepts.  The weights reproduce the hull distance of
+    the oracle's Goldfarb-Idnani solve of the quadprog tuple CAPTURED from the reference (qp_args.npz)."""
+    from chbin_amd import clustering
+    g = np.load(os.path.join(golden_dir, "qp_args.npz"))
+    for k in range(len(g["m"])):
+        m = int(g["m"][k])
+        P, x = g["P"][k][:m], g["x"][k]
+        mat_p, vec_q = 2.0 * P @ P.T, -2.0 * P @ x              # hull_distance.py:30-31
+        args = (mat_p, vec_q, -np.eye(m), np.zeros(m), np.ones((1, m)), np.ones(1))
+        alpha_gi = O.gi_solve(g["G"][k][:m, :m], g["a"][k][:m], g["C"][k][:m, : m + 1], g["b"][k][: m + 1], 1)
+        d_gi = np.linalg.norm(alpha_gi @ P - x)
+        for solver in ("quadprog", "cvxopt", "hip"):
+            alpha = clustering.solve_qp(*args, solver=solver)
+            assert alpha.shape == (m,) and np.all(alpha >= 0) and abs(alpha.sum() - 1) < 1e-12
+            assert abs(np.linalg.norm(alpha @ P - x) - d_gi) < 1e-9
+            assert abs(np.linalg.norm(alpha @ P - x) - g["dist_with_oracle_gi"][k]) < 1e-9
+        # equality-only form (affine hull, hull_distance.py:48-64)
+        beta = clustering.solve_qp(mat_p, vec_q, None, None, np.ones((1, m)), np.ones(1), solver="quadprog")
+        assert abs(beta.sum() - 1) < 1e-10
+        assert abs(np.linalg.norm(beta @ P - x) - O.affine_hull_distance(x, P)) < 1e-9
+    with pytest.raises(NotImplementedError):
+        clustering.solve_qp(np.eye(3), np.zeros(3), -np.eye(3), np.zeros(3), np.ones((1, 3)), np.ones(1), solver="nosuch")
+    with pytest.raises(NotImplementedError):   # not a form the reference poses
+        clustering.solve_qp(np.eye(3), np.zeros(3), np.eye(3), np.ones(3), np.ones((1, 3)), np.ones(1))
+
+
+def test_cvxopt_solver_name_runs_the_same_path(ctx, O):
+    """AlgoQpSolver=cvxopt (solve_qp.py:54-93, :129): same distances, same labels as quadprog."""
+    from chbin_amd import clustering
+    rng = np.random.default_rng(5)
+    xs, Ps = _hull_cases(rng, 40, 136, 8)
+    for x, P in zip(xs, Ps):
+        d_c = clustering.calculate_distance(x, P, "cvxopt", "convex")
+        assert d_c == clustering.calculate_distance(x, P, "quadprog", "convex")
+        assert abs(d_c - O.convex_hull_distance(x, P)) <= QP_TOL + 1e-7 * np.linalg.norm(P - x, axis=1).max() * (d_c < 1e-8)
+    X, initial, _ = _synth(700, 64, 6, seed=12, sigma=8e-3, mix=0.5, n_seed=8)
+    perms = _perms(initial, 4)
+    want, _, _ = O.fit_cluster(X, 6, initial, perms, 5, 4)
+    np.random.seed(0)
+    got = clustering.fit_cluster(X, 6, initial, None, num_neighbors=5, max_iterations=4, qp_solver="cvxopt")
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------ num_neighbors > 16 (no cap in the reference)
+
+@pytest.mark.parametrize("m", [17, 24, 40, 64])
+def test_hull_distance_more_than_16_vertices(ctx, O, m):
+    rng = np.random.default_rng(m)
+    xs, Ps = _hull_cases(rng, 36, 136 if m < 64 else 70, m)
+    for x, P in zip(xs, Ps):
+        if len(P) <= 16:
+            P = np.vstack([P, rng.random((17 - len(P), P.shape[1])) / P.shape[1]])
+        d, alpha = ctx.hull_distance_points(x, P, want_alpha=True)
+        scale = max(np.linalg.norm(P - x, axis=1).max(), 1e-300)
+        d_or = O.convex_hull_distance(x, P)
+        assert abs(d - d_or) <= QP_TOL + 1e-7 * scale * (d_or < 1e-6 * scale), (len(P), d, d_or)
+        assert np.all(alpha >= 0) and abs(alpha.sum() - 1) < 1e-12
+        assert abs(np.linalg.norm(alpha @ P - x) - d) <= QP_TOL + 1e-7 * scale * (d < 1e-6 * scale)
+
+
+@pytest.mark.parametrize("N,D,B,m,batch", [(500, 40, 3, 20, 0), (400, 136, 2, 33, 60), (300, 24, 2, 64, 0)])
+def test_fit_cluster_more_than_16_neighbors(ctx, O, N, D, B, m, batch):
+    """AlgoNumNeighbors beyond the tuned kernels' 16: plain kernels, same labels as the oracle."""
+    X, initial, _ = _synth(N, D, B, seed=N + m, sigma=6e-3, mix=0.5, n_seed=m + 6)
+    perms = _perms(initial, 3)
+    want, its_o, ch_o = O.fit_cluster(X, B, initial, perms, m, 3)
+    ctx.set_samples(X)
+    got, its, ch, mind = ctx.fit_cluster(B, initial, perms, m, 3, batch=batch, want_min_dist=True)
+    assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
+    labels = initial.copy()
+    for k in range(its):
+        labels, md = O.sweep(X, B, labels, perms[k], m)
+    assert np.allclose(mind[perms[its - 1]], md, rtol=0, atol=QP_TOL)
+    # the per-bin selection on its own, lists of more than 16
+    rng = np.random.default_rng(1)
+    q = rng.choice(N, 40, replace=False)
+    idx, dist, cnt = ctx.topm_per_bin(got, B, m, q)
+    for qi, qq in enumerate(q):
+        cur = got.copy(); cur[qq] = -1
+        row = O.cdist_row(X, int(qq))
+        for c in range(B):
+            wl = O.find_nearest_from_cluster(c, cur, row, m)
+            assert cnt[qi, c] == len(wl) and np.array_equal(idx[qi, c, :len(wl)], wl)
+            assert np.array_equal(dist[qi, c, :len(wl)], row[wl])
+
+
+# ------------------------------------------------------------------ regressions (round-1 review)
+
+def test_mirror_fit_cluster_reuploads_samples(ctx, O):
+    """Two fits through the reference-signature mirror with DIFFERENT Fortran-ordered / float32 arrays of the
+    same shape: each must be clustered on its own data (the mirror used to skip the upload when the
+    temporary C-contiguous copy landed at the previous call's address)."""
+    from chbin_amd import clustering
+    wants, gots = [], []
+    for seed, dtype in ((3, np.float64), (4, np.float64), (5, np.float32), (6, np.float32)):
+        X, initial, _ = _synth(1200, 136, 6, seed=seed, sigma=6e-3, mix=0.5, n_seed=8)
+        Xf = np.asfortranarray(X.astype(dtype))                # what DataFrame.values may hand over
+        perms = _perms(initial, 3)
+        wants.append(O.fit_cluster(np.ascontiguousarray(Xf, dtype=np.float64), 6, initial, perms, 5, 3)[0])
+        np.random.seed(0)
+        gots.append(clustering.fit_cluster(Xf, 6, initial, None, num_neighbors=5, max_iterations=3))
+    for w_, g_ in zip(wants, gots):
+        assert np.array_equal(g_, w_)
+    assert not np.array_equal(wants[0], wants[1])              # (the cases really differ)
+    # in-place modification between two calls
+    X, initial, _ = _synth(1200, 136, 6, seed=9, sigma=6e-3, mix=0.5, n_seed=8)
+    perms = _perms(initial, 3)
+    np.random.seed(0)
+    first = clustering.fit_cluster(X, 6, initial, None, num_neighbors=5, max_iterations=3)
+    X[:] = _synth(1200, 136, 6, seed=10, sigma=6e-3, mix=0.5, n_seed=8)[0]
+    np.random.seed(0)
+    second = clustering.fit_cluster(X, 6, initial, None, num_neighbors=5, max_iterations=3)
+    assert np.array_equal(second, O.fit_cluster(X, 6, initial, perms, 5, 3)[0])
+    assert not np.array_equal(first, second)
+
+
+@pytest.mark.parametrize("batch,n_seed", [(32, 1), (2, 1), (63, 2), (17, 3)])
+def test_small_batch_fewer_seeds_than_batch(ctx, O, batch, n_seed):
+    """A caller batch below 64 with fewer labelled members than the batch: the sweep-1 batch schedule must
+    stay inside the buffers sized for `batch`."""
+    X, initial, _ = _synth(500, 40, 6, seed=batch, sigma=8e-3, mix=0.4, n_seed=n_seed)
+    perms = _perms(initial, 3)
+    want, its_o, ch_o = O.fit_cluster(X, 6, initial, perms, 5, 3)
+    ctx.set_samples(X)
+    got, its, ch = ctx.fit_cluster(6, initial, perms, 5, 3, batch=batch)
+    assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
+    from chbin_amd.distributed import batch_schedule
+    assert all(K <= batch for _, K in batch_schedule(perms.shape[1], batch, int((initial >= 0).sum()), True))
