@@ -197,7 +197,7 @@ struct chb_ctx {
     int Dz = 0;
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
     bool pf_base = true, pf_update = true;   // developer switches (CHB_PF_BASE / CHB_PF_UPDATE; -DCHB_DEV_KNOBS builds only)
-    DevBuf<int> cand, cand_cnt, flags64, overflow;
+    DevBuf<int> cand, cand_cnt, flags64, flaglist, nflag, overflow;
     DevBuf<int> active, n_active, act_blk;
     // fused selection + hull distance (m <= 5): batch-entry candidates of this / the previous round,
     // the base stage's tau (bound of the m-th nearest distance), the exact path's work list
@@ -329,6 +329,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->n_active.ensure(1));
         HIPCHK(h->act_blk.ensure((K * B + 4095) / 4096 + 1));
         HIPCHK(h->flags64.ensure(B * ((K + kQTile - 1) / kQTile)));
+        HIPCHK(h->flaglist.ensure(B * ((K + kQTile - 1) / kQTile)));
+        HIPCHK(h->nflag.ensure(1));
         launch_fill_i32(h->flags64.p, 0, (int)(B * ((K + kQTile - 1) / kQTile)), h->stream);   // kept zero by its consumer
         HIPCHK(h->overflow.ensure(1));
         HIPCHK(h->qn.ensure(K * B * 2));
@@ -440,6 +442,8 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         if (fusedp) pa.tau_out = h->tau.p;
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
+            pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;
+            launch_fill_i32(h->nflag.p, 0, 1, s);
             launch_shortlist(pa, h->flags64.p, s);
         }
         if (!fusedp) {
@@ -457,7 +461,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         }
         {
             Timed t(h, "topm_fallback", 0.0);
-            launch_topm_flagged(a, h->flags64.p, s);
+            launch_topm_flagged(a, h->flags64.p, h->flaglist.p, h->nflag.p, s);
         }
     } else {
         Timed t(h, "topm_base", (double)(q_hi - q_lo) * h->hint_base_members);
@@ -505,7 +509,9 @@ int batch_round_dev(chb_ctx *h, int active)
             pa.overflow = h->overflow.p;
             {
                 Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
-                launch_shortlist(pa, h->flags64.p, s);
+                pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;
+            launch_fill_i32(h->nflag.p, 0, 1, s);
+            launch_shortlist(pa, h->flags64.p, s);
             }
             {
                 // overflowed pairs: exact top-m among the (eligible) batch entries as their shortlist
@@ -513,7 +519,7 @@ int batch_round_dev(chb_ctx *h, int active)
                 a.out = Lists{nullptr, nullptr, nullptr};
                 a.cand_out = h->candu[cur].p; a.cand_cnt_out = h->candu_cnt[cur].p; a.cand_cap = kCandCapU;
                 Timed t(h, "topm_fallback", 0.0);
-                launch_topm_flagged(a, h->flags64.p, s);
+                launch_topm_flagged(a, h->flags64.p, h->flaglist.p, h->nflag.p, s);
             }
             FusedArgs f{};
             f.X = h->X.p; f.D = h->D; f.Dp = h->Dp; f.bq = h->bq_cur; f.pos_begin = lo; f.pos_end = hi;
@@ -565,7 +571,9 @@ int batch_round_dev(chb_ctx *h, int active)
             pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.cand_cap = kCandCap; pa.overflow = h->overflow.p;
             {
                 Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
-                launch_shortlist(pa, h->flags64.p, s);
+                pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;
+            launch_fill_i32(h->nflag.p, 0, 1, s);
+            launch_shortlist(pa, h->flags64.p, s);
                 // the (position, bin) pairs with a non-empty shortlist, for rescore_kernel
                 launch_compact_active(h->cand_cnt.p, lo, hi, h->B, h->Kcap, h->act_blk.p, h->active.p,
                                       h->n_active.p, s);
@@ -590,7 +598,7 @@ int batch_round_dev(chb_ctx *h, int active)
             }
             {
                 Timed t(h, "topm_fallback", 0.0);
-                launch_topm_flagged(a, h->flags64.p, s);
+                launch_topm_flagged(a, h->flags64.p, h->flaglist.p, h->nflag.p, s);
             }
         } else {
             Timed t(h, "topm_update", (double)(hi - lo) * h->hint_batch_entries);
@@ -694,7 +702,7 @@ int chb_destroy(chb_ctx *h)
     DevBuf<int> *ib[] = {&h->labels, &h->inb, &h->bq, &h->lab_old, &h->lab_prev, &h->lab_new,
                          &h->first_change, &h->l0i, &h->l1i, &h->l0c, &h->l1c, &h->l2i, &h->l2c, &h->cnt, &h->bin_ptr,
                          &h->cursor, &h->memb_id, &h->cnt2, &h->bin_ptr2, &h->cursor2, &h->memb2_id,
-                         &h->memb2_code, &h->perm, &h->xq, &h->xhull, &h->xcnt, &h->cand, &h->cand_cnt, &h->flags64, &h->overflow};
+                         &h->memb2_code, &h->perm, &h->xq, &h->xhull, &h->xcnt, &h->cand, &h->cand_cnt, &h->flags64, &h->flaglist, &h->nflag, &h->overflow};
     for (auto *b : ib) b->release();
     DevBuf<double> *db[] = {&h->X, &h->mind, &h->mind2, &h->dist, &h->l0d, &h->l1d, &h->l2d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();

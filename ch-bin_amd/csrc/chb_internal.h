@@ -55,7 +55,9 @@ void launch_topm(const TopmArgs &a, hipStream_t s);
 // the same for 16 < m <= kMaxMGeneric: one wavefront per (bin, query), no tiling (slow; see topm_kernels.hip)
 void launch_topm_generic(const TopmArgs &a, hipStream_t s);
 // same, but only work items (bin, query tile of 64) whose flag is set run; the rest exit at once
-void launch_topm_flagged(const TopmArgs &a, int *flags64, hipStream_t s);   // (clears the flags it serves)
+// same for the listed work items only (flaglist[0 .. *nflag): indices bin * ceil(nq / 64) + query tile, written by
+// the shortlist kernel; flags64 de-duplicates the list and is cleared here)
+void launch_topm_flagged(const TopmArgs &a, int *flags64, const int *flaglist, const int *nflag, hipStream_t s);
 
 // ---- two-stage exact selection (prefilter_kernels.hip + rescore in topm_kernels.hip)
 constexpr int kCandCap = 128;   // shortlist capacity per (bin, batch position)
@@ -121,10 +123,13 @@ struct ShortlistArgs {
     float *tau_out;
     const float *tau_in;   // update mode: tau per (bin, position) instead of `seed` (nullptr: use seed)
     int *overflow;   // [1] number of (bin, position) pairs whose shortlist overflowed
+    int *flaglist;   // work items (query tile of 64, bin) whose shortlist overflowed, for launch_topm_flagged ...
+    int *nflag;      // ... and their number (zeroed by the caller before the launch)
     float gamma;         // accumulation error factor g (set by launch_shortlist)
     int tile_best_min;   // bins with at least this many tiles learn tau from per-tile bests (ditto)
 };
 // flags64[bin][ceil(nq/64)] (pre-zeroed): set for (query tile of 64, bin) pairs whose shortlist overflowed
+// (and listed once in a.flaglist)
 void launch_shortlist(const ShortlistArgs &a, int *flags64, hipStream_t s);
 
 struct RescoreArgs {

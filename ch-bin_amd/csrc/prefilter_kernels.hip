@@ -798,7 +798,8 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
             if (!UPD && a.tau_out != nullptr) a.tau_out[slot] = sTau[32 * w + col];
             if (ccount > a.cand_cap || wcnt > kPoolW) {
                 atomicAdd(a.overflow, 1);
-                flags64[(size_t)c * nqt64 + (qpos - a.pos_begin) / kQTile] = 1;
+                const int fi = c * nqt64 + (qpos - a.pos_begin) / kQTile;
+                if (atomicExch(&flags64[fi], 1) == 0) a.flaglist[atomicAdd(a.nflag, 1)] = fi;
             }
         }
     }

@@ -95,7 +95,8 @@ __device__ __forceinline__ void select_into(double (&s)[NC], const int (&mid)[NC
 // (chb_pairwise_distance); "bins" are then contiguous member ranges and bq is null.
 template <bool PW>
 __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int total, int pw_n,
-                                                   int pw_group, double *pw_out, int *flags, Gate gate)
+                                                   int pw_group, double *pw_out, int *flags, const int *flaglist,
+                                                   const int *nflag, Gate gate)
 {
     CHB_GATE(gate);
     __shared__ __attribute__((aligned(16))) double sQ[2][kKChunk][kLdsStride];
@@ -103,12 +104,22 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
     __shared__ int sMid[2][kPTile];
     __shared__ int sMcode[2][kPTile];
 
-    // XCD-aware order: blocks b and b+8 share an XCD (and its L2), so hand each XCD a contiguous
-    // range of work items; consecutive items share a bin, i.e. the same member rows.
-    const int per = (total + 7) >> 3;
-    const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (W >= total) return;
-    if (flags != nullptr && flags[W] == 0) return;   // fallback launch: only flagged work items
+    // fallback launch (flaglist != nullptr): a few workgroups walk the listed work items; otherwise one work
+    // item per workgroup
+    const int nfl = flaglist != nullptr ? *nflag : 0;
+    for (int witer = 0;; ++witer) {
+    int W;
+    if (flaglist != nullptr) {
+        const int i = (int)blockIdx.x + witer * (int)gridDim.x;
+        if (i >= nfl) return;
+        W = flaglist[i];
+    } else {
+        // XCD-aware order: blocks b and b+8 share an XCD (and its L2), so hand each XCD a contiguous
+        // range of work items; consecutive items share a bin, i.e. the same member rows.
+        const int per = (total + 7) >> 3;
+        W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        if (W >= total) return;
+    }
     const int c = W / nqt, qt = W - c * nqt;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
 
     if (nsteps > 0) { prefetch(); stash(0); }
     __syncthreads();
-    if (flags != nullptr && tid == 0) flags[W] = 0;   // every thread has read it (above the barrier): served
+    if (flags != nullptr && tid == 0) flags[W] = 0;   // served (the flag only de-duplicates the list)
 
     int ct = 0, cc = 0;  // (tile, chunk) of the step being computed
     for (int step = 0; step < nsteps; ++step) {
@@ -284,6 +295,9 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
                 }
             }
         }
+    }
+    if (flaglist == nullptr) return;
+    __syncthreads();   // the staging buffers are reused by the next listed work item
     }
 }
 
@@ -472,18 +486,18 @@ void launch_topm(const TopmArgs &a, hipStream_t s)
     const int total = nqt * a.B;
     const int grid = ((total + 7) / 8) * 8;
     hipLaunchKernelGGL(tile_kernel<false>, dim3(grid), dim3(256), 0, s, a, nqt, total, 0, 0,
-                       (double *)nullptr, (int *)nullptr, g_gate);
+                       (double *)nullptr, (int *)nullptr, (const int *)nullptr, (const int *)nullptr, g_gate);
 }
 
-void launch_topm_flagged(const TopmArgs &a, int *flags64, hipStream_t s)
+void launch_topm_flagged(const TopmArgs &a, int *flags64, const int *flaglist, const int *nflag, hipStream_t s)
 {
     const int nq = a.pos_end - a.pos_begin;
     if (nq <= 0 || a.B <= 0) return;
     const int nqt = (nq + kQTile - 1) / kQTile;
     const int total = nqt * a.B;
-    const int grid = ((total + 7) / 8) * 8;
+    const int grid = std::min(total, 256);   // the listed work items are few (usually none)
     hipLaunchKernelGGL(tile_kernel<false>, dim3(grid), dim3(256), 0, s, a, nqt, total, 0, 0,
-                       (double *)nullptr, flags64, g_gate);
+                       (double *)nullptr, flags64, flaglist, nflag, g_gate);
 }
 
 void launch_rescore(const RescoreArgs &a, hipStream_t s)
@@ -512,7 +526,7 @@ void launch_pairwise(const double *X, int N, int Dp, int r0, int r1, double *out
     const int total = nqt * ngroups;
     const int grid = ((total + 7) / 8) * 8;
     hipLaunchKernelGGL(tile_kernel<true>, dim3(grid), dim3(256), 0, s, a, nqt, total, N, group, out,
-                       (int *)nullptr, g_gate);
+                       (int *)nullptr, (const int *)nullptr, (const int *)nullptr, g_gate);
 }
 
 }  // namespace chb
