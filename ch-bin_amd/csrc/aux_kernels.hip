@@ -57,7 +57,7 @@ __global__ void count_base_kernel(const int *labels, const int *inb, int N, int 
 
 // bin_ptr / cursor = exclusive scan of cnt; pad_ptr (optional) = the same with every count rounded
 // up to a multiple of 32 (the padded layout of the shortlist stage).  One block of 256 threads.
-__global__ __launch_bounds__(256) void scan_kernel(const int *cnt, int B, int *bin_ptr, int *cursor, int *pad_ptr,
+__global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int *bin_ptr, int *cursor, int *pad_ptr,
                                                     Gate gate)
 {
     CHB_GATE(gate);
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const int *cnt, int B, int *b
             part[i] = run; ppart[i] = prun;
             run += v; prun += pv;
         }
-        for (int i = nparts; i < 256; ++i) { part[i] = run; ppart[i] = prun; }
+        bin_ptr[B] = run;   // (the totals)
+        if (pad_ptr) pad_ptr[B] = prun;
     }
     __syncthreads();
     int run = part[threadIdx.x], prun = ppart[threadIdx.x];
@@ -84,10 +85,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const int *cnt, int B, int *b
         bin_ptr[b] = run; cursor[b] = run;
         if (pad_ptr) pad_ptr[b] = prun;
         run += cnt[b]; prun += (cnt[b] + 31) / 32 * 32;
-    }
-    if (threadIdx.x == 255) {   // (its prefix + its own bins = everything)
-        bin_ptr[B] = run;
-        if (pad_ptr) pad_ptr[B] = prun;
+        cnt[b] = 0;   // left clean for the next count (launch_bucket_base needs no separate fill)
     }
 }
 
@@ -161,20 +159,17 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
             part[i] = run; ppart[i] = prun;
             run += v; prun += pv;
         }
-        for (int i = nparts; i < 1024; ++i) { part[i] = run; ppart[i] = prun; }
+        bin_ptr[B] = run;   // (the totals)
+        if (pad_ptr) pad_ptr[B] = prun;
     }
     __syncthreads();
-    int run = part[tid], prun = ppart[tid];
+    int run = part[tid], prun = ppart[tid];   // (read only where b0 < b1: tid < nparts)
     for (int b = b0; b < b1; ++b) {
         const int c = cnt[b];
         bin_ptr[b] = run;
         if (pad_ptr) pad_ptr[b] = prun;
         cnt[b] = run;   // becomes the bin's cursor
         run += c; prun += (c + 31) / 32 * 32;
-    }
-    if (tid == 1023) {
-        bin_ptr[B] = run;
-        if (pad_ptr) pad_ptr[B] = prun;
     }
     __syncthreads();
     for (int i = tid; i < K; i += 1024) {
@@ -458,7 +453,7 @@ void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, in
 void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
                         int *cursor, int *memb_id, int *pad_ptr, hipStream_t s)
 {
-    launch_fill_i32(cnt, 0, B, s);
+    // (cnt is all zero here: allocated zeroed, and scan_kernel clears what it has read)
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt, g_gate);

@@ -126,6 +126,28 @@ struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+// pinned host staging (labels, permutations): asynchronous copies at DMA speed instead of the driver's
+// bounce-buffer path for pageable memory
+template <typename T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipHostMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { release(); }
+};
+
 }  // namespace
 
 // device storage behind a MemberPack
@@ -185,6 +207,7 @@ struct chb_ctx {
     DevBuf<int> cnt, bin_ptr, cursor, memb_id;
     DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
     DevBuf<int> perm;
+    PinBuf<int> pin_a, pin_b;   // host staging: labels in / permutation, labels out
     // two-stage selection: fp16 shadow copies + shortlists (prefilter_kernels.hip)
     DevBuf<unsigned short> Gs, Zs;     // per sample: query-side row (global centre), member-side row (own bin)
     DevBuf<float> gq, ms;              // per sample: float2 {||qh||^2, rho}, float4 {bias, rho, ||zh||^2, amax}
@@ -313,7 +336,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->l1i.ensure(K * B * m));
     HIPCHK(h->l0c.ensure(K * B));
     HIPCHK(h->l1c.ensure(K * B));
-    HIPCHK(h->cnt.ensure(B));
+    { const size_t had = h->cnt.cap; HIPCHK(h->cnt.ensure(B)); if (h->cnt.cap != had) HIPCHK(hipMemsetAsync(h->cnt.p, 0, sizeof(int) * h->cnt.cap, h->stream)); }
     HIPCHK(h->bin_ptr.ensure(B + 1));
     HIPCHK(h->cursor.ensure(B));
     HIPCHK(h->memb_id.ensure((size_t)h->N));
@@ -362,7 +385,8 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     // one-wavefront-per-problem kernels run (brute-force selection, LDS-resident solver)
     h->pf_fit = h->use_prefilter && h->shadow_ok && m <= kMaxM;
     h->fused = h->allow_fused && h->pf_fit && h->pf_base && h->pf_update && fused_supported(m);
-    std::vector<int> lab((size_t)h->N);
+    HIPCHK(h->pin_a.ensure((size_t)h->N));
+    int *lab = h->pin_a.p;
     for (int64_t i = 0; i < h->N; ++i) {
         const int64_t v = initial[i];
         if (v >= B) return fail(CHB_EINVAL, "initial_bins contains a label >= num_clusters");
@@ -370,9 +394,10 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     }
     HIPCHK(h->labels.ensure((size_t)h->N));
     HIPCHK(h->inb.ensure((size_t)h->N));
-    HIPCHK(hipMemcpyAsync(h->labels.p, lab.data(), sizeof(int) * h->N, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->labels.p, lab, sizeof(int) * h->N, hipMemcpyHostToDevice, h->stream));
     launch_fill_i32(h->inb.p, -1, (int)h->N, h->stream);
     HIPCHK(h->cnt.ensure((size_t)B));
+    HIPCHK(hipMemsetAsync(h->cnt.p, 0, sizeof(int) * h->cnt.cap, h->stream));   // (kept zero by scan_kernel from here on)
     HIPCHK(h->bin_ptr.ensure((size_t)B + 1));
     HIPCHK(h->cursor.ensure((size_t)B));
     HIPCHK(h->memb_id.ensure((size_t)h->N));
@@ -953,10 +978,13 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     int it = 0;
     for (; it < max_iter; ++it) {
         const int64_t *perm = perms + (int64_t)it * n_move;
-        std::vector<int> p32 = to_i32(perm, (size_t)n_move);
         HIPCHK(h->perm.ensure((size_t)std::max<int64_t>(n_move, 1)));
-        if (n_move)
-            HIPCHK(hipMemcpyAsync(h->perm.p, p32.data(), sizeof(int) * n_move, hipMemcpyHostToDevice, s));
+        HIPCHK(h->pin_a.ensure((size_t)std::max<int64_t>(n_move, 1)));
+        if (n_move) {
+            HIPCHK(hipStreamSynchronize(s));   // (pin_a may still be the source of the previous upload)
+            for (int64_t i = 0; i < n_move; ++i) h->pin_a.p[i] = (int)perm[i];
+            HIPCHK(hipMemcpyAsync(h->perm.p, h->pin_a.p, sizeof(int) * n_move, hipMemcpyHostToDevice, s));
+        }
         // ---- the batches of this sweep.  A batch = start (selection against the members outside it), a
         // label guess, then rounds until the first changed position is past its end.  On one GPU the
         // NEXT batch is enqueued while the first round's verdict is still on its way to the host: its
@@ -1100,13 +1128,16 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             t0 = t1;
         }
         h->stats[3] += n_move * (int64_t)h->B;
-        HIPCHK(hipMemcpyAsync(cur.data(), h->labels.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+        HIPCHK(h->pin_b.ensure((size_t)N));
+        HIPCHK(hipMemcpyAsync(h->pin_b.p, h->labels.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         int64_t diff = 0;  // algorithm.py:63
         labelled = 0;
         for (int64_t i = 0; i < N; ++i) {
-            diff += prev[(size_t)i] != cur[(size_t)i];
-            labelled += cur[(size_t)i] >= 0;
+            const int v = h->pin_b.p[i];
+            cur[(size_t)i] = v;
+            diff += prev[(size_t)i] != v;
+            labelled += v >= 0;
         }
         if (changed_per_iter) changed_per_iter[it] = diff;
         if (diff == 0) { ++it; break; }  // algorithm.py:64-66
