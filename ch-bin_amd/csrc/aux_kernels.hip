@@ -58,9 +58,10 @@ __global__ void count_base_kernel(const int *labels, const int *inb, int N, int 
 // bin_ptr / cursor = exclusive scan of cnt; pad_ptr (optional) = the same with every count rounded
 // up to a multiple of 32 (the padded layout of the shortlist stage).  One block of 256 threads.
 __global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int *bin_ptr, int *cursor, int *pad_ptr,
-                                                    Gate gate)
+                                                    int *zero_me, Gate gate)
 {
     CHB_GATE(gate);
+    if (zero_me != nullptr && threadIdx.x == 0) *zero_me = 0;   // (the fallback list's counter: saves a launch)
     __shared__ int part[256], ppart[256];
     const int per = (B + 255) / 256;
     const int b0 = min(B, (int)threadIdx.x * per), b1 = min(B, b0 + per);
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(256) void fill_base_kernel(const int *labels, const
 // LDS cursors.  Entry codes: see chb_internal.h (TopmArgs::memb_code).
 __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev, const int *lab_old, const int *bq,
                                                             int K, int B, int *bin_ptr, int *pad_ptr, int *memb_id,
-                                                            int *memb_code, int *first_change, int *n_slow, Gate gate)
+                                                            int *memb_code, int *first_change, int *n_slow, int *nflag,
+                                                            Gate gate)
 {
     CHB_GATE(gate);
     extern __shared__ int sh[];   // [B] counts -> cursors, [1024] scan partials x 2
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
     if (tid == 0) {   // the round's scalars
         if (first_change) *first_change = K;
         if (n_slow) *n_slow = 0;
+        if (nflag) *nflag = 0;
     }
     for (int b = tid; b < B; b += 1024) cnt[b] = 0;
     __syncthreads();
@@ -451,23 +454,23 @@ void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, in
 }
 
 void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
-                        int *cursor, int *memb_id, int *pad_ptr, hipStream_t s)
+                        int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s)
 {
     // (cnt is all zero here: allocated zeroed, and scan_kernel clears what it has read)
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt, g_gate);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr, g_gate);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr, zero_me, g_gate);
     hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * sizeof(int), s, labels, inb, N, B, cursor, memb_id, g_gate);
 }
 
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
-                         int *first_change, int *n_slow, hipStream_t s)
+                         int *first_change, int *n_slow, int *nflag, hipStream_t s)
 {
     (void)cnt; (void)cursor;   // (scratch of the former three-kernel form)
     hipLaunchKernelGGL(bucket_batch_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 2048), s, lab_prev,
-                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow, g_gate);
+                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow, nflag, g_gate);
 }
 
 void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int pos_begin,

@@ -407,7 +407,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
         // the bin keeps them tight.  Then every labelled sample's shadow row against its own bin.
         HIPCHK(h->centers.ensure((size_t)B * h->Dp));
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p,
-                           h->memb_id.p, nullptr, h->stream);
+                           h->memb_id.p, nullptr, nullptr, h->stream);
         launch_bin_centers(h->X.p, h->D, h->Dp, h->memb_id.p, h->bin_ptr.p, h->B, h->centers.p, h->stream);
         launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
                              h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, nullptr, nullptr, h->stream);
@@ -432,7 +432,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
     {
         Timed t(h, "bucket", (double)h->N);
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
-                           h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, s);
+                           h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, h->nflag.p, s);
     }
     TopmArgs a{};
     a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = q_lo; a.pos_end = q_hi;
@@ -467,8 +467,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         if (fusedp) pa.tau_out = h->tau.p;
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
-            pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;
-            launch_fill_i32(h->nflag.p, 0, 1, s);
+            pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;   // (counter reset by the CSR scan / the batch CSR kernel)
             launch_shortlist(pa, h->flags64.p, s);
         }
         if (!fusedp) {
@@ -509,7 +508,7 @@ int batch_round_dev(chb_ctx *h, int active)
             Timed t(h, "bucket", (double)h->K);
             launch_bucket_batch(h->lab_prev.p, h->lab_old.p, h->bq_cur, h->K, h->B, h->cnt2.p,
                                 h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, h->pk2.pad_ptr.p,
-                                h->fc_cur, fusedp ? h->n_slow.p : nullptr, s);
+                                h->fc_cur, fusedp ? h->n_slow.p : nullptr, h->nflag.p, s);
         }
         TopmArgs a{};
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = lo; a.pos_end = hi;
@@ -534,8 +533,7 @@ int batch_round_dev(chb_ctx *h, int active)
             pa.overflow = h->overflow.p;
             {
                 Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
-                pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;
-            launch_fill_i32(h->nflag.p, 0, 1, s);
+                pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;   // (counter reset by the CSR scan / the batch CSR kernel)
             launch_shortlist(pa, h->flags64.p, s);
             }
             {
@@ -596,8 +594,7 @@ int batch_round_dev(chb_ctx *h, int active)
             pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.cand_cap = kCandCap; pa.overflow = h->overflow.p;
             {
                 Timed t(h, "prefilter_update", (double)(hi - lo) * h->hint_batch_entries);
-                pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;
-            launch_fill_i32(h->nflag.p, 0, 1, s);
+                pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;   // (counter reset by the CSR scan / the batch CSR kernel)
             launch_shortlist(pa, h->flags64.p, s);
                 // the (position, bin) pairs with a non-empty shortlist, for rescore_kernel
                 launch_compact_active(h->cand_cnt.p, lo, hi, h->B, h->Kcap, h->act_blk.p, h->active.p,
@@ -1180,7 +1177,7 @@ int chb_topm_per_bin(chb_ctx *h, const int64_t *labels, int64_t B, int m, const 
         if (rc) return rc;
         // every other query of the chunk is an ordinary member: code "pos != i"
         launch_bucket_batch(h->lab_old.p, nullptr, h->bq_cur, K, h->B, h->cnt2.p, h->bin_ptr2.p,
-                            h->cursor2.p, h->memb2_id.p, h->memb2_code.p, nullptr, nullptr, nullptr, s);
+                            h->cursor2.p, h->memb2_id.p, h->memb2_code.p, nullptr, nullptr, nullptr, nullptr, s);
         TopmArgs a{};
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = 0; a.pos_end = K;
         a.bin_ptr = h->bin_ptr2.p; a.memb_id = h->memb2_id.p; a.memb_code = h->memb2_code.p;

@@ -213,13 +213,14 @@ void launch_batch_open(const int *labels, int *inb, const int *bq, int K, int *l
 void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, int K, hipStream_t s);
 // CSR of all labelled samples outside the batch
 // (pad_ptr, optional: the same CSR with every bin padded to a multiple of 32 rows -> MemberPack)
+// (zero_me, optional: one int the scan also resets -- the fallback list's counter of the coming shortlist launch)
 void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
-                        int *cursor, int *memb_id, int *pad_ptr, hipStream_t s);
+                        int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s);
 // CSR of the batch's own members: earlier positions under lab_prev, later positions under lab_old
-// (also starts the round's scalars: *first_change = K, *n_slow = 0 where the pointers are non-null)
+// (also starts the round's scalars: *first_change = K, *n_slow = 0, *nflag = 0 where the pointers are non-null)
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
-                         int *first_change, int *n_slow, hipStream_t s);
+                         int *first_change, int *n_slow, int *nflag, hipStream_t s);
 // first position in [p0,K) whose label changed (atomicMin into *first_change)
 void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,
                          hipStream_t s);
