@@ -59,7 +59,11 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #endif
 constexpr float kGamma = 2.5e-5f;
 constexpr float kSlack = 1e-6f;
-constexpr int kPfQ = 128;  // batch positions per workgroup (32 per wavefront)
+#ifndef CHB_SL_WAVES
+#define CHB_SL_WAVES 4   // wavefronts per workgroup of the shortlist kernel (developer experiment: 8)
+#endif
+constexpr int kPfW = CHB_SL_WAVES;
+constexpr int kPfQ = 32 * kPfW;  // batch positions per workgroup (32 per wavefront)
 constexpr int kPfP = 32;   // members per tile
 
 __device__ __forceinline__ float round_up_f32(double v)
@@ -469,7 +473,7 @@ __device__ __forceinline__ void list_insert_desc(float (&l)[ML], float v)
 }
 
 template <int ML, bool UPD, int KS>
-__global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
+__global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
                                                                          int bpw, int *flags64, int nqt64, Gate gate)
 {
     CHB_GATE(gate);
@@ -481,8 +485,8 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
     constexpr int NBUF = 3;
     constexpr int kPoolW = shortlist_pool_entries(ML);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned *sPool = reinterpret_cast<unsigned *>(smem + NBUF * BUFB);   // [4][kPoolW]
-    int *sCnt = reinterpret_cast<int *>(sPool + 4 * kPoolW);              // [kPfQ]
+    unsigned *sPool = reinterpret_cast<unsigned *>(smem + NBUF * BUFB);   // [kPfW][kPoolW]
+    int *sCnt = reinterpret_cast<int *>(sPool + kPfW * kPoolW);           // [kPfQ]
     float *sTau = reinterpret_cast<float *>(sCnt + kPfQ);                 // [kPfQ] tau of the bin (parked: no register)
 
     // consecutive workgroups alternate over the 8 XCDs: give each XCD a contiguous range of work
@@ -526,14 +530,14 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
     int src_off[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int pch = (w + 4 * j) * 64 + lane;
+        const int pch = (w + kPfW * j) * 64 + lane;
         const int r = pch / CPR, cs = pch - r * CPR;
         const int f = KS == 9 ? ((r >> 4) & 1) : ((r >> 2) & 3);
         src_off[j] = (r * CPR + (cs ^ f)) * 16;
     }
     int n_w = 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) n_w += (w + 4 * j < KS) ? CHB_SL_DMAREP : 0;
+    for (int j = 0; j < 3; ++j) n_w += (w + kPfW * j < KS) ? CHB_SL_DMAREP : 0;
     n_w += (w == 3) ? 1 : 0;
     n_w += (UPD && w == 2) ? 1 : 0;
     const unsigned char *zall = reinterpret_cast<const unsigned char *>(a.P.Z);
@@ -560,9 +564,9 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
         const unsigned char *src_ = zall + row_ * ROWB;                                            \
         _Pragma("unroll") for (int rep_ = 0; rep_ < CHB_SL_DMAREP; ++rep_)                         \
         _Pragma("unroll") for (int j = 0; j < 3; ++j)                                              \
-            if (w + 4 * j < KS)                                                                    \
+            if (w + kPfW * j < KS)                                                                 \
                 __builtin_amdgcn_global_load_lds(src_ + src_off[j],                                \
-                    (__attribute__((address_space(3))) void *)(dst_ + (w + 4 * j) * 1024), 16, 0, 0); \
+                    (__attribute__((address_space(3))) void *)(dst_ + (w + kPfW * j) * 1024), 16, 0, 0); \
         if (w == 3) {                                                                              \
             const float *p_ = (h ? (UPD ? a.P.cs : a.P.sn) : a.P.bias) + row_ + col;               \
             __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB), 4, 0, 0); \
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(256, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_k
 
 static size_t shortlist_lds_bytes(int ks, int ml)
 {
-    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)4 * shortlist_pool_entries(ml) * 4 + 2 * kPfQ * 4;
+    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 2 * kPfQ * 4;
 }
 
 template <int ML, bool UPD>
@@ -821,7 +825,7 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
     const int nqt64 = (nq + kQTile - 1) / kQTile;
     // bins per workgroup: long tile streams per workgroup, but enough workgroups for the 256 CUs x 4
     const long long units = (long long)nqt * a.B;
-    int bpw = (int)std::max<long long>(1, units / (UPD ? 1024 : 2048));
+    int bpw = (int)std::max<long long>(1, units / ((UPD ? 1024 : 2048) * 4 / kPfW));
 #ifdef CHB_DEV_KNOBS
     static int env_bpw = -2;
     if (env_bpw == -2) { const char *e = getenv("CHB_SL_BPW"); env_bpw = e ? atoi(e) : 0; }
@@ -832,10 +836,10 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
     const int total = nqt * nchunk;
     const int grid = ((total + 7) / 8) * 8;
     if (a.Dz == 144)
-        hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(256), shortlist_lds_bytes(9, ML), s, a,
+        hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(64 * kPfW), shortlist_lds_bytes(9, ML), s, a,
                            nqt, nchunk, bpw, flags64, nqt64, g_gate);
     else
-        hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(256), shortlist_lds_bytes(10, ML), s, a,
+        hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(64 * kPfW), shortlist_lds_bytes(10, ML), s, a,
                            nqt, nchunk, bpw, flags64, nqt64, g_gate);
 }
 
