@@ -994,8 +994,13 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         const bool can_spec = h->speculate && h->fused && !xchg && min_dist_out == nullptr;
         struct Geom { int64_t t0; int K, q_lo, q_hi, C; };
         auto geom_at = [&](int64_t t0) {
-            // sweep 1 starts from few labelled members: do not let a batch outnumber them
-            const int64_t members = (it == 0) ? assigned0 + t0 : N;
+            // sweep 1 starts from few labelled members: do not let a batch outnumber them by much
+            // (measured: a batch of up to 1.5x the labelled members costs no extra rounds and saves a batch)
+            int64_t members = (it == 0) ? (assigned0 + t0) * 3 / 2 : N;
+#ifdef CHB_DEV_KNOBS
+            { static double r = -1.0; if (r < 0.0) { const char *e = getenv("CHB_EARLY_RATIO"); r = e ? atof(e) : 1.5; }
+              if (it == 0) members = (int64_t)((assigned0 + t0) * r); }
+#endif
             int K = (int)std::min<int64_t>(Kmax, n_move - t0);
             if (members < K) K = (int)std::max<int64_t>(std::min<int64_t>(64, n_move - t0), members);
             K = std::min(K, Kmax);   // (the floor of 64 above must not exceed a caller's smaller batch: buffers hold Kmax)

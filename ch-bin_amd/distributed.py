@@ -26,11 +26,11 @@ def slice_bounds(K, world, rank):
 
 def batch_schedule(n_move, batch, members0, first_sweep):
     """Batch sizes for one sweep.  Any partition gives the same labels; in sweep 1 a batch is not
-    allowed to outnumber the members labelled so far (keeps speculation rounds few)."""
+    allowed to outnumber the members labelled so far by more than half (keeps speculation rounds few)."""
     out, t0 = [], 0
     kmax = max(1, min(int(batch) if batch and batch > 0 else 8192, max(n_move, 1)))
     while t0 < n_move:
-        members = members0 + t0 if first_sweep else 1 << 62
+        members = (members0 + t0) * 3 // 2 if first_sweep else 1 << 62   # (as csrc/chb_api.hip)
         K = min(kmax, n_move - t0)
         if members < K:
             K = min(max(min(64, n_move - t0), members), kmax)
