@@ -944,8 +944,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     int rc = fit_begin_impl(h, B, initial_bins, m);
     if (rc) return rc;
     const int64_t N = h->N;
-    for (int64_t i = 0; i < (int64_t)max_iter * n_move; ++i)
-        if (perms[i] < 0 || perms[i] >= N) return fail(CHB_EINVAL, "perm entry out of range");
+    // (the permutations are range-checked sweep by sweep, while they are converted for the upload)
     if (h->world > 1 && !h->comm && !h->hook) return fail(CHB_ESTATE, "world > 1 but chb_comm_init was not called");
     // default batch: 8192 positions on one GPU, growing with sqrt(world): the batch-member
     // (update) work per rank is ~K^2/world, the per-rank grids ~K/world
@@ -957,8 +956,9 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     hipStream_t s = h->stream;
     memset(h->stats, 0, sizeof(h->stats));
 
-    std::vector<int> prev((size_t)N), cur((size_t)N);
-    for (int64_t i = 0; i < N; ++i) prev[(size_t)i] = initial_bins[i] < 0 ? -1 : (int)initial_bins[i];
+    // (fit_begin_impl left the converted initial labels in pin_a and has synchronised the stream)
+    std::vector<int> prev(h->pin_a.p, h->pin_a.p + N), cur;
+    cur.resize((size_t)N);
     std::vector<double> mind_host, mind2_host;
     if (min_dist_out) {
         for (int64_t i = 0; i < N; ++i) min_dist_out[i] = NAN;
@@ -979,7 +979,13 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         HIPCHK(h->pin_a.ensure((size_t)std::max<int64_t>(n_move, 1)));
         if (n_move) {
             HIPCHK(hipStreamSynchronize(s));   // (pin_a may still be the source of the previous upload)
-            for (int64_t i = 0; i < n_move; ++i) h->pin_a.p[i] = (int)perm[i];
+            int64_t bad = 0;
+            for (int64_t i = 0; i < n_move; ++i) {
+                const int64_t v = perm[i];
+                bad |= (v < 0) | (v >= N);
+                h->pin_a.p[i] = (int)v;
+            }
+            if (bad) return fail(CHB_EINVAL, "perm entry out of range");
             HIPCHK(hipMemcpyAsync(h->perm.p, h->pin_a.p, sizeof(int) * n_move, hipMemcpyHostToDevice, s));
         }
         // ---- the batches of this sweep.  A batch = start (selection against the members outside it), a
