@@ -810,48 +810,69 @@ struct Inv16 {
     double H[16];
 };
 
-// vertex v enters: false (and no change) when it is affinely dependent on the support
-__device__ __forceinline__ bool inv16_insert(Inv16 &I, const double (&Qr)[16], double s, unsigned &S, int v,
-                                             int l16, int gbase)
+// Every lane of a 16-lane group publishes one value; afterwards out[j] is lane j's.  Through a 16-double LDS row
+// of the group (one ds_write_b64 + eight ds_read_b128, broadcast reads) instead of sixteen shuffles of a double
+// (32 ds_bpermute_b32): the LDS crossbar is what the 16-lane solver runs on.
+__device__ __forceinline__ void group_allgather16(double *sv, int l16, double v, double (&out)[16])
 {
-    // a_j = Q[v][j] + s for j in S (row v of Q lives on lane v); u = H a
+    sv[l16] = v;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const double2 t = *reinterpret_cast<const double2 *>(sv + j);
+        out[j] = t.x; out[j + 1] = t.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kQ16Ld = 18;   // row stride of the 16 x 16 Gram tile in LDS (16-byte aligned rows)
+
+// vertex v enters: false (and no change) when it is affinely dependent on the support.
+// Qt = the group's Gram tile in LDS (row stride kQ16Ld), sv = its 16-double exchange row.
+__device__ __forceinline__ bool inv16_insert(Inv16 &I, const double (&Qr)[16], const double *Qt, double *sv, double s,
+                                             unsigned &S, int v, int l16)
+{
+    // a_j = Q[v][j] + s for j in S (row v of the tile, a broadcast read); u = H a
     double u = 0.0, a_own = 0.0, avv = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double aj = __shfl(Qr[j], gbase + v, 64) + s;
-        if ((S >> j) & 1u) u = fma(I.H[j], aj, u);
-        a_own = (j == l16) ? aj : a_own;
-        avv = (j == v) ? aj : avv;
+    for (int j = 0; j < 16; j += 2) {
+        const double2 t = *reinterpret_cast<const double2 *>(Qt + v * kQ16Ld + j);
+        const double a0 = t.x + s, a1 = t.y + s;
+        if ((S >> j) & 1u) u = fma(I.H[j], a0, u);
+        if ((S >> (j + 1)) & 1u) u = fma(I.H[j + 1], a1, u);
+        a_own = (j == l16) ? a0 : ((j + 1 == l16) ? a1 : a_own);
+        avv = (j == v) ? a0 : ((j + 1 == v) ? a1 : avv);
     }
     const bool in = (S >> l16) & 1u;
     double delta = avv - group_sum16(in ? a_own * u : 0.0);
+    double ug[16];
     if (!(delta > 1e-6 * avv)) {
         // A small pivot is decided after one step of iterative refinement against the ORIGINAL rows
         // of Q: the stored inverse carries an error of eps * cond, which must not leak into the
         // test below (a dependent vertex has to come out at delta ~ eps * avv, as the Schur
         // complement of a factorisation does).
+        group_allgather16(sv, l16, in ? u : 0.0, ug);
         double r = a_own;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double uj = __shfl(in ? u : 0.0, gbase + j, 64);
-            if ((S >> j) & 1u) r = fma(-(Qr[j] + s), uj, r);
-        }
+        for (int j = 0; j < 16; ++j)
+            if ((S >> j) & 1u) r = fma(-(Qr[j] + s), ug[j], r);
         r = in ? r : 0.0;
+        group_allgather16(sv, l16, r, ug);
         double du = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double rj = __shfl(r, gbase + j, 64);
-            if ((S >> j) & 1u) du = fma(I.H[j], rj, du);
-        }
+        for (int j = 0; j < 16; ++j)
+            if ((S >> j) & 1u) du = fma(I.H[j], ug[j], du);
         u += du;
         delta = avv - group_sum16(in ? a_own * u : 0.0);
     }
     if (!(delta > 1e-13 * avv)) return false;
     const double inv = 1.0 / delta;
     const double ui = in ? u : 0.0;
+    group_allgather16(sv, l16, ui, ug);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const double uj = __shfl(ui, gbase + j, 64);
+        const double uj = ug[j];
         double h;
         if (l16 == v) h = (j == v) ? inv : -uj * inv;                      // the new row
         else h = (j == v) ? -ui * inv : fma(ui * inv, uj, I.H[j]);         // old rows + the new column
@@ -866,16 +887,16 @@ __device__ __forceinline__ bool inv16_insert(Inv16 &I, const double (&Qr)[16], d
 }
 
 // vertex r (in S) leaves
-__device__ __forceinline__ void inv16_remove(Inv16 &I, unsigned &S, int r, int l16, int gbase)
+__device__ __forceinline__ void inv16_remove(Inv16 &I, double *sv, unsigned &S, int r, int l16)
 {
+    // row r of H = column r (H is symmetric): every lane contributes its own entry H[l16][r]
     double hrr = 0.0, own = 0.0;
-    double hr[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        hr[j] = __shfl(I.H[j], gbase + r, 64);
-        hrr = (j == r) ? hr[j] : hrr;
-        own = (j == r) ? I.H[j] : own;
-    }
+    for (int j = 0; j < 16; ++j) own = (j == r) ? I.H[j] : own;
+    double hr[16];
+    group_allgather16(sv, l16, own, hr);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) hrr = (j == r) ? hr[j] : hrr;
     const double f = own / hrr;
 #pragma unroll
     for (int j = 0; j < 16; ++j) I.H[j] = (l16 == r || j == r) ? 0.0 : fma(-f, hr[j], I.H[j]);
@@ -897,9 +918,10 @@ template <bool INDEXED>
 __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, const int *xq, const int *xhull,
                                                         const int *xn, int xm, double *xdist, double *xalpha)
 {
-    __shared__ double sQ[4][4][16][17];   // [wavefront][problem][row][col], padded
+    __shared__ __attribute__((aligned(16))) double sQ[4][4][16][kQ16Ld];   // [wavefront][problem][row][col], padded
+    __shared__ __attribute__((aligned(16))) double sV[4][4][16];           // exchange row of each 16-lane group
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int grp = lane >> 4, l16 = lane & 15, gbase = lane & ~15;
+    const int grp = lane >> 4, l16 = lane & 15;
     const int m = INDEXED ? xm : a.m;
     const int g = (blockIdx.x * 4 + w) * 4 + grp;   // my group's problem
     const bool valid = g < nprob;
@@ -967,6 +989,9 @@ __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, 
     double Qr[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) Qr[j] = sQ[w][grp][l16][j];
+    const double *Qt = &sQ[w][grp][0][0];
+    double *sv = &sV[w][grp][0];
+    double ag[16];   // gathered weights
     const bool mine = l16 < n;
     double alpha = 0.0, val = 0.0;
     if (n <= 0) {
@@ -989,26 +1014,27 @@ __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, 
             Inv16 I;
 #pragma unroll
             for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
-            (void)inv16_insert(I, Qr, scale, S, i0, l16, gbase);   // a single vertex is always independent
+            (void)inv16_insert(I, Qr, Qt, sv, scale, S, i0, l16);   // a single vertex is always independent
             alpha = l16 == i0 ? 1.0 : 0.0;
             const double tol = 1.4210854715202004e-14 * scale;  // 64 eps * scale
             for (int it = 0; it < 3 * 16 + 8; ++it) {
                 double gi = 0.0;
+                group_allgather16(sv, l16, alpha, ag);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) gi = fma(Qr[j], __shfl(alpha, gbase + j, 64), gi);
+                for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
                 val = group_sum16(alpha * gi);
                 double gmin;
                 int jb;
                 group_argmin16((mine && !(((S | banned) >> l16) & 1u)) ? gi : kInf, l16, gmin, jb);
                 if (jb < 0 || !(gmin < val - tol)) break;
-                if (!inv16_insert(I, Qr, scale, S, jb, l16, gbase)) {
+                if (!inv16_insert(I, Qr, Qt, sv, scale, S, jb, l16)) {
                     banned |= 1u << jb;
                     continue;
                 }
                 for (int mi = 0; mi <= 16; ++mi) {
                     double beta;
                     if (!inv16_beta(I, beta)) {   // (degenerate weights: give the vertex up)
-                        if ((S >> jb) & 1u) inv16_remove(I, S, jb, l16, gbase);
+                        if ((S >> jb) & 1u) inv16_remove(I, sv, S, jb, l16);
                         banned |= 1u << jb;
                         break;
                     }
@@ -1024,13 +1050,14 @@ __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, 
                     group_argmin16(bad ? (den > 0.0 ? alpha / den : 0.0) : kInf, l16, theta, kr);
                     const double vnew = alpha + theta * (beta - alpha);
                     alpha = (in && l16 != kr) ? vnew : 0.0;
-                    inv16_remove(I, S, kr, l16, gbase);
+                    inv16_remove(I, sv, S, kr, l16);
                     if (kr == jb) banned |= 1u << jb;
                 }
             }
             double gi = 0.0;
+            group_allgather16(sv, l16, alpha, ag);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) gi = fma(Qr[j], __shfl(alpha, gbase + j, 64), gi);
+            for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
             val = group_sum16(alpha * gi);
         } else {
             // distance to the AFFINE hull: greedy maximal affinely independent subset (affine_min_norm)
@@ -1038,14 +1065,15 @@ __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, 
             Inv16 I;
 #pragma unroll
             for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
-            for (int k = 0; k < n; ++k) (void)inv16_insert(I, Qr, scale, S, k, l16, gbase);
+            for (int k = 0; k < n; ++k) (void)inv16_insert(I, Qr, Qt, sv, scale, S, k, l16);
             double beta = 0.0;
             const bool okb = S != 0u && inv16_beta(I, beta);
             alpha = (okb && ((S >> l16) & 1u)) ? beta : 0.0;
             if (!okb) alpha = l16 == 0 ? 1.0 : 0.0;
             double gi = 0.0;
+            group_allgather16(sv, l16, alpha, ag);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) gi = fma(Qr[j], __shfl(alpha, gbase + j, 64), gi);
+            for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
             val = group_sum16(alpha * gi);
         }
     }
