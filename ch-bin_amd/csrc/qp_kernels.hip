@@ -781,31 +781,65 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
 //     incrementally maintained inverse with one matrix row per lane (see Inv16).
 // Groups follow their own control flow (all branches are uniform within a group of 16 lanes).
 
+// Reductions over a 16-lane group = one DPP row: rotations inside the row are VALU moves (row_ror), no LDS
+// crossbar and no lgkmcnt wait.  The rotation butterfly (8, 4, 2, 1) adds the same pairs as the xor butterfly at
+// every level (the partial results are periodic), so every lane ends with the bit-identical value.
+template <int N>
+__device__ __forceinline__ int row_ror_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ double row_ror_f64(double v)
+{
+    const int lo = row_ror_i32<N>(__double2loint(v)), hi = row_ror_i32<N>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double group_sum16(double v)
 {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 16);
+    v += row_ror_f64<8>(v);
+    v += row_ror_f64<4>(v);
+    v += row_ror_f64<2>(v);
+    v += row_ror_f64<1>(v);
     return v;
 }
-// smallest key, ties to the lowest lane; key = +inf everywhere gives idx = -1
-__device__ __forceinline__ void group_argmin16(double key, int l16, double &kmin, int &idx)
+__device__ __forceinline__ double group_max16(double v)
 {
-    kmin = key;
-    idx = key < kInf ? l16 : -1;
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        const double ok = __shfl_xor(kmin, off, 16);
-        const int oi = __shfl_xor(idx, off, 16);
-        if (oi >= 0 && (idx < 0 || ok < kmin || (ok == kmin && oi < idx))) { kmin = ok; idx = oi; }
-    }
+    v = fmax(v, row_ror_f64<8>(v));
+    v = fmax(v, row_ror_f64<4>(v));
+    v = fmax(v, row_ror_f64<2>(v));
+    v = fmax(v, row_ror_f64<1>(v));
+    return v;
+}
+__device__ __forceinline__ double group_min16(double v)
+{
+    v = fmin(v, row_ror_f64<8>(v));
+    v = fmin(v, row_ror_f64<4>(v));
+    v = fmin(v, row_ror_f64<2>(v));
+    v = fmin(v, row_ror_f64<1>(v));
+    return v;
+}
+// smallest key, ties to the lowest lane; key = +inf (or NaN) everywhere gives idx = -1
+__device__ __forceinline__ void group_argmin16(double key, int lane, double &kmin, int &idx)
+{
+    kmin = group_min16(key);
+    const unsigned hit = (unsigned)(__ballot(key == kmin && key < kInf) >> (lane & 48)) & 0xFFFFu;
+    idx = hit ? __ffs(hit) - 1 : -1;
 }
 
 // The affine sub-problem (Q_SS + s 11^T) b = 1, beta = b / sum(b) is solved through the explicit
 // inverse H of the lifted support Gram, kept up to date as vertices enter and leave (lane i holds
 // row i of H, zeros outside the support).  Entering / leaving is a bordering / Schur update whose
-// broadcasts are independent of each other -- a few shuffle rounds deep, where an elimination from
+// broadcasts are independent of each other -- a few LDS rounds deep, where an elimination from
 // scratch is a 16-step dependent chain.  The pivot of the update is the Schur complement delta, the
 // same quantity whose collapse marks an affinely dependent support in solve_affine<M>.
+#ifdef CHB_DEV_KNOBS   // developer builds (tools/m15_probe.py): iteration statistics of the 16-lane solver
+__device__ unsigned long long g_qp16_stats[8];
+#define QP16_STAT(i, v) do { if (l16 == 0) atomicAdd(&g_qp16_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define QP16_STAT(i, v) do { } while (0)
+#endif
+
 struct Inv16 {
     double H[16];
 };
@@ -826,63 +860,57 @@ __device__ __forceinline__ void group_allgather16(double *sv, int l16, double v,
     __builtin_amdgcn_wave_barrier();
 }
 
+#ifndef CHB_QP16_OCC
+#define CHB_QP16_OCC 3   // wavefronts per SIMD the 16-lane solver is compiled for (168 VGPRs)
+#endif
 constexpr int kQ16Ld = 18;   // row stride of the 16 x 16 Gram tile in LDS (16-byte aligned rows)
 
 // vertex v enters: false (and no change) when it is affinely dependent on the support.
-// Qt = the group's Gram tile in LDS (row stride kQ16Ld), sv = its 16-double exchange row.
-__device__ __forceinline__ bool inv16_insert(Inv16 &I, const double (&Qr)[16], const double *Qt, double *sv, double s,
-                                             unsigned &S, int v, int l16)
+// Qt = the group's LIFTED Gram tile in LDS (Q + s, row stride kQ16Ld), sv = its 16-double exchange row.
+// Rows and columns of H outside the support are zero, so the products below need no support mask.
+__device__ __forceinline__ bool inv16_insert(Inv16 &I, const double *Qt, double *sv, unsigned &S, int v, int l16)
 {
-    // a_j = Q[v][j] + s for j in S (row v of the tile, a broadcast read); u = H a
-    double u = 0.0, a_own = 0.0, avv = 0.0;
+    // a = lifted row v (a broadcast read); u = H a
+    double u = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; j += 2) {
         const double2 t = *reinterpret_cast<const double2 *>(Qt + v * kQ16Ld + j);
-        const double a0 = t.x + s, a1 = t.y + s;
-        if ((S >> j) & 1u) u = fma(I.H[j], a0, u);
-        if ((S >> (j + 1)) & 1u) u = fma(I.H[j + 1], a1, u);
-        a_own = (j == l16) ? a0 : ((j + 1 == l16) ? a1 : a_own);
-        avv = (j == v) ? a0 : ((j + 1 == v) ? a1 : avv);
+        u = fma(I.H[j], t.x, u);
+        u = fma(I.H[j + 1], t.y, u);
     }
-    const bool in = (S >> l16) & 1u;
-    double delta = avv - group_sum16(in ? a_own * u : 0.0);
+    const double a_own = Qt[v * kQ16Ld + l16], avv = Qt[v * kQ16Ld + v];
+    double delta = avv - group_sum16(a_own * u);
     double ug[16];
     if (!(delta > 1e-6 * avv)) {
+#ifdef CHB_DEV_KNOBS
+        if (l16 == 0) atomicAdd(&g_qp16_stats[4], 1ull);
+#endif
         // A small pivot is decided after one step of iterative refinement against the ORIGINAL rows
         // of Q: the stored inverse carries an error of eps * cond, which must not leak into the
         // test below (a dependent vertex has to come out at delta ~ eps * avv, as the Schur
         // complement of a factorisation does).
-        group_allgather16(sv, l16, in ? u : 0.0, ug);
+        const bool in = (S >> l16) & 1u;
+        group_allgather16(sv, l16, u, ug);
         double r = a_own;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if ((S >> j) & 1u) r = fma(-(Qr[j] + s), ug[j], r);
+        for (int j = 0; j < 16; ++j) r = fma(-Qt[l16 * kQ16Ld + j], ug[j], r);   // u is zero outside the support
         r = in ? r : 0.0;
         group_allgather16(sv, l16, r, ug);
         double du = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if ((S >> j) & 1u) du = fma(I.H[j], ug[j], du);
+        for (int j = 0; j < 16; ++j) du = fma(I.H[j], ug[j], du);
         u += du;
-        delta = avv - group_sum16(in ? a_own * u : 0.0);
+        delta = avv - group_sum16(a_own * u);
     }
     if (!(delta > 1e-13 * avv)) return false;
     const double inv = 1.0 / delta;
-    const double ui = in ? u : 0.0;
-    group_allgather16(sv, l16, ui, ug);
+    // bordering: H' = H + w w^T / delta with w = (u on the support, -1 at v, 0 elsewhere)
+    const double w = l16 == v ? -1.0 : u;
+    group_allgather16(sv, l16, w, ug);
+    const double f = w * inv;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double uj = ug[j];
-        double h;
-        if (l16 == v) h = (j == v) ? inv : -uj * inv;                      // the new row
-        else h = (j == v) ? -ui * inv : fma(ui * inv, uj, I.H[j]);         // old rows + the new column
-        I.H[j] = h;
-    }
+    for (int j = 0; j < 16; ++j) I.H[j] = fma(f, ug[j], I.H[j]);
     S |= 1u << v;
-    if (!in && l16 != v) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
-    }
     return true;
 }
 
@@ -915,7 +943,7 @@ __device__ __forceinline__ bool inv16_beta(const Inv16 &I, double &beta)
 }
 
 template <bool INDEXED>
-__global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, const int *xq, const int *xhull,
+__global__ __launch_bounds__(256, CHB_QP16_OCC) void hull_qp16_kernel(QpArgs a, int nprob, const int *xq, const int *xhull,
                                                         const int *xn, int xm, double *xdist, double *xalpha)
 {
     __shared__ __attribute__((aligned(16))) double sQ[4][4][16][kQ16Ld];   // [wavefront][problem][row][col], padded
@@ -989,7 +1017,7 @@ __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, 
     double Qr[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) Qr[j] = sQ[w][grp][l16][j];
-    const double *Qt = &sQ[w][grp][0][0];
+    double *Qt = &sQ[w][grp][0][0];
     double *sv = &sV[w][grp][0];
     double ag[16];   // gathered weights
     const bool mine = l16 < n;
@@ -997,37 +1025,40 @@ __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, 
     if (n <= 0) {
         val = kInf;
     } else {
-        double diag = 0.0;
+        const double diag = Qt[l16 * kQ16Ld + l16];
+        const double scale = group_max16(mine ? diag : 0.0);
+        // the tile in LDS becomes the lifted Gram Q + scale (what inv16_insert reads); Qr keeps the plain rows
 #pragma unroll
-        for (int j = 0; j < 16; ++j) diag = (j == l16) ? Qr[j] : diag;
-        double scale = mine ? diag : 0.0;
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) scale = fmax(scale, __shfl_xor(scale, off, 16));
+        for (int j = 0; j < 16; j += 2)
+            *reinterpret_cast<double2 *>(Qt + l16 * kQ16Ld + j) = double2{Qr[j] + scale, Qr[j + 1] + scale};
+        __builtin_amdgcn_wave_barrier();
         if (!(scale > 0.0)) {   // every vertex coincides with the query (or NaN input)
             alpha = l16 == 0 ? 1.0 : 0.0;
             val = scale == 0.0 ? 0.0 : scale;
         } else if (a.metric == 0) {
             double best;
             int i0;
-            group_argmin16(mine ? diag : kInf, l16, best, i0);
+            group_argmin16(mine ? diag : kInf, lane, best, i0);
             unsigned S = 0u, banned = 0u;
             Inv16 I;
 #pragma unroll
             for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
-            (void)inv16_insert(I, Qr, Qt, sv, scale, S, i0, l16);   // a single vertex is always independent
+            (void)inv16_insert(I, Qt, sv, S, i0, l16);   // a single vertex is always independent
             alpha = l16 == i0 ? 1.0 : 0.0;
             const double tol = 1.4210854715202004e-14 * scale;  // 64 eps * scale
+            QP16_STAT(0, 1);
             for (int it = 0; it < 3 * 16 + 8; ++it) {
                 double gi = 0.0;
+                QP16_STAT(1, 1);
                 group_allgather16(sv, l16, alpha, ag);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
                 val = group_sum16(alpha * gi);
                 double gmin;
                 int jb;
-                group_argmin16((mine && !(((S | banned) >> l16) & 1u)) ? gi : kInf, l16, gmin, jb);
+                group_argmin16((mine && !(((S | banned) >> l16) & 1u)) ? gi : kInf, lane, gmin, jb);
                 if (jb < 0 || !(gmin < val - tol)) break;
-                if (!inv16_insert(I, Qr, Qt, sv, scale, S, jb, l16)) {
+                if (!inv16_insert(I, Qt, sv, S, jb, l16)) {
                     banned |= 1u << jb;
                     continue;
                 }
@@ -1044,16 +1075,18 @@ __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, 
                         alpha = in ? beta : 0.0;
                         break;
                     }
+                    QP16_STAT(2, 1);
                     const double den = alpha - beta;
                     double theta;
                     int kr;
-                    group_argmin16(bad ? (den > 0.0 ? alpha / den : 0.0) : kInf, l16, theta, kr);
+                    group_argmin16(bad ? (den > 0.0 ? alpha / den : 0.0) : kInf, lane, theta, kr);
                     const double vnew = alpha + theta * (beta - alpha);
                     alpha = (in && l16 != kr) ? vnew : 0.0;
                     inv16_remove(I, sv, S, kr, l16);
                     if (kr == jb) banned |= 1u << jb;
                 }
             }
+            QP16_STAT(3, __popc(S));
             double gi = 0.0;
             group_allgather16(sv, l16, alpha, ag);
 #pragma unroll
@@ -1065,7 +1098,7 @@ __global__ __launch_bounds__(256, 3) void hull_qp16_kernel(QpArgs a, int nprob, 
             Inv16 I;
 #pragma unroll
             for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
-            for (int k = 0; k < n; ++k) (void)inv16_insert(I, Qr, Qt, sv, scale, S, k, l16);
+            for (int k = 0; k < n; ++k) (void)inv16_insert(I, Qt, sv, S, k, l16);
             double beta = 0.0;
             const bool okb = S != 0u && inv16_beta(I, beta);
             alpha = (okb && ((S >> l16) & 1u)) ? beta : 0.0;
@@ -1415,3 +1448,18 @@ void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const 
 }
 
 }  // namespace chb
+
+#ifdef CHB_DEV_KNOBS
+// developer builds only: [0] problems solved, [1] major iterations, [2] ratio-test removals, [3] final support
+// sizes (sum), [4] small-pivot refinements of inv16_insert
+extern "C" int chb_dev_qp16_stats(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(chb::g_qp16_stats), 8 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    if (reset) {
+        const unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(chb::g_qp16_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

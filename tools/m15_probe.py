@@ -1,4 +1,7 @@
-"""Developer probe: m = 15 sweep timing, corral-overflow counts, parity against the oracle on a prefix."""
+"""Developer probe: m = 15 sweep timing, 16-lane solver iteration statistics (developer library only), shortlist
+width histogram, parity against the oracle on a prefix.
+usage: CHBIN_LIB=ch-bin_amd/libchbin_hip_dev.so python tools/m15_probe.py [m]"""
+import ctypes
 import os
 import sys
 import time
@@ -16,11 +19,27 @@ perms = synth.draw_permutations(initial, 3, seed=0)
 ctx = _lib.Context(0)
 ctx.set_samples(X)
 lab, _, _ = ctx.fit_cluster(B, initial, perms[:1], m, 1)
+lib = ctypes.CDLL(_lib.LIB_PATH)
+have = hasattr(lib, "chb_dev_qp16_stats")
+st = (ctypes.c_ulonglong * 8)()
+if have:
+    lib.chb_dev_qp16_stats(st, 1)
 t = time.perf_counter()
 for _ in range(3):
     lab, _, _ = ctx.fit_cluster(B, initial, perms[:1], m, 1)
 dt = (time.perf_counter() - t) / 3
 print(f"m={m}: {dt*1e3:.2f} ms/sweep, slow pairs (last round) {ctx.counter('slow_pairs_last_round')}, overflow {ctx.counter('prefilter_overflow')}")
+if have:
+    lib.chb_dev_qp16_stats(st, 0)
+    p = max(st[0], 1)
+    print(f"solver: {st[0]} problems, {st[1]/p:.2f} major iterations, {st[2]/p:.2f} removals, final support {st[3]/p:.2f}, "
+          f"{st[4]/p:.3f} small-pivot refinements per problem")
+for n in (8, 12, 15, 16, 20, 24, 32, 48):
+    try:
+        print(f"  shortlist <= {n}: {ctx.counter('shortlist_le%d_last_batch' % n)}", end="")
+    except Exception:
+        pass
+print()
 ns = 40
 lab_o, _ = O.sweep(X, B, initial, perms[0][:ns], m)
 print("prefix parity:", np.array_equal(lab_o[perms[0][:ns]], lab[perms[0][:ns]]))
