@@ -942,182 +942,565 @@ __device__ __forceinline__ bool inv16_beta(const Inv16 &I, double &beta)
     return sum > 0.0;
 }
 
+// phase 2 of the 16-lane kernels: the hull (metric 0) or affine-hull distance SQUARED of the group's problem.
+// Qt = the group's plain shifted Gram tile in LDS (rows / columns >= n finite, e.g. zero), sv = its exchange row;
+// lane l16 owns vertex l16 (n <= 16 vertices, n > 0) and returns its weight in `alpha`.
+__device__ __forceinline__ double solve16(double *Qt, double *sv, int n, int metric, int lane, double &alpha)
+{
+    const int l16 = lane & 15;
+    double Qr[16];
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const double2 t = *reinterpret_cast<const double2 *>(Qt + l16 * kQ16Ld + j);
+        Qr[j] = t.x; Qr[j + 1] = t.y;
+    }
+    double ag[16];   // gathered weights
+    const bool mine = l16 < n;
+    double val = 0.0;
+    alpha = 0.0;
+    const double diag = Qt[l16 * kQ16Ld + l16];
+    const double scale = group_max16(mine ? diag : 0.0);
+    // the tile in LDS becomes the lifted Gram Q + scale (what inv16_insert reads); Qr keeps the plain rows
+#pragma unroll
+    for (int j = 0; j < 16; j += 2)
+        *reinterpret_cast<double2 *>(Qt + l16 * kQ16Ld + j) = double2{Qr[j] + scale, Qr[j + 1] + scale};
+    __builtin_amdgcn_wave_barrier();
+    if (!(scale > 0.0)) {   // every vertex coincides with the query (or NaN input)
+        alpha = l16 == 0 ? 1.0 : 0.0;
+        val = scale == 0.0 ? 0.0 : scale;
+    } else if (metric == 0) {
+        double best;
+        int i0;
+        group_argmin16(mine ? diag : kInf, lane, best, i0);
+        unsigned S = 0u, banned = 0u;
+        Inv16 I;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
+        (void)inv16_insert(I, Qt, sv, S, i0, l16);   // a single vertex is always independent
+        alpha = l16 == i0 ? 1.0 : 0.0;
+        const double tol = 1.4210854715202004e-14 * scale;  // 64 eps * scale
+        QP16_STAT(0, 1);
+        for (int it = 0; it < 3 * 16 + 8; ++it) {
+            double gi = 0.0;
+            QP16_STAT(1, 1);
+            group_allgather16(sv, l16, alpha, ag);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
+            val = group_sum16(alpha * gi);
+            double gmin;
+            int jb;
+            group_argmin16((mine && !(((S | banned) >> l16) & 1u)) ? gi : kInf, lane, gmin, jb);
+            if (jb < 0 || !(gmin < val - tol)) break;
+            if (!inv16_insert(I, Qt, sv, S, jb, l16)) {
+                banned |= 1u << jb;
+                continue;
+            }
+            for (int mi = 0; mi <= 16; ++mi) {
+                double beta;
+                if (!inv16_beta(I, beta)) {   // (degenerate weights: give the vertex up)
+                    if ((S >> jb) & 1u) inv16_remove(I, sv, S, jb, l16);
+                    banned |= 1u << jb;
+                    break;
+                }
+                const bool in = (S >> l16) & 1u;
+                const bool bad = in && !(beta > 0.0);
+                if (((__ballot(bad) >> (lane & 48)) & 0xFFFFull) == 0ull) {
+                    alpha = in ? beta : 0.0;
+                    break;
+                }
+                QP16_STAT(2, 1);
+                const double den = alpha - beta;
+                double theta;
+                int kr;
+                group_argmin16(bad ? (den > 0.0 ? alpha / den : 0.0) : kInf, lane, theta, kr);
+                const double vnew = alpha + theta * (beta - alpha);
+                alpha = (in && l16 != kr) ? vnew : 0.0;
+                inv16_remove(I, sv, S, kr, l16);
+                if (kr == jb) banned |= 1u << jb;
+            }
+        }
+        QP16_STAT(3, __popc(S));
+        double gi = 0.0;
+        group_allgather16(sv, l16, alpha, ag);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
+        val = group_sum16(alpha * gi);
+    } else {
+        // distance to the AFFINE hull: greedy maximal affinely independent subset (affine_min_norm)
+        unsigned S = 0u;
+        Inv16 I;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
+        for (int k = 0; k < n; ++k) (void)inv16_insert(I, Qt, sv, S, k, l16);
+        double beta = 0.0;
+        const bool okb = S != 0u && inv16_beta(I, beta);
+        alpha = (okb && ((S >> l16) & 1u)) ? beta : 0.0;
+        if (!okb) alpha = l16 == 0 ? 1.0 : 0.0;
+        double gi = 0.0;
+        group_allgather16(sv, l16, alpha, ag);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
+        val = group_sum16(alpha * gi);
+    }
+    return val;
+}
+
+// One k-sweep of the matrix core over the 16 rows `idv` (lane (row, kq): row = lane & 15 supplies the row,
+// kq = lane >> 4 its features 4 kq .. 4 kq + 3 of every 16) shifted by the query row q: the 16 x 16 Gram tile,
+// lane (row, kq) ends with D[kq + 4 r][row] in acc[r].  TWO: a second row set idw and the tiles
+// <rows, rows> (acc), <rows, rows2> (acx: acx[r] = <row kq + 4 r of the first set, row `row` of the second>),
+// <rows2, rows2> (acw) from ONE read of every row.
+template <bool TWO>
+struct RowChunk16 {   // 32 features of the lane's rows: 2 x 4 doubles each
+    double2 v[4], x[4], u[TWO ? 4 : 1];
+};
+template <bool TWO>
+__device__ __forceinline__ void load_chunk16(RowChunk16<TWO> &c, const double *vptr, const double *wptr,
+                                             const double *qptr, int k0, int kq, int Dp)
+{
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int kk = k0 + 16 * t + 4 * kq;
+        const bool in = kk < Dp;   // Dp % 8 == 0 and kk % 4 == 0: all 4 in range
+        c.v[2 * t] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t) : double2{0.0, 0.0};
+        c.v[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
+        c.x[2 * t] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t) : double2{0.0, 0.0};
+        c.x[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
+        if (TWO) {
+            c.u[2 * t] = in ? *reinterpret_cast<const double2 *>(wptr + k0 + 16 * t) : double2{0.0, 0.0};
+            c.u[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(wptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
+        }
+    }
+}
+template <bool TWO>
+__device__ __forceinline__ void gram_tile16(const double *X, int Dp, int q, int idv, int idw, int kq, f64x4 &acc,
+                                            f64x4 &acx, f64x4 &acw)
+{
+    const double *vptr = X + (size_t)(idv >= 0 ? idv : q) * Dp + 4 * kq;   // a missing vertex reads the query row: y = 0
+    const double *wptr = X + (size_t)(idw >= 0 ? idw : q) * Dp + 4 * kq;
+    const double *qptr = X + (size_t)q * Dp + 4 * kq;
+    for (int k0 = 0; k0 < Dp; k0 += 32) {
+        RowChunk16<TWO> cur;
+        load_chunk16<TWO>(cur, vptr, wptr, qptr, k0, kq, Dp);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double y0 = cur.v[t].x - cur.x[t].x;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, acc, 0, 0, 0);
+            if (TWO) {
+                const double z0 = cur.u[t].x - cur.x[t].x;
+                acx = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, z0, acx, 0, 0, 0);
+                acw = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, z0, acw, 0, 0, 0);
+            }
+            const double y1 = cur.v[t].y - cur.x[t].y;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, acc, 0, 0, 0);
+            if (TWO) {
+                const double z1 = cur.u[t].y - cur.x[t].y;
+                acx = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, z1, acx, 0, 0, 0);
+                acw = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, z1, acw, 0, 0, 0);
+            }
+        }
+    }
+}
+
+constexpr int kExtraMax = 3;                                  // extra rows beside the tile (LDS budget: 3 workgroups per CU)
+constexpr int kExtraNP = kExtraMax * (kExtraMax + 1) / 2;
+// The same sweep for 16 rows plus ne <= kExtraMax EXTRA rows ide[0..ne) (the usual shape of a shortlist at m = 15:
+// 17 .. 19 candidates).  The matrix core forms the tile of the 16 rows; the few products with and between the extra
+// rows are vector FMAs on the lanes' feature slices: ae[b] = <row `row`, extra b>, ee[] = <extra b, extra b'>
+// (b' <= b, packed lower-triangular: ee[b (b + 1) / 2 + b']), complete on every lane
+// after the reduction over the four feature slices (lanes row, row + 16, row + 32, row + 48).
+__device__ __forceinline__ void gram_tile16_extra(const double *X, int Dp, int q, int idv, const int (&ide)[kExtraMax], int ne,
+                                                  int kq, f64x4 &acc, double (&ae)[kExtraMax], double (&ee)[kExtraNP])
+{
+    const double *vptr = X + (size_t)(idv >= 0 ? idv : q) * Dp + 4 * kq;
+    const double *qptr = X + (size_t)q * Dp + 4 * kq;
+    const double *eptr[kExtraMax];
+#pragma unroll
+    for (int b = 0; b < kExtraMax; ++b) eptr[b] = X + (size_t)(b < ne ? ide[b] : q) * Dp + 4 * kq;
+#pragma unroll
+    for (int b = 0; b < kExtraMax; ++b) ae[b] = 0.0;
+#pragma unroll
+    for (int e = 0; e < kExtraNP; ++e) ee[e] = 0.0;
+    for (int k0 = 0; k0 < Dp; k0 += 16) {
+        const bool in = k0 + 4 * kq < Dp;   // Dp % 8 == 0: all 4 in range
+        double y[4], z[kExtraMax][4];
+        {
+            const double2 v0 = in ? *reinterpret_cast<const double2 *>(vptr + k0) : double2{0.0, 0.0};
+            const double2 v1 = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 2) : double2{0.0, 0.0};
+            const double2 x0 = in ? *reinterpret_cast<const double2 *>(qptr + k0) : double2{0.0, 0.0};
+            const double2 x1 = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 2) : double2{0.0, 0.0};
+            double2 e0[kExtraMax], e1[kExtraMax];
+#pragma unroll
+            for (int b = 0; b < kExtraMax; ++b) {
+                e0[b] = x0; e1[b] = x1;
+                if (b < ne && in) {   // (wave-uniform in b < ne)
+                    e0[b] = *reinterpret_cast<const double2 *>(eptr[b] + k0);
+                    e1[b] = *reinterpret_cast<const double2 *>(eptr[b] + k0 + 2);
+                }
+            }
+            y[0] = v0.x - x0.x; y[1] = v0.y - x0.y; y[2] = v1.x - x1.x; y[3] = v1.y - x1.y;
+#pragma unroll
+            for (int b = 0; b < kExtraMax; ++b) {
+                z[b][0] = e0[b].x - x0.x; z[b][1] = e0[b].y - x0.y; z[b][2] = e1[b].x - x1.x; z[b][3] = e1[b].y - x1.y;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y[t], y[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < kExtraMax; ++b) {
+            if (b < ne) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ae[b] = fma(y[t], z[b][t], ae[b]);
+#pragma unroll
+                for (int b2 = 0; b2 <= b; ++b2)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ee[b * (b + 1) / 2 + b2] = fma(z[b][t], z[b2][t], ee[b * (b + 1) / 2 + b2]);
+            }
+        }
+    }
+    // sum over the four feature slices
+#pragma unroll
+    for (int b = 0; b < kExtraMax; ++b) {
+        ae[b] += __shfl_xor(ae[b], 16, 64);
+        ae[b] += __shfl_xor(ae[b], 32, 64);
+    }
+#pragma unroll
+    for (int e = 0; e < kExtraNP; ++e) {
+        ee[e] += __shfl_xor(ee[e], 16, 64);
+        ee[e] += __shfl_xor(ee[e], 32, 64);
+    }
+}
+
+// List-based form: the vertex lists are given (a.lists / explicit problems).  Active mode (a.active): the listed
+// pairs only, walked grid-stride.
 template <bool INDEXED>
 __global__ __launch_bounds__(256, CHB_QP16_OCC) void hull_qp16_kernel(QpArgs a, int nprob, const int *xq, const int *xhull,
-                                                        const int *xn, int xm, double *xdist, double *xalpha)
+                                                        const int *xn, int xm, double *xdist, double *xalpha, Gate gate)
 {
+    CHB_GATE(gate);
     __shared__ __attribute__((aligned(16))) double sQ[4][4][16][kQ16Ld];   // [wavefront][problem][row][col], padded
     __shared__ __attribute__((aligned(16))) double sV[4][4][16];           // exchange row of each 16-lane group
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
     const int m = INDEXED ? xm : a.m;
-    const int g = (blockIdx.x * 4 + w) * 4 + grp;   // my group's problem
-    const bool valid = g < nprob;
-    int n = 0, idm = -1, qid = 0;
-    size_t slot = 0;
-    if (valid) {
+    const int *act = INDEXED ? nullptr : a.active;
+    if (act != nullptr) nprob = *a.n_active;
+    for (int gw = (blockIdx.x * 4 + w) * 4; gw < nprob; gw += (int)gridDim.x * 16) {   // wave-uniform
+        const int g = gw + grp;   // my group's problem
+        const bool valid = g < nprob;
+        int n = 0, idm = -1, qid = 0, pr = 0;
+        size_t slot = 0;
+        if (valid) {
+            if (INDEXED) {
+                qid = xq[g];
+                n = xn[g];
+                if (l16 < n) idm = xhull[(size_t)g * m + l16];
+            } else {
+                pr = act ? act[g] : g;
+                const int pos = a.pos_begin + pr / a.B, c = pr - (pr / a.B) * a.B;
+                qid = a.bq[pos];
+                slot = (size_t)c * a.Kcap + pos;
+                n = a.lists.cnt[slot];
+                if (l16 < n) idm = a.lists.idx[slot * m + l16];
+            }
+        }
+        bool changed = valid;
+        if (!INDEXED && a.prev.idx != nullptr && act == nullptr && valid)
+            changed = a.prev.cnt[slot] != n || (l16 < n && a.prev.idx[slot * m + l16] != idm);
+        const bool doit = ((__ballot(changed) >> (16 * grp)) & 0xFFFFull) != 0ull;   // else: keep the stored distance
+
+        // ---- phase 1: Gram of the shifted vertices, one matrix-core tile per problem
+        const int row = lane & 15, kq = lane >> 4;
+#pragma unroll 1
+        for (int p = 0; p < 4; ++p) {
+            const int np = __shfl(n, 16 * p, 64);
+            const bool go = __shfl(doit ? 1 : 0, 16 * p, 64) != 0 && np > 0;
+            const int id = __shfl(idm, 16 * p + row, 64);
+            const int q = __shfl(qid, 16 * p, 64);
+            if (!go) continue;   // wave-uniform
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0}, d0 = acc, d1 = acc;
+            gram_tile16<false>(a.X, a.Dp, q, id, -1, kq, acc, d0, d1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sQ[w][p][kq + 4 * r][row] = acc[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wavefront's LDS writes have landed
+        if (!valid || !doit) continue;
+
+        // ---- phase 2: one problem per 16-lane group
+        double alpha = 0.0;
+        const double val = n <= 0 ? kInf : solve16(&sQ[w][grp][0][0], &sV[w][grp][0], n, a.metric, lane, alpha);
+        const double dist = n <= 0 ? kInf : sqrt(fmax(val, 0.0));
         if (INDEXED) {
-            qid = xq[g];
-            n = xn[g];
-            if (l16 < n) idm = xhull[(size_t)g * m + l16];
-        } else {
-            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
-            qid = a.bq[pos];
-            slot = (size_t)c * a.Kcap + pos;
-            n = a.lists.cnt[slot];
-            if (l16 < n) idm = a.lists.idx[slot * m + l16];
+            if (l16 == 0) xdist[g] = dist;
+            if (xalpha && l16 < m) xalpha[(size_t)g * m + l16] = alpha;
+        } else if (l16 == 0) {
+            const int pos = a.pos_begin + pr / a.B, c = pr - (pr / a.B) * a.B;
+            a.dist[(size_t)pos * a.B + c] = dist;
         }
     }
-    bool changed = valid;
-    if (!INDEXED && a.prev.idx != nullptr && valid)
-        changed = a.prev.cnt[slot] != n || (l16 < n && a.prev.idx[slot * m + l16] != idm);
-    const bool doit = ((__ballot(changed) >> (16 * grp)) & 0xFFFFull) != 0ull;   // else: keep the stored distance
+}
 
-    // ---- phase 1: Gram of the shifted vertices, one matrix-core tile per problem
+// Fused selection + hull distance for 5 < m <= 16 (the same contract as hull_select_qp_kernel: FusedArgs, tie
+// rule kTieRel, pairs it does not decide are appended to `slow`).  One (position, bin) pair per 16-lane group.
+// A pair's candidates (base shortlist, then the batch's own entries) are read ONCE:
+//   n <= 16: one matrix-core tile (Gram of all candidates);
+//   17 .. 20 (the usual excess at m = 15): the tile of candidates 0..15 plus the n - 16 extra rows by vector FMAs;
+//   21 .. 32: two tiles and the block between them (ranked and scattered inside the sweep loop);
+//   n > 32, or a near-tie between ranks m - 1 and m: exact path.
+// The diagonal = the squared distances ranks the candidates; the entries between the m nearest become the hull's
+// Gram tile (vertex slot = rank).  For n <= 20 that happens after the sweeps, the four pairs of the wavefront
+// side by side (16 lanes each: lane i owns candidate i's row of the raw tile and moves it to its slot).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_kernel(FusedArgs a, int nprob, Gate gate)
+{
+    CHB_GATE(gate);
+    __shared__ __attribute__((aligned(16))) double sQ[WAVES][4][16][kQ16Ld];
+    __shared__ __attribute__((aligned(16))) double sV[WAVES][4][16];
+    __shared__ __attribute__((aligned(16))) double sAE[WAVES][4][kExtraMax][16];   // <candidate i, extra b> of each pair
+    __shared__ __attribute__((aligned(16))) double sEE[WAVES][4][kExtraNP];        // <extra b, extra b'>
+    __shared__ __attribute__((aligned(16))) double sGD[WAVES][4][20];      // squared distances of a pair's candidates
+    __shared__ __attribute__((aligned(16))) int sGI[WAVES][4][20];         // their sample indices
+    __shared__ __attribute__((aligned(16))) int sGN[WAVES][4][20];         // their vertex slots (-1: not selected)
+    __shared__ double sTh[WAVES][4][2];   // squared distances of ranks m - 1 and m
+    __shared__ int sSlowN, sSlowBase;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int grp = lane >> 4, l16 = lane & 15;
+    const int m = a.m;
+    // the two-tile form works on one pair at a time inside the sweep loop and borrows the wavefront's group arrays
+    // (32 of the 80 entries each), which the groups only use after the loop
+    double *sDw = &sGD[w][0][0];
+    int *sIdw = &sGI[w][0][0], *sNeww = &sGN[w][0][0];
+    if (threadIdx.x == 0) sSlowN = 0;
+    __syncthreads();
+    const int gw = (blockIdx.x * WAVES + w) * 4;
+    const int g = gw + grp;
+    const bool valid = g < nprob;
+    int nb = 0, nu = 0, qid = 0;
+    bool changed = valid;
+    const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+    const size_t slot = (size_t)c * a.Kcap + pos;
+    if (valid) {
+        qid = a.bq[pos];
+        nb = a.cand_cnt[slot];
+        if (a.candu != nullptr) nu = a.candu_cnt[slot];
+        // unchanged set of batch-entry candidates (the base candidates are fixed during a batch): keep the distance
+        if (a.candp != nullptr && a.candp_cnt[slot] == nu) {
+            bool same = true;
+            for (int i = l16; i < nu; i += 16) {
+                const int u = a.candu[slot * kCandCapU + i];
+                bool f = false;
+                for (int j = 0; j < nu; ++j) f = f || a.candp[slot * kCandCapU + j] == u;
+                same = same && f;
+            }
+            changed = ((__ballot(!same) >> (lane & 48)) & 0xFFFFull) != 0ull;
+        }
+    }
+    const int n = nb + nu;
+    const bool work = changed && n > 0 && n <= 32;
+    bool slow = changed && n > 32;
+    int nsel = n < m ? n : m;   // vertices of the hull problem
+
+    // ---- phase 1: the wavefront's four pairs one after the other, all 64 lanes on one pair
     const int row = lane & 15, kq = lane >> 4;
 #pragma unroll 1
     for (int p = 0; p < 4; ++p) {
         const int np = __shfl(n, 16 * p, 64);
-        const bool go = __shfl(doit ? 1 : 0, 16 * p, 64) != 0 && np > 0;
-        if (!go) continue;   // wave-uniform
-        const int id = __shfl(idm, 16 * p + row, 64);
+        const int nbp = __shfl(nb, 16 * p, 64);
         const int q = __shfl(qid, 16 * p, 64);
-        const bool live = id >= 0;
-        const double *vptr = a.X + (size_t)(live ? id : q) * a.Dp + 4 * kq;
-        const double *qptr = a.X + (size_t)q * a.Dp + 4 * kq;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < a.Dp; k0 += 32) {
-            double2 v[4], x[4];
+        const bool go = __shfl(work ? 1 : 0, 16 * p, 64) != 0;
+        if (!go) continue;   // wave-uniform
+        const int gp = gw + p;
+        const size_t slot_p = (size_t)(gp - (gp / a.B) * a.B) * a.Kcap + (a.pos_begin + gp / a.B);
+        const bool two = np > 16 + kExtraMax;
+        const int ne = (np > 16 && !two) ? np - 16 : 0;
+        int idA = -1, idB = -1;
+        if (row < np) idA = row < nbp ? a.cand[slot_p * kCandCap + row] : a.candu[slot_p * kCandCapU + (row - nbp)];
+        double *Qp = &sQ[w][p][0][0];
+        if (!two) {
+            f64x4 aa = {0.0, 0.0, 0.0, 0.0};
+            if (ne > 0) {
+                int ide[kExtraMax];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int kk = k0 + 16 * t + 4 * kq;
-                const bool in = kk < a.Dp;   // Dp % 8 == 0 and kk % 4 == 0: all 4 in range
-                v[2 * t] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t) : double2{0.0, 0.0};
-                v[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
-                x[2 * t] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t) : double2{0.0, 0.0};
-                x[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
+                for (int b = 0; b < kExtraMax; ++b) {
+                    ide[b] = -1;
+                    if (b < ne)
+                        ide[b] = 16 + b < nbp ? a.cand[slot_p * kCandCap + 16 + b]
+                                              : a.candu[slot_p * kCandCapU + (16 + b - nbp)];
+                }
+                double ae[kExtraMax], ee[kExtraNP];
+                gram_tile16_extra(a.X, a.Dp, q, idA, ide, ne, kq, aa, ae, ee);
+                if (kq == 0) {
+#pragma unroll
+                    for (int b = 0; b < kExtraMax; ++b) sAE[w][p][b][row] = ae[b];
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int e = 0; e < kExtraNP; ++e) sEE[w][p][e] = ee[e];
+                }
+            } else {
+                f64x4 d0 = aa, d1 = aa;
+                gram_tile16<false>(a.X, a.Dp, q, idA, -1, kq, aa, d0, d1);
             }
+            // the raw tile of candidates 0..15; selection (np > m) follows after the loop
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const double y0 = v[t].x - x[t].x;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, acc, 0, 0, 0);
-                const double y1 = v[t].y - x[t].y;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, acc, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) Qp[(kq + 4 * r) * kQ16Ld + row] = aa[r];
+            continue;
+        }
+        // ---- two tiles (up to 32 candidates): rank and scatter here, the accumulators are this pair's
+        if (16 + row < np)
+            idB = 16 + row < nbp ? a.cand[slot_p * kCandCap + 16 + row] : a.candu[slot_p * kCandCapU + (16 + row - nbp)];
+        f64x4 aa = {0.0, 0.0, 0.0, 0.0}, ab = aa, bb = aa;
+        gram_tile16<true>(a.X, a.Dp, q, idA, idB, kq, aa, ab, bb);
+        // squared distances = the diagonals (lane (row, kq = row & 3) holds D[row][row] in acc[row >> 2])
+        if ((row & 3) == kq) {
+            const int rr = row >> 2;
+            const double dA = rr == 0 ? aa[0] : rr == 1 ? aa[1] : rr == 2 ? aa[2] : aa[3];
+            const double dB = rr == 0 ? bb[0] : rr == 1 ? bb[1] : rr == 2 ? bb[2] : bb[3];
+            sDw[row] = dA; sIdw[row] = idA;
+            sDw[16 + row] = dB; sIdw[16 + row] = idB;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // rank of candidate lane & 31 by (squared distance, index): each half of the wavefront scans 16 entries
+        {
+            const int cI = lane & 31, u0 = (lane >> 5) * 16;
+            const double dc = cI < np ? sDw[cI] : kInf;
+            const int ic = sIdw[cI];
+            int rank = 0;
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
+                const int u = u0 + t;
+                const double2 dd = *reinterpret_cast<const double2 *>(&sDw[u]);
+                const int2 ii = *reinterpret_cast<const int2 *>(&sIdw[u]);
+                rank += (u < np && u != cI && (dd.x < dc || (dd.x == dc && ii.x < ic))) ? 1 : 0;
+                rank += (u + 1 < np && u + 1 != cI && (dd.y < dc || (dd.y == dc && ii.y < ic))) ? 1 : 0;
+            }
+            rank += __shfl_xor(rank, 32, 64);
+            if (lane < 32) {
+                sNeww[cI] = (cI < np && rank < m) ? rank : -1;
+                if (cI < np && rank == m - 1) sTh[w][p][0] = dc;
+                if (cI < np && rank == m) sTh[w][p][1] = dc;
             }
         }
-        // lane holds D[kq + 4 r][row]
+        __builtin_amdgcn_wave_barrier();
+        const double t0 = sTh[w][p][0], t1 = sTh[w][p][1];
+        const bool tie = !(t1 - t0 > kTieRel * t1);   // (also catches NaN)
+        if (tie) {
+            if (grp == p) slow = true;
+            continue;
+        }
+        // exactly m candidates are selected: the scatter below writes every entry between vertex slots < m once;
+        // rows / columns m .. 15 of the tile are cleared (the solver multiplies them by zero weights)
+        for (int v = m; v < 16; ++v)
+            if (lane < 16) { Qp[v * kQ16Ld + lane] = 0.0; Qp[lane * kQ16Ld + v] = 0.0; }
+        const int njA = sNeww[row], njB = sNeww[16 + row];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sQ[w][p][kq + 4 * r][row] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+            const int niA = sNeww[kq + 4 * r], niB = sNeww[16 + kq + 4 * r];
+            if (niA >= 0 && njA >= 0) Qp[niA * kQ16Ld + njA] = aa[r];
+            if (niA >= 0 && njB >= 0) { Qp[niA * kQ16Ld + njB] = ab[r]; Qp[njB * kQ16Ld + niA] = ab[r]; }
+            if (niB >= 0 && njB >= 0) Qp[niB * kQ16Ld + njB] = bb[r];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wavefront's LDS writes have landed
-    if (!valid || !doit) return;
 
-    // ---- phase 2: one problem per 16-lane group
-    double Qr[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) Qr[j] = sQ[w][grp][l16][j];
-    double *Qt = &sQ[w][grp][0][0];
-    double *sv = &sV[w][grp][0];
-    double ag[16];   // gathered weights
-    const bool mine = l16 < n;
-    double alpha = 0.0, val = 0.0;
-    if (n <= 0) {
-        val = kInf;
-    } else {
-        const double diag = Qt[l16 * kQ16Ld + l16];
-        const double scale = group_max16(mine ? diag : 0.0);
-        // the tile in LDS becomes the lifted Gram Q + scale (what inv16_insert reads); Qr keeps the plain rows
-#pragma unroll
-        for (int j = 0; j < 16; j += 2)
-            *reinterpret_cast<double2 *>(Qt + l16 * kQ16Ld + j) = double2{Qr[j] + scale, Qr[j + 1] + scale};
+    // ---- selection for m < n <= 20, one pair per 16-lane group: lane i owns candidate i (and, i < n - 16, extra i)
+    if (work && n > m && n <= 16 + kExtraMax) {
+        double *Qt = &sQ[w][grp][0][0];
+        const int ne = n > 16 ? n - 16 : 0, nA = n - ne;
+        int idm = -1, ide = -1;
+        if (l16 < nA) idm = l16 < nb ? a.cand[slot * kCandCap + l16] : a.candu[slot * kCandCapU + (l16 - nb)];
+        if (l16 < ne) ide = 16 + l16 < nb ? a.cand[slot * kCandCap + 16 + l16] : a.candu[slot * kCandCapU + (16 + l16 - nb)];
+        const double dA = l16 < nA ? Qt[l16 * kQ16Ld + l16] : kInf;
+        const double dE = l16 < ne ? sEE[w][grp][l16 * (l16 + 1) / 2 + l16] : kInf;
+        sGD[w][grp][l16] = dA; sGI[w][grp][l16] = idm;
+        if (l16 < 4) { sGD[w][grp][16 + l16] = dE; sGI[w][grp][16 + l16] = ide; }   // (+inf / -1 beyond the extras)
         __builtin_amdgcn_wave_barrier();
-        if (!(scale > 0.0)) {   // every vertex coincides with the query (or NaN input)
-            alpha = l16 == 0 ? 1.0 : 0.0;
-            val = scale == 0.0 ? 0.0 : scale;
-        } else if (a.metric == 0) {
-            double best;
-            int i0;
-            group_argmin16(mine ? diag : kInf, lane, best, i0);
-            unsigned S = 0u, banned = 0u;
-            Inv16 I;
+        int rA = 0, rE = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
-            (void)inv16_insert(I, Qt, sv, S, i0, l16);   // a single vertex is always independent
-            alpha = l16 == i0 ? 1.0 : 0.0;
-            const double tol = 1.4210854715202004e-14 * scale;  // 64 eps * scale
-            QP16_STAT(0, 1);
-            for (int it = 0; it < 3 * 16 + 8; ++it) {
-                double gi = 0.0;
-                QP16_STAT(1, 1);
-                group_allgather16(sv, l16, alpha, ag);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
-                val = group_sum16(alpha * gi);
-                double gmin;
-                int jb;
-                group_argmin16((mine && !(((S | banned) >> l16) & 1u)) ? gi : kInf, lane, gmin, jb);
-                if (jb < 0 || !(gmin < val - tol)) break;
-                if (!inv16_insert(I, Qt, sv, S, jb, l16)) {
-                    banned |= 1u << jb;
-                    continue;
-                }
-                for (int mi = 0; mi <= 16; ++mi) {
-                    double beta;
-                    if (!inv16_beta(I, beta)) {   // (degenerate weights: give the vertex up)
-                        if ((S >> jb) & 1u) inv16_remove(I, sv, S, jb, l16);
-                        banned |= 1u << jb;
-                        break;
-                    }
-                    const bool in = (S >> l16) & 1u;
-                    const bool bad = in && !(beta > 0.0);
-                    if (((__ballot(bad) >> (16 * grp)) & 0xFFFFull) == 0ull) {
-                        alpha = in ? beta : 0.0;
-                        break;
-                    }
-                    QP16_STAT(2, 1);
-                    const double den = alpha - beta;
-                    double theta;
-                    int kr;
-                    group_argmin16(bad ? (den > 0.0 ? alpha / den : 0.0) : kInf, lane, theta, kr);
-                    const double vnew = alpha + theta * (beta - alpha);
-                    alpha = (in && l16 != kr) ? vnew : 0.0;
-                    inv16_remove(I, sv, S, kr, l16);
-                    if (kr == jb) banned |= 1u << jb;
-                }
-            }
-            QP16_STAT(3, __popc(S));
-            double gi = 0.0;
-            group_allgather16(sv, l16, alpha, ag);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
-            val = group_sum16(alpha * gi);
-        } else {
-            // distance to the AFFINE hull: greedy maximal affinely independent subset (affine_min_norm)
-            unsigned S = 0u;
-            Inv16 I;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
-            for (int k = 0; k < n; ++k) (void)inv16_insert(I, Qt, sv, S, k, l16);
-            double beta = 0.0;
-            const bool okb = S != 0u && inv16_beta(I, beta);
-            alpha = (okb && ((S >> l16) & 1u)) ? beta : 0.0;
-            if (!okb) alpha = l16 == 0 ? 1.0 : 0.0;
-            double gi = 0.0;
-            group_allgather16(sv, l16, alpha, ag);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
-            val = group_sum16(alpha * gi);
+        for (int u = 0; u < 20; u += 2) {
+            const double2 dd = *reinterpret_cast<const double2 *>(&sGD[w][grp][u]);
+            const int2 ii = *reinterpret_cast<const int2 *>(&sGI[w][grp][u]);
+            // (absent candidates carry +inf: they never precede a real one)
+            rA += (u != l16 && (dd.x < dA || (dd.x == dA && ii.x < idm))) ? 1 : 0;
+            rA += (u + 1 != l16 && (dd.y < dA || (dd.y == dA && ii.y < idm))) ? 1 : 0;
+            rE += (u != 16 + l16 && (dd.x < dE || (dd.x == dE && ii.x < ide))) ? 1 : 0;
+            rE += (u + 1 != 16 + l16 && (dd.y < dE || (dd.y == dE && ii.y < ide))) ? 1 : 0;
         }
+        const int newA = (l16 < nA && rA < m) ? rA : -1;
+        const int newE = (l16 < ne && rE < m) ? rE : -1;
+        sGN[w][grp][l16] = newA;
+        if (l16 < 4) sGN[w][grp][16 + l16] = newE;
+        if (l16 < nA && rA == m - 1) sTh[w][grp][0] = dA;
+        if (l16 < nA && rA == m) sTh[w][grp][1] = dA;
+        if (l16 < ne && rE == m - 1) sTh[w][grp][0] = dE;
+        if (l16 < ne && rE == m) sTh[w][grp][1] = dE;
+        // my candidate's row of the raw tile, its products with the extras, and (extra lanes) the extras' own block
+        double Qr[16], qe[kExtraMax], qx[kExtraMax];
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const double2 t = *reinterpret_cast<const double2 *>(Qt + l16 * kQ16Ld + j);
+            Qr[j] = t.x; Qr[j + 1] = t.y;
+        }
+#pragma unroll
+        for (int b = 0; b < kExtraMax; ++b) {
+            qe[b] = sAE[w][grp][b][l16];
+            const int hi = min(max(l16, b), kExtraMax - 1), lo = min(l16, b);
+            qx[b] = sEE[w][grp][hi * (hi + 1) / 2 + lo];   // <extra l16, extra b> (used by lanes < ne)
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double t0 = sTh[w][grp][0], t1 = sTh[w][grp][1];
+        if (!(t1 - t0 > kTieRel * t1)) {   // near-tie at the selection boundary (also catches NaN)
+            slow = true;
+        } else {
+            int nj[20];
+#pragma unroll
+            for (int u = 0; u < 20; u += 4) {
+                const int4 t = *reinterpret_cast<const int4 *>(&sGN[w][grp][u]);
+                nj[u] = t.x; nj[u + 1] = t.y; nj[u + 2] = t.z; nj[u + 3] = t.w;
+            }
+            // rows / columns m .. 15 of the tile are cleared (the solver multiplies them by zero weights)
+            for (int v = m; v < 16; ++v) { Qt[v * kQ16Ld + l16] = 0.0; Qt[l16 * kQ16Ld + v] = 0.0; }
+            if (newA >= 0) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (nj[j] >= 0) Qt[newA * kQ16Ld + nj[j]] = Qr[j];
+#pragma unroll
+                for (int b = 0; b < kExtraMax; ++b)
+                    if (b < ne && nj[16 + b] >= 0) {
+                        Qt[newA * kQ16Ld + nj[16 + b]] = qe[b];
+                        Qt[nj[16 + b] * kQ16Ld + newA] = qe[b];
+                    }
+            }
+            if (newE >= 0) {
+#pragma unroll
+                for (int b = 0; b < kExtraMax; ++b)
+                    if (b < ne && nj[16 + b] >= 0) Qt[newE * kQ16Ld + nj[16 + b]] = qx[b];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    const double dist = n <= 0 ? kInf : sqrt(fmax(val, 0.0));
-    if (INDEXED) {
-        if (l16 == 0) xdist[g] = dist;
-        if (xalpha && l16 < m) xalpha[(size_t)g * m + l16] = alpha;
-    } else if (l16 == 0) {
-        const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
-        a.dist[(size_t)pos * a.B + c] = dist;
+
+    // ---- the exact path's work list: one device-scope atomic per workgroup
+    {
+        const unsigned long long bal = __ballot(slow && l16 == 0);
+        const int nsl = __popcll(bal);
+        int wbase = 0;
+        if (lane == 0 && nsl > 0) wbase = atomicAdd(&sSlowN, nsl);
+        __syncthreads();
+        if (threadIdx.x == 0) sSlowBase = sSlowN > 0 ? atomicAdd(a.n_slow, sSlowN) : 0;
+        __syncthreads();
+        wbase = __shfl(wbase, 0, 64) + sSlowBase;
+        if (slow && l16 == 0) a.slow[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = g;
     }
+    if (!valid || !changed || slow) return;   // distance kept, or written by the exact path
+
+    // ---- phase 2: one pair per 16-lane group
+    double alpha = 0.0;
+    double dist = kInf;
+    if (n > 0) dist = sqrt(fmax(solve16(&sQ[w][grp][0][0], &sV[w][grp][0], nsel, a.metric, lane, alpha), 0.0));
+    if (l16 == 0) a.dist[(size_t)pos * a.B + c] = dist;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1401,8 +1784,12 @@ void dispatch(const QpArgs &a, int nprob, int m, const int *xq, const int *xhull
     else if (m <= 5) launch_one<5, 4, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
     else if (m <= 8) launch_one<8, 2, INDEXED>(a, nprob, m, xq, xhull, xn, xdist, xalpha, s);
     else
-        hipLaunchKernelGGL((hull_qp16_kernel<INDEXED>), dim3((nprob + 15) / 16), dim3(256), 0, s, a, nprob, xq, xhull,
-                           xn, m, xdist, xalpha);
+    {
+        int grid = (nprob + 15) / 16;
+        if (!INDEXED && a.active != nullptr) grid = std::min(grid, 1024);   // listed pairs (device-side count): grid-stride
+        hipLaunchKernelGGL((hull_qp16_kernel<INDEXED>), dim3(grid), dim3(256), 0, s, a, nprob, xq, xhull,
+                           xn, m, xdist, xalpha, g_gate);
+    }
 }
 
 }  // namespace
@@ -1413,13 +1800,18 @@ void launch_hull_qp(const QpArgs &a, hipStream_t s)
     dispatch<false>(a, nprob, a.m, nullptr, nullptr, nullptr, nullptr, nullptr, s);
 }
 
-bool fused_supported(int m) { return m >= 1 && m <= 5; }
+bool fused_supported(int m) { return m >= 1 && m <= 16; }
 
 void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
 {
     const int nprob = (a.pos_end - a.pos_begin) * a.B;
     if (nprob <= 0) return;
     constexpr int WV = 4;
+    if (a.m > 5) {   // 16 lanes per pair
+        hipLaunchKernelGGL((hull_select_qp16_kernel<WV>), dim3((nprob + 4 * WV - 1) / (4 * WV)), dim3(64 * WV), 0, s, a,
+                           nprob, g_gate);
+        return;
+    }
     const int grid = (nprob + 64 * WV - 1) / (64 * WV);
     hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
 }

@@ -28,13 +28,13 @@ t = time.perf_counter()
 for _ in range(3):
     lab, _, _ = ctx.fit_cluster(B, initial, perms[:1], m, 1)
 dt = (time.perf_counter() - t) / 3
-print(f"m={m}: {dt*1e3:.2f} ms/sweep, slow pairs (last round) {ctx.counter('slow_pairs_last_round')}, overflow {ctx.counter('prefilter_overflow')}")
+print(f"last batch K={ctx.counter('last_batch_k')} x B={B} pairs; m={m}: {dt*1e3:.2f} ms/sweep, slow pairs (last round) {ctx.counter('slow_pairs_last_round')}, overflow {ctx.counter('prefilter_overflow')}")
 if have:
     lib.chb_dev_qp16_stats(st, 0)
     p = max(st[0], 1)
     print(f"solver: {st[0]} problems, {st[1]/p:.2f} major iterations, {st[2]/p:.2f} removals, final support {st[3]/p:.2f}, "
           f"{st[4]/p:.3f} small-pivot refinements per problem")
-for n in (8, 12, 15, 16, 20, 24, 32, 48):
+for n in (14, 15, 16, 17, 18, 19, 20, 22, 24, 28, 32, 48):
     try:
         print(f"  shortlist <= {n}: {ctx.counter('shortlist_le%d_last_batch' % n)}", end="")
     except Exception:
