@@ -19,6 +19,7 @@
 // The result is the same projection distance the reference's QP defines (unique even when alpha
 // is not); agreement with the CPU oracle's Goldfarb-Idnani restatement is ~1e-13 relative.
 #include "chb_internal.h"
+#include <type_traits>
 
 #include <math.h>
 
@@ -787,7 +788,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
 template <int N>
 __device__ __forceinline__ int row_ror_i32(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, false);
+    // (every lane of the row is written: no `old` operand to initialise)
+    return __builtin_amdgcn_mov_dpp(v, 0x120 + N, 0xF, 0xF, false);
 }
 template <int N>
 __device__ __forceinline__ double row_ror_f64(double v)
@@ -839,6 +841,16 @@ __device__ unsigned long long g_qp16_stats[8];
 #else
 #define QP16_STAT(i, v) do { } while (0)
 #endif
+
+// 1 / x for normal, well-scaled x (the solver works on a Gram normalised to O(1)): hardware estimate + two Newton
+// steps, within an ulp or two of the correctly rounded quotient
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
 
 struct Inv16 {
     double H[16];
@@ -903,7 +915,7 @@ __device__ __forceinline__ bool inv16_insert(Inv16 &I, const double *Qt, double 
         delta = avv - group_sum16(a_own * u);
     }
     if (!(delta > 1e-13 * avv)) return false;
-    const double inv = 1.0 / delta;
+    const double inv = fast_rcp(delta);
     // bordering: H' = H + w w^T / delta with w = (u on the support, -1 at v, 0 elsewhere)
     const double w = l16 == v ? -1.0 : u;
     group_allgather16(sv, l16, w, ug);
@@ -938,7 +950,7 @@ __device__ __forceinline__ bool inv16_beta(const Inv16 &I, double &beta)
 #pragma unroll
     for (int j = 0; j < 16; ++j) b += I.H[j];
     const double sum = group_sum16(b);
-    beta = b / sum;
+    beta = b * fast_rcp(sum);
     return sum > 0.0;
 }
 
@@ -959,7 +971,16 @@ __device__ __forceinline__ double solve16(double *Qt, double *sv, int n, int met
     double val = 0.0;
     alpha = 0.0;
     const double diag = Qt[l16 * kQ16Ld + l16];
-    const double scale = group_max16(mine ? diag : 0.0);
+    const double scale0 = group_max16(mine ? diag : 0.0);
+    // The problem is normalised by a power of two (exact): the largest squared distance becomes `scale` in
+    // [0.5, 1), so thresholds and reciprocals see O(1) numbers whatever the units of the data.
+    int ex = 0;
+    if (scale0 > 0.0 && scale0 < kInf) (void)frexp(scale0, &ex);
+    ex = ex < -1000 ? -1000 : (ex > 1000 ? 1000 : ex);
+    const double dn = ldexp(1.0, -ex);
+    const double scale = scale0 * dn;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Qr[j] *= dn;
     // the tile in LDS becomes the lifted Gram Q + scale (what inv16_insert reads); Qr keeps the plain rows
 #pragma unroll
     for (int j = 0; j < 16; j += 2)
@@ -971,7 +992,7 @@ __device__ __forceinline__ double solve16(double *Qt, double *sv, int n, int met
     } else if (metric == 0) {
         double best;
         int i0;
-        group_argmin16(mine ? diag : kInf, lane, best, i0);
+        group_argmin16(mine ? diag * dn : kInf, lane, best, i0);
         unsigned S = 0u, banned = 0u;
         Inv16 I;
 #pragma unroll
@@ -1042,7 +1063,7 @@ __device__ __forceinline__ double solve16(double *Qt, double *sv, int n, int met
         for (int j = 0; j < 16; ++j) gi = fma(Qr[j], ag[j], gi);
         val = group_sum16(alpha * gi);
     }
-    return val;
+    return ldexp(val, ex);   // back to the data's units (exact)
 }
 
 // One k-sweep of the matrix core over the 16 rows `idv` (lane (row, kq): row = lane & 15 supplies the row,
@@ -1054,14 +1075,15 @@ template <bool TWO>
 struct RowChunk16 {   // 32 features of the lane's rows: 2 x 4 doubles each
     double2 v[4], x[4], u[TWO ? 4 : 1];
 };
-template <bool TWO>
+// FULL: the whole chunk lies inside the row (no range checks; only a row's last chunk can be partial)
+template <bool TWO, bool FULL>
 __device__ __forceinline__ void load_chunk16(RowChunk16<TWO> &c, const double *vptr, const double *wptr,
                                              const double *qptr, int k0, int kq, int Dp)
 {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int kk = k0 + 16 * t + 4 * kq;
-        const bool in = kk < Dp;   // Dp % 8 == 0 and kk % 4 == 0: all 4 in range
+        const bool in = FULL || kk < Dp;   // Dp % 8 == 0 and kk % 4 == 0: all 4 in range
         c.v[2 * t] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t) : double2{0.0, 0.0};
         c.v[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
         c.x[2 * t] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t) : double2{0.0, 0.0};
@@ -1073,36 +1095,48 @@ __device__ __forceinline__ void load_chunk16(RowChunk16<TWO> &c, const double *v
     }
 }
 template <bool TWO>
+__device__ __forceinline__ void mfma_chunk16(const RowChunk16<TWO> &cur, f64x4 &acc, f64x4 &acx, f64x4 &acw)
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double y0 = cur.v[t].x - cur.x[t].x;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, acc, 0, 0, 0);
+        if (TWO) {
+            const double z0 = cur.u[t].x - cur.x[t].x;
+            acx = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, z0, acx, 0, 0, 0);
+            acw = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, z0, acw, 0, 0, 0);
+        }
+        const double y1 = cur.v[t].y - cur.x[t].y;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, acc, 0, 0, 0);
+        if (TWO) {
+            const double z1 = cur.u[t].y - cur.x[t].y;
+            acx = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, z1, acx, 0, 0, 0);
+            acw = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, z1, acw, 0, 0, 0);
+        }
+    }
+}
+template <bool TWO>
 __device__ __forceinline__ void gram_tile16(const double *X, int Dp, int q, int idv, int idw, int kq, f64x4 &acc,
                                             f64x4 &acx, f64x4 &acw)
 {
     const double *vptr = X + (size_t)(idv >= 0 ? idv : q) * Dp + 4 * kq;   // a missing vertex reads the query row: y = 0
     const double *wptr = X + (size_t)(idw >= 0 ? idw : q) * Dp + 4 * kq;
     const double *qptr = X + (size_t)q * Dp + 4 * kq;
-    for (int k0 = 0; k0 < Dp; k0 += 32) {
+    const int Dfull = Dp & ~31;
+    int k0 = 0;
+    for (; k0 < Dfull; k0 += 32) {
         RowChunk16<TWO> cur;
-        load_chunk16<TWO>(cur, vptr, wptr, qptr, k0, kq, Dp);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const double y0 = cur.v[t].x - cur.x[t].x;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, acc, 0, 0, 0);
-            if (TWO) {
-                const double z0 = cur.u[t].x - cur.x[t].x;
-                acx = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, z0, acx, 0, 0, 0);
-                acw = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, z0, acw, 0, 0, 0);
-            }
-            const double y1 = cur.v[t].y - cur.x[t].y;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, acc, 0, 0, 0);
-            if (TWO) {
-                const double z1 = cur.u[t].y - cur.x[t].y;
-                acx = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, z1, acx, 0, 0, 0);
-                acw = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, z1, acw, 0, 0, 0);
-            }
-        }
+        load_chunk16<TWO, true>(cur, vptr, wptr, qptr, k0, kq, Dp);
+        mfma_chunk16<TWO>(cur, acc, acx, acw);
+    }
+    if (k0 < Dp) {
+        RowChunk16<TWO> cur;
+        load_chunk16<TWO, false>(cur, vptr, wptr, qptr, k0, kq, Dp);
+        mfma_chunk16<TWO>(cur, acc, acx, acw);
     }
 }
 
-constexpr int kExtraMax = 3;                                  // extra rows beside the tile (LDS budget: 3 workgroups per CU)
+constexpr int kExtraMax = 2;                                  // extra rows beside the tile (register budget of the 32-feature sweep)
 constexpr int kExtraNP = kExtraMax * (kExtraMax + 1) / 2;
 // The same sweep for 16 rows plus ne <= kExtraMax EXTRA rows ide[0..ne) (the usual shape of a shortlist at m = 15:
 // 17 .. 19 candidates).  The matrix core forms the tile of the 16 rows; the few products with and between the extra
@@ -1121,43 +1155,53 @@ __device__ __forceinline__ void gram_tile16_extra(const double *X, int Dp, int q
     for (int b = 0; b < kExtraMax; ++b) ae[b] = 0.0;
 #pragma unroll
     for (int e = 0; e < kExtraNP; ++e) ee[e] = 0.0;
-    for (int k0 = 0; k0 < Dp; k0 += 16) {
-        const bool in = k0 + 4 * kq < Dp;   // Dp % 8 == 0: all 4 in range
-        double y[4], z[kExtraMax][4];
+    // 32 features per round trip; only a row's last chunk can be partial (FULL = no range checks)
+    auto chunk = [&](int k0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        double y[8], z[kExtraMax][8];
         {
-            const double2 v0 = in ? *reinterpret_cast<const double2 *>(vptr + k0) : double2{0.0, 0.0};
-            const double2 v1 = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 2) : double2{0.0, 0.0};
-            const double2 x0 = in ? *reinterpret_cast<const double2 *>(qptr + k0) : double2{0.0, 0.0};
-            const double2 x1 = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 2) : double2{0.0, 0.0};
-            double2 e0[kExtraMax], e1[kExtraMax];
+            double2 v[4], x[4], e[kExtraMax][4];
 #pragma unroll
-            for (int b = 0; b < kExtraMax; ++b) {
-                e0[b] = x0; e1[b] = x1;
-                if (b < ne && in) {   // (wave-uniform in b < ne)
-                    e0[b] = *reinterpret_cast<const double2 *>(eptr[b] + k0);
-                    e1[b] = *reinterpret_cast<const double2 *>(eptr[b] + k0 + 2);
+            for (int t = 0; t < 2; ++t) {
+                const bool in = FULL || k0 + 16 * t + 4 * kq < Dp;   // Dp % 8 == 0: all 4 in range
+                v[2 * t] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t) : double2{0.0, 0.0};
+                v[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
+                x[2 * t] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t) : double2{0.0, 0.0};
+                x[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
+#pragma unroll
+                for (int b = 0; b < kExtraMax; ++b) {
+                    // (an absent extra reads the query row: z = 0)
+                    e[b][2 * t] = in ? *reinterpret_cast<const double2 *>(eptr[b] + k0 + 16 * t) : double2{0.0, 0.0};
+                    e[b][2 * t + 1] = in ? *reinterpret_cast<const double2 *>(eptr[b] + k0 + 16 * t + 2) : double2{0.0, 0.0};
                 }
             }
-            y[0] = v0.x - x0.x; y[1] = v0.y - x0.y; y[2] = v1.x - x1.x; y[3] = v1.y - x1.y;
 #pragma unroll
-            for (int b = 0; b < kExtraMax; ++b) {
-                z[b][0] = e0[b].x - x0.x; z[b][1] = e0[b].y - x0.y; z[b][2] = e1[b].x - x1.x; z[b][3] = e1[b].y - x1.y;
+            for (int t = 0; t < 4; ++t) {
+                y[2 * t] = v[t].x - x[t].x; y[2 * t + 1] = v[t].y - x[t].y;
+#pragma unroll
+                for (int b = 0; b < kExtraMax; ++b) {
+                    z[b][2 * t] = e[b][t].x - x[t].x; z[b][2 * t + 1] = e[b][t].y - x[t].y;
+                }
             }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y[t], y[t], acc, 0, 0, 0);
+        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y[t], y[t], acc, 0, 0, 0);
 #pragma unroll
         for (int b = 0; b < kExtraMax; ++b) {
-            if (b < ne) {
+            if (b < ne) {   // (wave-uniform)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) ae[b] = fma(y[t], z[b][t], ae[b]);
+                for (int t = 0; t < 8; ++t) ae[b] = fma(y[t], z[b][t], ae[b]);
 #pragma unroll
                 for (int b2 = 0; b2 <= b; ++b2)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) ee[b * (b + 1) / 2 + b2] = fma(z[b][t], z[b2][t], ee[b * (b + 1) / 2 + b2]);
+                    for (int t = 0; t < 8; ++t) ee[b * (b + 1) / 2 + b2] = fma(z[b][t], z[b2][t], ee[b * (b + 1) / 2 + b2]);
             }
         }
-    }
+    };
+    const int Dfull = Dp & ~31;
+    int k0 = 0;
+    for (; k0 < Dfull; k0 += 32) chunk(k0, std::true_type{});
+    if (k0 < Dp) chunk(k0, std::false_type{});
     // sum over the four feature slices
 #pragma unroll
     for (int b = 0; b < kExtraMax; ++b) {
@@ -1572,7 +1616,7 @@ __device__ __forceinline__ bool gen_insert(GenLds &L, int n, double s, unsigned 
         gen_sync();
     }
     if (!(delta > 1e-13 * avv)) return false;
-    const double inv = 1.0 / delta;
+    const double inv = fast_rcp(delta);
     L.vu[lane] = in ? u : 0.0;
     gen_sync();
     if (in) {
