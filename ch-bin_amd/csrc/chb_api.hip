@@ -384,7 +384,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     // the fp16 shortlist stage and the tuned kernels hold lists of up to 16 entries; beyond that the plain
     // one-wavefront-per-problem kernels run (brute-force selection, LDS-resident solver)
     h->pf_fit = h->use_prefilter && h->shadow_ok && m <= kMaxM;
-    h->fused = h->allow_fused && h->pf_fit && h->pf_base && h->pf_update && fused_supported(m);
+    h->fused = h->allow_fused && h->pf_fit && h->pf_base && h->pf_update && fused_supported(m, h->Dp);
     HIPCHK(h->pin_a.ensure((size_t)h->N));
     int *lab = h->pin_a.p;
     for (int64_t i = 0; i < h->N; ++i) {

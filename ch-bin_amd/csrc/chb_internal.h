@@ -191,8 +191,10 @@ struct FusedArgs {
     int *slow;        // pair indices (pos - pos_begin) * B + bin
     int *n_slow;      // zeroed by the caller
 };
-// false: m not supported by the fused kernel (caller uses the list-based path)
-bool fused_supported(int m);
+// false: not supported by the fused kernels (caller uses the list-based path): m <= 16, padded rows of at most
+// kFusedMaxDp doubles (the 16-lane kernel stages the query row in LDS)
+constexpr int kFusedMaxDp = 288;
+bool fused_supported(int m, int Dp);
 void launch_hull_select_qp(const FusedArgs &a, hipStream_t s);
 
 // explicit problems: query sample q[p], hull_idx[p][m_max] compacted, hull_cnt[p] vertices

@@ -20,6 +20,7 @@
 // is not); agreement with the CPU oracle's Goldfarb-Idnani restatement is ~1e-13 relative.
 #include "chb_internal.h"
 #include <type_traits>
+#include <vector>
 
 #include <math.h>
 
@@ -835,15 +836,31 @@ __device__ __forceinline__ void group_argmin16(double key, int lane, double &kmi
 // broadcasts are independent of each other -- a few LDS rounds deep, where an elimination from
 // scratch is a 16-step dependent chain.  The pivot of the update is the Schur complement delta, the
 // same quantity whose collapse marks an affinely dependent support in solve_affine<M>.
-#ifdef CHB_DEV_KNOBS   // developer builds (tools/m15_probe.py): iteration statistics of the 16-lane solver
-__device__ unsigned long long g_qp16_stats[8];
+// developer builds (tools/m15_probe.py): CHB_DEV_KNOBS = iteration statistics of the 16-lane solver (its atomics
+// distort timings), CHB_DEV_CLK = cycle stamps of the fused 16-lane kernel's phases only
+#if defined(CHB_DEV_KNOBS) || defined(CHB_DEV_CLK)
+__device__ unsigned long long g_qp16_stats[16];
+#endif
+#ifdef CHB_DEV_CLK
+__device__ unsigned long long g_qp16_clk[131072][8];   // per-wavefront cycle stamps of the last launch (no atomics)
+#endif
+#ifdef CHB_DEV_KNOBS
 #define QP16_STAT(i, v) do { if (l16 == 0) atomicAdd(&g_qp16_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define QP16_STAT(i, v) do { } while (0)
 #endif
+#ifdef CHB_DEV_CLK
+#define QP16_CLK(t) const unsigned long long t = __builtin_readcyclecounter()
+#define QP16_CLK_ADD(i, v) do { if (lane == 0) atomicAdd(&g_qp16_stats[i], (unsigned long long)(v)); } while (0)
+#define QP16_CLK_ACC(var, v) do { var += (unsigned long long)(v); } while (0)
+#else
+#define QP16_CLK(t) do { } while (0)
+#define QP16_CLK_ADD(i, v) do { } while (0)
+#define QP16_CLK_ACC(var, v) do { } while (0)
+#endif
 
-// 1 / x for normal, well-scaled x (the solver works on a Gram normalised to O(1)): hardware estimate + two Newton
-// steps, within an ulp or two of the correctly rounded quotient
+// 1 / x for normal, well-scaled x (the 16-lane solver works on a Gram normalised to O(1)): hardware estimate + two
+// Newton steps, within an ulp or two of the correctly rounded quotient
 __device__ __forceinline__ double fast_rcp(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -875,6 +892,7 @@ __device__ __forceinline__ void group_allgather16(double *sv, int l16, double v,
 #ifndef CHB_QP16_OCC
 #define CHB_QP16_OCC 3   // wavefronts per SIMD the 16-lane solver is compiled for (168 VGPRs)
 #endif
+static_assert(kFusedMaxDp <= 16 * 18, "the query row is staged in a 16 x kQ16Ld tile");
 constexpr int kQ16Ld = 18;   // row stride of the 16 x 16 Gram tile in LDS (16-byte aligned rows)
 
 // vertex v enters: false (and no change) when it is affinely dependent on the support.
@@ -1136,82 +1154,90 @@ __device__ __forceinline__ void gram_tile16(const double *X, int Dp, int q, int 
     }
 }
 
-constexpr int kExtraMax = 2;                                  // extra rows beside the tile (register budget of the 32-feature sweep)
+constexpr int kExtraMax = 2;   // extra rows beside the tile (3 measured the same: 19 candidates are rare enough)
 constexpr int kExtraNP = kExtraMax * (kExtraMax + 1) / 2;
-// The same sweep for 16 rows plus ne <= kExtraMax EXTRA rows ide[0..ne) (the usual shape of a shortlist at m = 15:
-// 17 .. 19 candidates).  The matrix core forms the tile of the 16 rows; the few products with and between the extra
-// rows are vector FMAs on the lanes' feature slices: ae[b] = <row `row`, extra b>, ee[] = <extra b, extra b'>
-// (b' <= b, packed lower-triangular: ee[b (b + 1) / 2 + b']), complete on every lane
-// after the reduction over the four feature slices (lanes row, row + 16, row + 32, row + 48).
-__device__ __forceinline__ void gram_tile16_extra(const double *X, int Dp, int q, int idv, const int (&ide)[kExtraMax], int ne,
-                                                  int kq, f64x4 &acc, double (&ae)[kExtraMax], double (&ee)[kExtraNP])
+// The sweep of the fused kernel for rows of up to 288 doubles: 16 rows plus NE <= kExtraMax EXTRA rows ide[0..NE)
+// (the usual shape of a shortlist at m = 15: 17 or 18 candidates).  The matrix core forms the tile of the 16 rows;
+// the few products with and between the extra rows are vector FMAs on the lanes' feature slices: ae[b] = <row `row`,
+// extra b>, ee[] = <extra b, extra b'> (b' <= b, packed lower-triangular: ee[b (b + 1) / 2 + b']), complete on every
+// lane after the reduction over the four feature slices (lanes row, row + 16, row + 32, row + 48).  The query row
+// comes from LDS (xs, zero-padded to a multiple of 16 doubles), which leaves the registers to the candidate rows:
+// CH features of every row are in flight per round trip (the whole row for NE = 0 and D <= 160).
+// features per round trip for 0 / 1 / 2 extra rows (register budget of the kernel: 168 VGPRs)
+#ifndef CHB_SW0
+#define CHB_SW0 160
+#define CHB_SW1 48
+#define CHB_SW2 32
+#endif
+template <int NE, int CH, bool FULL>
+__device__ __forceinline__ void gram_sweep16_chunk(const double *vptr, const double *const (&eptr)[kExtraMax],
+                                                   const double *xs, int k0, int kq, int Dp, f64x4 &acc,
+                                                   double (&ae)[kExtraMax], double (&ee)[kExtraNP])
 {
-    const double *vptr = X + (size_t)(idv >= 0 ? idv : q) * Dp + 4 * kq;
-    const double *qptr = X + (size_t)q * Dp + 4 * kq;
+    constexpr int NG = CH / 16;   // 16-feature groups: the lane holds 4 doubles of each row per group
+    double2 v[NG][2], e[NE > 0 ? NE : 1][NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const bool in = FULL || k0 + 16 * g + 4 * kq < Dp;   // Dp % 8 == 0: all 4 in range
+        v[g][0] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * g) : double2{0.0, 0.0};
+        v[g][1] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * g + 2) : double2{0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b < NE; ++b) {
+            e[b][g][0] = in ? *reinterpret_cast<const double2 *>(eptr[b] + k0 + 16 * g) : double2{0.0, 0.0};
+            e[b][g][1] = in ? *reinterpret_cast<const double2 *>(eptr[b] + k0 + 16 * g + 2) : double2{0.0, 0.0};
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (FULL || k0 + 16 * g < Dp) {   // (wave-uniform)
+            const double2 x0 = *reinterpret_cast<const double2 *>(xs + k0 + 16 * g + 4 * kq);
+            const double2 x1 = *reinterpret_cast<const double2 *>(xs + k0 + 16 * g + 4 * kq + 2);
+            const double y[4] = {v[g][0].x - x0.x, v[g][0].y - x0.y, v[g][1].x - x1.x, v[g][1].y - x1.y};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y[t], y[t], acc, 0, 0, 0);
+            double z[NE > 0 ? NE : 1][4];
+#pragma unroll
+            for (int b = 0; b < NE; ++b) {
+                z[b][0] = e[b][g][0].x - x0.x; z[b][1] = e[b][g][0].y - x0.y;
+                z[b][2] = e[b][g][1].x - x1.x; z[b][3] = e[b][g][1].y - x1.y;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ae[b] = fma(y[t], z[b][t], ae[b]);
+#pragma unroll
+                for (int b2 = 0; b2 <= b; ++b2)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ee[b * (b + 1) / 2 + b2] = fma(z[b][t], z[b2][t], ee[b * (b + 1) / 2 + b2]);
+            }
+        }
+    }
+}
+template <int NE, int CH>
+__device__ __forceinline__ void gram_sweep16(const double *X, int Dp, int q, int idv, const int (&ide)[kExtraMax], int kq,
+                                             const double *xs, f64x4 &acc, double (&ae)[kExtraMax],
+                                             double (&ee)[kExtraNP])
+{
+    const double *vptr = X + (size_t)(idv >= 0 ? idv : q) * Dp + 4 * kq;   // a missing vertex reads the query row: y = 0
     const double *eptr[kExtraMax];
 #pragma unroll
-    for (int b = 0; b < kExtraMax; ++b) eptr[b] = X + (size_t)(b < ne ? ide[b] : q) * Dp + 4 * kq;
+    for (int b = 0; b < kExtraMax; ++b) eptr[b] = X + (size_t)(b < NE ? ide[b] : q) * Dp + 4 * kq;
 #pragma unroll
     for (int b = 0; b < kExtraMax; ++b) ae[b] = 0.0;
 #pragma unroll
     for (int e = 0; e < kExtraNP; ++e) ee[e] = 0.0;
-    // 32 features per round trip; only a row's last chunk can be partial (FULL = no range checks)
-    auto chunk = [&](int k0, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        double y[8], z[kExtraMax][8];
-        {
-            double2 v[4], x[4], e[kExtraMax][4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const bool in = FULL || k0 + 16 * t + 4 * kq < Dp;   // Dp % 8 == 0: all 4 in range
-                v[2 * t] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t) : double2{0.0, 0.0};
-                v[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(vptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
-                x[2 * t] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t) : double2{0.0, 0.0};
-                x[2 * t + 1] = in ? *reinterpret_cast<const double2 *>(qptr + k0 + 16 * t + 2) : double2{0.0, 0.0};
-#pragma unroll
-                for (int b = 0; b < kExtraMax; ++b) {
-                    // (an absent extra reads the query row: z = 0)
-                    e[b][2 * t] = in ? *reinterpret_cast<const double2 *>(eptr[b] + k0 + 16 * t) : double2{0.0, 0.0};
-                    e[b][2 * t + 1] = in ? *reinterpret_cast<const double2 *>(eptr[b] + k0 + 16 * t + 2) : double2{0.0, 0.0};
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                y[2 * t] = v[t].x - x[t].x; y[2 * t + 1] = v[t].y - x[t].y;
-#pragma unroll
-                for (int b = 0; b < kExtraMax; ++b) {
-                    z[b][2 * t] = e[b][t].x - x[t].x; z[b][2 * t + 1] = e[b][t].y - x[t].y;
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y[t], y[t], acc, 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < kExtraMax; ++b) {
-            if (b < ne) {   // (wave-uniform)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) ae[b] = fma(y[t], z[b][t], ae[b]);
-#pragma unroll
-                for (int b2 = 0; b2 <= b; ++b2)
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) ee[b * (b + 1) / 2 + b2] = fma(z[b][t], z[b2][t], ee[b * (b + 1) / 2 + b2]);
-            }
-        }
-    };
-    const int Dfull = Dp & ~31;
     int k0 = 0;
-    for (; k0 < Dfull; k0 += 32) chunk(k0, std::true_type{});
-    if (k0 < Dp) chunk(k0, std::false_type{});
-    // sum over the four feature slices
+    for (; k0 + CH <= Dp; k0 += CH) gram_sweep16_chunk<NE, CH, true>(vptr, eptr, xs, k0, kq, Dp, acc, ae, ee);
+    if (k0 < Dp) gram_sweep16_chunk<NE, CH, false>(vptr, eptr, xs, k0, kq, Dp, acc, ae, ee);
+    if (NE > 0) {
+        // sum over the four feature slices
 #pragma unroll
-    for (int b = 0; b < kExtraMax; ++b) {
-        ae[b] += __shfl_xor(ae[b], 16, 64);
-        ae[b] += __shfl_xor(ae[b], 32, 64);
-    }
+        for (int b = 0; b < NE; ++b) {
+            ae[b] += __shfl_xor(ae[b], 16, 64);
+            ae[b] += __shfl_xor(ae[b], 32, 64);
+        }
 #pragma unroll
-    for (int e = 0; e < kExtraNP; ++e) {
-        ee[e] += __shfl_xor(ee[e], 16, 64);
-        ee[e] += __shfl_xor(ee[e], 32, 64);
+        for (int e = 0; e < NE * (NE + 1) / 2; ++e) {
+            ee[e] += __shfl_xor(ee[e], 16, 64);
+            ee[e] += __shfl_xor(ee[e], 32, 64);
+        }
     }
 }
 
@@ -1293,7 +1319,7 @@ __global__ __launch_bounds__(256, CHB_QP16_OCC) void hull_qp16_kernel(QpArgs a, 
 //   21 .. 32: two tiles and the block between them (ranked and scattered inside the sweep loop);
 //   n > 32, or a near-tie between ranks m - 1 and m: exact path.
 // The diagonal = the squared distances ranks the candidates; the entries between the m nearest become the hull's
-// Gram tile (vertex slot = rank).  For n <= 20 that happens after the sweeps, the four pairs of the wavefront
+// Gram tile (vertex slot = rank).  For n <= 18 that happens after the sweeps, the four pairs of the wavefront
 // side by side (16 lanes each: lane i owns candidate i's row of the raw tile and moves it to its slot).
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_kernel(FusedArgs a, int nprob, Gate gate)
@@ -1340,6 +1366,10 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
             changed = ((__ballot(!same) >> (lane & 48)) & 0xFFFFull) != 0ull;
         }
     }
+    QP16_CLK(tc0);
+#ifdef CHB_DEV_CLK
+    unsigned long long c_ids = 0, c_sweep = 0, c_one = 0;
+#endif
     const int n = nb + nu;
     const bool work = changed && n > 0 && n <= 32;
     bool slow = changed && n > 32;
@@ -1354,6 +1384,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
         const int q = __shfl(qid, 16 * p, 64);
         const bool go = __shfl(work ? 1 : 0, 16 * p, 64) != 0;
         if (!go) continue;   // wave-uniform
+        QP16_CLK(tp0);
         const int gp = gw + p;
         const size_t slot_p = (size_t)(gp - (gp / a.B) * a.B) * a.Kcap + (a.pos_begin + gp / a.B);
         const bool two = np > 16 + kExtraMax;
@@ -1363,17 +1394,30 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
         double *Qp = &sQ[w][p][0][0];
         if (!two) {
             f64x4 aa = {0.0, 0.0, 0.0, 0.0};
-            if (ne > 0) {
-                int ide[kExtraMax];
+            int ide[kExtraMax];
 #pragma unroll
-                for (int b = 0; b < kExtraMax; ++b) {
-                    ide[b] = -1;
-                    if (b < ne)
-                        ide[b] = 16 + b < nbp ? a.cand[slot_p * kCandCap + 16 + b]
-                                              : a.candu[slot_p * kCandCapU + (16 + b - nbp)];
-                }
-                double ae[kExtraMax], ee[kExtraNP];
-                gram_tile16_extra(a.X, a.Dp, q, idA, ide, ne, kq, aa, ae, ee);
+            for (int b = 0; b < kExtraMax; ++b) {
+                ide[b] = -1;
+                if (b < ne)
+                    ide[b] = 16 + b < nbp ? a.cand[slot_p * kCandCap + 16 + b]
+                                          : a.candu[slot_p * kCandCapU + (16 + b - nbp)];
+            }
+            double ae[kExtraMax], ee[kExtraNP];
+            QP16_CLK(tp1);
+            QP16_CLK_ACC(c_ids, tp1 - tp0);
+            {
+                // the query row goes through LDS: the pair's own tile is free until its sweep ends and holds rows of
+                // up to kFusedMaxDp doubles (the caller checks; the shortlist stage itself needs D <= 160)
+                const int Dp16 = (a.Dp + 15) & ~15;
+                for (int e = 2 * lane; e < Dp16; e += 128)
+                    *reinterpret_cast<double2 *>(Qp + e) =
+                        e < a.Dp ? *reinterpret_cast<const double2 *>(a.X + (size_t)q * a.Dp + e) : double2{0.0, 0.0};
+                __builtin_amdgcn_wave_barrier();
+                if (ne == 0) gram_sweep16<0, CHB_SW0>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
+                else if (ne == 1) gram_sweep16<1, CHB_SW1>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
+                else gram_sweep16<2, CHB_SW2>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
+            }
+            if (ne > 0) {
                 if (kq == 0) {
 #pragma unroll
                     for (int b = 0; b < kExtraMax; ++b) sAE[w][p][b][row] = ae[b];
@@ -1382,13 +1426,15 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
 #pragma unroll
                     for (int e = 0; e < kExtraNP; ++e) sEE[w][p][e] = ee[e];
                 }
-            } else {
-                f64x4 d0 = aa, d1 = aa;
-                gram_tile16<false>(a.X, a.Dp, q, idA, -1, kq, aa, d0, d1);
             }
             // the raw tile of candidates 0..15; selection (np > m) follows after the loop
 #pragma unroll
             for (int r = 0; r < 4; ++r) Qp[(kq + 4 * r) * kQ16Ld + row] = aa[r];
+            {
+                QP16_CLK(tp2);
+                QP16_CLK_ACC(c_sweep, tp2 - tp1);
+                QP16_CLK_ACC(c_one, 1);
+            }
             continue;
         }
         // ---- two tiles (up to 32 candidates): rank and scatter here, the accumulators are this pair's
@@ -1449,7 +1495,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wavefront's LDS writes have landed
 
-    // ---- selection for m < n <= 20, one pair per 16-lane group: lane i owns candidate i (and, i < n - 16, extra i)
+    QP16_CLK(tc1);
+    // ---- selection for m < n <= 18, one pair per 16-lane group: lane i owns candidate i (and, i < n - 16, extra i)
     if (work && n > m && n <= 16 + kExtraMax) {
         double *Qt = &sQ[w][grp][0][0];
         const int ne = n > 16 ? n - 16 : 0, nA = n - ne;
@@ -1526,6 +1573,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
         __builtin_amdgcn_wave_barrier();
     }
 
+    QP16_CLK(tc2);
     // ---- the exact path's work list: one device-scope atomic per workgroup
     {
         const unsigned long long bal = __ballot(slow && l16 == 0);
@@ -1545,6 +1593,16 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
     double dist = kInf;
     if (n > 0) dist = sqrt(fmax(solve16(&sQ[w][grp][0][0], &sV[w][grp][0], nsel, a.metric, lane, alpha), 0.0));
     if (l16 == 0) a.dist[(size_t)pos * a.B + c] = dist;
+#ifdef CHB_DEV_CLK
+    {
+        QP16_CLK(tc3);
+        const unsigned wid = blockIdx.x * WAVES + w;
+        if (lane == 0 && wid < 131072u) {
+            unsigned long long *o = g_qp16_clk[wid];
+            o[0] = tc1 - tc0; o[1] = tc2 - tc1; o[2] = tc3 - tc2; o[3] = c_ids; o[4] = c_sweep; o[5] = c_one; o[6] = 1; o[7] = tc0;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1616,7 +1674,7 @@ __device__ __forceinline__ bool gen_insert(GenLds &L, int n, double s, unsigned 
         gen_sync();
     }
     if (!(delta > 1e-13 * avv)) return false;
-    const double inv = fast_rcp(delta);
+    const double inv = 1.0 / delta;
     L.vu[lane] = in ? u : 0.0;
     gen_sync();
     if (in) {
@@ -1844,7 +1902,7 @@ void launch_hull_qp(const QpArgs &a, hipStream_t s)
     dispatch<false>(a, nprob, a.m, nullptr, nullptr, nullptr, nullptr, nullptr, s);
 }
 
-bool fused_supported(int m) { return m >= 1 && m <= 16; }
+bool fused_supported(int m, int Dp) { return m >= 1 && m <= 16 && Dp <= kFusedMaxDp; }
 
 void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
 {
@@ -1885,15 +1943,35 @@ void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const 
 
 }  // namespace chb
 
-#ifdef CHB_DEV_KNOBS
+#if defined(CHB_DEV_KNOBS) || defined(CHB_DEV_CLK)
 // developer builds only: [0] problems solved, [1] major iterations, [2] ratio-test removals, [3] final support
 // sizes (sum), [4] small-pivot refinements of inv16_insert
+#ifdef CHB_DEV_CLK
+// sums of the per-wavefront stamps of the last launch: [0] sweeps [1] selection [2] slow list + solver [3] id loads
+// [4] one-tile sweeps [5] one-tile pairs [6] wavefronts [7] span (last start - first start)
+extern "C" int chb_dev_qp16_clk(unsigned long long *out8)
+{
+    std::vector<unsigned long long> h(131072 * 8);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(chb::g_qp16_clk), h.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) out8[k] = 0;
+    unsigned long long lo = ~0ull, hi = 0;
+    for (size_t i = 0; i < 131072; ++i) {
+        if (!h[i * 8 + 6]) continue;
+        for (int k = 0; k < 7; ++k) out8[k] += h[i * 8 + k];
+        lo = std::min(lo, h[i * 8 + 7]); hi = std::max(hi, h[i * 8 + 7]);
+    }
+    out8[7] = hi > lo ? hi - lo : 0;
+    const std::vector<unsigned long long> z(131072 * 8, 0ull);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(chb::g_qp16_clk), z.data(), z.size() * sizeof(unsigned long long));
+    return 0;
+}
+#endif
 extern "C" int chb_dev_qp16_stats(unsigned long long *out, int reset)
 {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(chb::g_qp16_stats), 8 * sizeof(unsigned long long)) != hipSuccess)
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(chb::g_qp16_stats), 16 * sizeof(unsigned long long)) != hipSuccess)
         return -1;
     if (reset) {
-        const unsigned long long z[8] = {};
+        const unsigned long long z[16] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(chb::g_qp16_stats), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

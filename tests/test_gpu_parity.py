@@ -699,3 +699,62 @@ def test_small_batch_fewer_seeds_than_batch(ctx, O, batch, n_seed):
     assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
     from chbin_amd.distributed import batch_schedule
     assert all(K <= batch for _, K in batch_schedule(perms.shape[1], batch, int((initial >= 0).sum()), True))
+
+
+# ------------------------------------------------------------------ fused selection + hull kernel, 5 < m <= 16
+
+F16_CASES = [
+    # N, D, B, m, n_seed, batch, dup  (sigma 6e-3, mix 0.5: overlapping bins, several rounds per batch)
+    (1500, 136, 6, 15, 20, 0, False),      # one matrix-core tile (+ 1..2 extra rows) per pair
+    (1500, 136, 6, 16, 20, 0, False),      # m = 16: every tile row is a vertex
+    (1500, 136, 6, 6, 8, 0, False),        # short lists on the 16-lane kernel
+    (1200, 140, 5, 9, 12, 600, False),
+    (1200, 40, 4, 12, 3, 800, False),      # few seeds, large batches: most candidates are batch entries (two tiles, exact path)
+    (800, 160, 3, 15, 20, 0, False),       # the longest rows the shortlist stage takes
+    (1000, 64, 4, 15, 20, 0, True),        # duplicated members: exact ties at the selection boundary -> exact path
+]
+
+
+@pytest.mark.parametrize("N,D,B,m,n_seed,batch,dup", F16_CASES)
+def test_fused_16_lane_kernel_vs_oracle_and_lists(O, N, D, B, m, n_seed, batch, dup):
+    """The fused kernel for 5 < m <= 16 (qp_kernels.hip: hull_select_qp16_kernel) against the oracle and against
+    the list-based formulation (CHB_FUSED=0) of the same library: labels, sweeps and winning distances."""
+    from chbin_amd import _lib
+    S = 5 if D == 140 else 1
+    X, initial, _ = _synth(N, D, B, S=S, seed=N + m, sigma=6e-3, mix=0.5, n_seed=n_seed)
+    if dup:
+        rng = np.random.default_rng(1)
+        src = rng.choice(N, N // 3, replace=False)
+        dst = rng.choice(N, N // 3, replace=False)
+        X[dst] = X[src]
+    perms = _perms(initial, 3)
+    want, its_o, ch_o = O.fit_cluster(X, B, initial, perms, m, 3)
+    a = _lib.Context(0)
+    try:
+        a.set_samples(X)
+        got, its, ch, mind = a.fit_cluster(B, initial, perms, m, 3, batch=batch, want_min_dist=True)
+        assert a.counter("fused_enabled") == 1
+    finally:
+        a.close()
+    assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
+    labels = initial.copy()
+    for k in range(its):
+        labels, md = O.sweep(X, B, labels, perms[k], m)
+    assert np.allclose(mind[perms[its - 1]], md, rtol=0, atol=QP_TOL, equal_nan=True)
+    old = os.environ.get("CHB_FUSED")
+    os.environ["CHB_FUSED"] = "0"
+    try:
+        b = _lib.Context(0)
+    finally:
+        if old is None:
+            del os.environ["CHB_FUSED"]
+        else:
+            os.environ["CHB_FUSED"] = old
+    try:
+        b.set_samples(X)
+        got_l, its_l, ch_l, mind_l = b.fit_cluster(B, initial, perms, m, 3, batch=batch, want_min_dist=True)
+        assert b.counter("fused_enabled") == 0
+    finally:
+        b.close()
+    assert its_l == its and np.array_equal(ch_l, ch) and np.array_equal(got_l, got)
+    assert np.allclose(mind_l, mind, rtol=0, atol=QP_TOL, equal_nan=True)

@@ -21,7 +21,7 @@ ctx.set_samples(X)
 lab, _, _ = ctx.fit_cluster(B, initial, perms[:1], m, 1)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 have = hasattr(lib, "chb_dev_qp16_stats")
-st = (ctypes.c_ulonglong * 8)()
+st = (ctypes.c_ulonglong * 16)()
 if have:
     lib.chb_dev_qp16_stats(st, 1)
 t = time.perf_counter()
@@ -32,8 +32,16 @@ print(f"last batch K={ctx.counter('last_batch_k')} x B={B} pairs; m={m}: {dt*1e3
 if have:
     lib.chb_dev_qp16_stats(st, 0)
     p = max(st[0], 1)
-    print(f"solver: {st[0]} problems, {st[1]/p:.2f} major iterations, {st[2]/p:.2f} removals, final support {st[3]/p:.2f}, "
+    if st[0]:
+        print(f"solver: {st[0]} problems, {st[1]/p:.2f} major iterations, {st[2]/p:.2f} removals, final support {st[3]/p:.2f}, "
           f"{st[4]/p:.3f} small-pivot refinements per problem")
+if hasattr(lib, "chb_dev_qp16_clk"):
+    ck = (ctypes.c_ulonglong * 8)()
+    lib.chb_dev_qp16_clk(ck)
+    w = max(ck[6], 1)
+    print(f"fused 16-lane kernel, last launch, cycles per wavefront that reaches the end ({ck[6]}): sweeps {ck[0]/w:.0f}, "
+          f"selection {ck[1]/w:.0f}, slow list + solver {ck[2]/w:.0f}; per one-tile pair ({ck[5]}): ids {ck[3]/max(ck[5],1):.0f}, "
+          f"sweep + tile store {ck[4]/max(ck[5],1):.0f}; first-to-last wavefront start {ck[7]} cycles")
 for n in (14, 15, 16, 17, 18, 19, 20, 22, 24, 28, 32, 48):
     try:
         print(f"  shortlist <= {n}: {ctx.counter('shortlist_le%d_last_batch' % n)}", end="")
