@@ -171,7 +171,7 @@ int chb_profile_enable(chb_ctx *h, int on);
 int chb_profile_reset(chb_ctx *h);
 /* kernel: "prefilter" | "prefilter_update" | "rescore" | "rescore_update" | "query_norms" |
  * "topm_fallback" | "topm_base" | "topm_update" | "hull_qp" | "slow_path" | "argmin" | "bucket" |
- * "pairwise" | "kmer_count".  For m <= 5 "hull_qp" is the fused selection + hull-distance kernel and
+ * "pairwise" | "kmer_count".  For m <= 16 "hull_qp" is the fused selection + hull-distance kernel and
  * "slow_path" the exact path for what it leaves over; "rescore*" then only appear for m > 5. */
 int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *launches,
                     double *work_units);
