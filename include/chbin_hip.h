@@ -172,7 +172,7 @@ int chb_profile_reset(chb_ctx *h);
 /* kernel: "prefilter" | "prefilter_update" | "rescore" | "rescore_update" | "query_norms" |
  * "topm_fallback" | "topm_base" | "topm_update" | "hull_qp" | "slow_path" | "argmin" | "bucket" |
  * "pairwise" | "kmer_count".  For m <= 16 "hull_qp" is the fused selection + hull-distance kernel and
- * "slow_path" the exact path for what it leaves over; "rescore*" then only appear for m > 5. */
+ * "slow_path" the exact path for what it leaves over; "rescore*" then only appear for m > 16 or CHB_FUSED=0. */
 int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *launches,
                     double *work_units);
 /* counters of the last chb_fit_cluster call: [0]=batches [1]=rounds [2]=hull distances evaluated
