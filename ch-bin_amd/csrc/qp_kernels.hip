@@ -732,11 +732,36 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             if (l16 == 0 && tie) slowmask |= 1ull << pl;
         }
     }
-    // ---- the exact path's work list: one device-scope atomic per workgroup
     unsigned long long sm = slowmask;   // classification bits on every lane, tie bits on lanes 0, 16, 32, 48
     sm |= __shfl_xor(sm, 16, 64);
     sm |= __shfl_xor(sm, 32, 64);
     sm = __shfl(sm, 0, 64);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
+
+    // ---- phase 2: one problem per lane
+    {
+        const int g = g0 + lane;
+        const int n = g < nprob ? sN[w][lane] : -1;
+        if (g < nprob && n != -1 && !((sm >> lane) & 1ull)) {   // else: distance kept, or written by the exact path
+            double Q[NPM];
+#pragma unroll
+            for (int e = 0; e < NPM; ++e) Q[e] = sQ[w][e][lane];
+            double alpha[M];
+            double dist;
+            if (n <= 0) {
+                dist = kInf;
+            } else {
+                const double val = a.metric == 0 ? min_norm_point<M>(Q, n, alpha) : affine_min_norm<M>(Q, n, alpha);
+                dist = sqrt(fmax(val, 0.0));
+            }
+            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
+            a.dist[(size_t)pos * a.B + c] = dist;
+        }
+    }
+
+    // ---- the exact path's work list: one device-scope atomic per workgroup (at the very end: the barriers
+    // below must not hold a wavefront back between its sweeps and its solver)
     const int nsl = __popcll(sm);
     int wbase = 0;
     if (lane == 0 && nsl > 0) wbase = atomicAdd(&sSlowN, nsl);
@@ -748,28 +773,6 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
         const int before = __popcll(sm & ((1ull << lane) - 1ull));
         a.slow[wbase + before] = g0 + lane;
     }
-    if (g0 >= nprob) return;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed
-
-    // ---- phase 2: one problem per lane
-    const int g = g0 + lane;
-    if (g >= nprob) return;
-    const int n = sN[w][lane];
-    if (n == -1 || ((sm >> lane) & 1ull)) return;   // distance kept, or written by the exact path
-    double Q[NPM];
-#pragma unroll
-    for (int e = 0; e < NPM; ++e) Q[e] = sQ[w][e][lane];
-    double alpha[M];
-    double dist;
-    if (n <= 0) {
-        dist = kInf;
-    } else {
-        const double val = a.metric == 0 ? min_norm_point<M>(Q, n, alpha) : affine_min_norm<M>(Q, n, alpha);
-        dist = sqrt(fmax(val, 0.0));
-    }
-    const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
-    a.dist[(size_t)pos * a.B + c] = dist;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1574,7 +1577,17 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
     }
 
     QP16_CLK(tc2);
-    // ---- the exact path's work list: one device-scope atomic per workgroup
+    // ---- phase 2: one pair per 16-lane group
+    if (valid && changed && !slow) {   // else: distance kept, or written by the exact path
+        double alpha = 0.0;
+        double dist = kInf;
+        if (n > 0) dist = sqrt(fmax(solve16(&sQ[w][grp][0][0], &sV[w][grp][0], nsel, a.metric, lane, alpha), 0.0));
+        if (l16 == 0) a.dist[(size_t)pos * a.B + c] = dist;
+    }
+    QP16_CLK(tc3);
+
+    // ---- the exact path's work list: one device-scope atomic per workgroup (at the very end: the barriers
+    // below must not hold a wavefront back between its sweeps and its solver)
     {
         const unsigned long long bal = __ballot(slow && l16 == 0);
         const int nsl = __popcll(bal);
@@ -1586,16 +1599,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
         wbase = __shfl(wbase, 0, 64) + sSlowBase;
         if (slow && l16 == 0) a.slow[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = g;
     }
-    if (!valid || !changed || slow) return;   // distance kept, or written by the exact path
-
-    // ---- phase 2: one pair per 16-lane group
-    double alpha = 0.0;
-    double dist = kInf;
-    if (n > 0) dist = sqrt(fmax(solve16(&sQ[w][grp][0][0], &sV[w][grp][0], nsel, a.metric, lane, alpha), 0.0));
-    if (l16 == 0) a.dist[(size_t)pos * a.B + c] = dist;
 #ifdef CHB_DEV_CLK
     {
-        QP16_CLK(tc3);
         const unsigned wid = blockIdx.x * WAVES + w;
         if (lane == 0 && wid < 131072u) {
             unsigned long long *o = g_qp16_clk[wid];
