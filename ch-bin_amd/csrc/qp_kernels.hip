@@ -1378,6 +1378,23 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
     bool slow = changed && n > 32;
     int nsel = n < m ? n : m;   // vertices of the hull problem
 
+    // ---- before the sweeps, every group for its own pair (one round trip for the four pairs): the candidates'
+    // sample indices (lane i: candidate i; lanes 0 .. kExtraMax - 1 also the extra candidates 16 + i) and the query
+    // row, which goes through LDS -- the pair's own tile is free until its sweep ends and holds rows of up to
+    // kFusedMaxDp doubles (the caller checks; the shortlist stage itself needs D <= 160)
+    int idm = -1, idx = -1;
+    if (work) {
+        if (l16 < n) idm = l16 < nb ? a.cand[slot * kCandCap + l16] : a.candu[slot * kCandCapU + (l16 - nb)];
+        if (l16 < kExtraMax && 16 + l16 < n)
+            idx = 16 + l16 < nb ? a.cand[slot * kCandCap + 16 + l16] : a.candu[slot * kCandCapU + (16 + l16 - nb)];
+        double *xq = &sQ[w][grp][0][0];
+        const int Dp16 = (a.Dp + 15) & ~15;
+        for (int e = 2 * l16; e < Dp16; e += 32)
+            *reinterpret_cast<double2 *>(xq + e) =
+                e < a.Dp ? *reinterpret_cast<const double2 *>(a.X + (size_t)qid * a.Dp + e) : double2{0.0, 0.0};
+    }
+    __builtin_amdgcn_wave_barrier();
+
     // ---- phase 1: the wavefront's four pairs one after the other, all 64 lanes on one pair
     const int row = lane & 15, kq = lane >> 4;
 #pragma unroll 1
@@ -1386,40 +1403,26 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
         const int nbp = __shfl(nb, 16 * p, 64);
         const int q = __shfl(qid, 16 * p, 64);
         const bool go = __shfl(work ? 1 : 0, 16 * p, 64) != 0;
+        const int idA = __shfl(idm, 16 * p + row, 64);
+        int ide[kExtraMax];
+#pragma unroll
+        for (int b = 0; b < kExtraMax; ++b) ide[b] = __shfl(idx, 16 * p + b, 64);
         if (!go) continue;   // wave-uniform
         QP16_CLK(tp0);
         const int gp = gw + p;
         const size_t slot_p = (size_t)(gp - (gp / a.B) * a.B) * a.Kcap + (a.pos_begin + gp / a.B);
         const bool two = np > 16 + kExtraMax;
         const int ne = (np > 16 && !two) ? np - 16 : 0;
-        int idA = -1, idB = -1;
-        if (row < np) idA = row < nbp ? a.cand[slot_p * kCandCap + row] : a.candu[slot_p * kCandCapU + (row - nbp)];
+        int idB = -1;
         double *Qp = &sQ[w][p][0][0];
         if (!two) {
             f64x4 aa = {0.0, 0.0, 0.0, 0.0};
-            int ide[kExtraMax];
-#pragma unroll
-            for (int b = 0; b < kExtraMax; ++b) {
-                ide[b] = -1;
-                if (b < ne)
-                    ide[b] = 16 + b < nbp ? a.cand[slot_p * kCandCap + 16 + b]
-                                          : a.candu[slot_p * kCandCapU + (16 + b - nbp)];
-            }
             double ae[kExtraMax], ee[kExtraNP];
             QP16_CLK(tp1);
             QP16_CLK_ACC(c_ids, tp1 - tp0);
-            {
-                // the query row goes through LDS: the pair's own tile is free until its sweep ends and holds rows of
-                // up to kFusedMaxDp doubles (the caller checks; the shortlist stage itself needs D <= 160)
-                const int Dp16 = (a.Dp + 15) & ~15;
-                for (int e = 2 * lane; e < Dp16; e += 128)
-                    *reinterpret_cast<double2 *>(Qp + e) =
-                        e < a.Dp ? *reinterpret_cast<const double2 *>(a.X + (size_t)q * a.Dp + e) : double2{0.0, 0.0};
-                __builtin_amdgcn_wave_barrier();
-                if (ne == 0) gram_sweep16<0, CHB_SW0>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
-                else if (ne == 1) gram_sweep16<1, CHB_SW1>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
-                else gram_sweep16<2, CHB_SW2>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
-            }
+            if (ne == 0) gram_sweep16<0, CHB_SW0>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
+            else if (ne == 1) gram_sweep16<1, CHB_SW1>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
+            else gram_sweep16<2, CHB_SW2>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
             if (ne > 0) {
                 if (kq == 0) {
 #pragma unroll
@@ -1503,9 +1506,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
     if (work && n > m && n <= 16 + kExtraMax) {
         double *Qt = &sQ[w][grp][0][0];
         const int ne = n > 16 ? n - 16 : 0, nA = n - ne;
-        int idm = -1, ide = -1;
-        if (l16 < nA) idm = l16 < nb ? a.cand[slot * kCandCap + l16] : a.candu[slot * kCandCapU + (l16 - nb)];
-        if (l16 < ne) ide = 16 + l16 < nb ? a.cand[slot * kCandCap + 16 + l16] : a.candu[slot * kCandCapU + (16 + l16 - nb)];
+        const int ide = l16 < ne ? idx : -1;
+        if (l16 >= nA) idm = -1;
         const double dA = l16 < nA ? Qt[l16 * kQ16Ld + l16] : kInf;
         const double dE = l16 < ne ? sEE[w][grp][l16 * (l16 + 1) / 2 + l16] : kInf;
         sGD[w][grp][l16] = dA; sGI[w][grp][l16] = idm;
