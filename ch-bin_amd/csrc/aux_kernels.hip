@@ -138,7 +138,21 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
     }
     for (int b = tid; b < B; b += 1024) cnt[b] = 0;
     __syncthreads();
-    for (int i = tid; i < K; i += 1024) {
+    // (the first kReg entries of a thread stay in registers between the two passes: K <= 8192 at the default batch)
+    constexpr int kReg = 8;
+    int ra[kReg], rb[kReg];
+#pragma unroll
+    for (int t = 0; t < kReg; ++t) {
+        const int i = tid + 1024 * t;
+        ra[t] = i < K ? lab_prev[i] : -1;
+        rb[t] = (lab_old && i < K) ? lab_old[i] : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < kReg; ++t) {
+        if (ra[t] >= 0 && ra[t] < B) atomicAdd(&cnt[ra[t]], 1);
+        if (rb[t] >= 0 && rb[t] < B) atomicAdd(&cnt[rb[t]], 1);
+    }
+    for (int i = tid + 1024 * kReg; i < K; i += 1024) {
         const int a = lab_prev[i];
         if (a >= 0 && a < B) atomicAdd(&cnt[a], 1);
         if (lab_old) {
@@ -153,20 +167,30 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
     for (int b = b0; b < b1; ++b) { s += cnt[b]; sp += (cnt[b] + 31) / 32 * 32; }
     part[tid] = s; ppart[tid] = sp;
     __syncthreads();
-    if (tid == 0) {
-        // (threads beyond ceil(B / per) own no bin: the serial part stays as short as the bin count)
-        const int nparts = (B + per - 1) / per;
-        int run = 0, prun = 0;
-        for (int i = 0; i < nparts; ++i) {
-            const int v = part[i], pv = ppart[i];
-            part[i] = run; ppart[i] = prun;
+    if (tid < 64) {
+        // exclusive scan of the partials by one wavefront: lane l owns parts 16 l .. 16 l + 15
+        // (threads beyond ceil(B / per) own no bin and contribute zeros)
+        int loc = 0, ploc = 0;
+        for (int i = 0; i < 16; ++i) { loc += part[16 * tid + i]; ploc += ppart[16 * tid + i]; }
+        int inc = loc, pinc = ploc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off, 64), po = __shfl_up(pinc, off, 64);
+            if (tid >= off) { inc += o; pinc += po; }
+        }
+        int run = inc - loc, prun = pinc - ploc;
+        for (int i = 0; i < 16; ++i) {
+            const int v = part[16 * tid + i], pv = ppart[16 * tid + i];
+            part[16 * tid + i] = run; ppart[16 * tid + i] = prun;
             run += v; prun += pv;
         }
-        bin_ptr[B] = run;   // (the totals)
-        if (pad_ptr) pad_ptr[B] = prun;
+        if (tid == 63) {
+            bin_ptr[B] = run;   // (the totals)
+            if (pad_ptr) pad_ptr[B] = prun;
+        }
     }
     __syncthreads();
-    int run = part[tid], prun = ppart[tid];   // (read only where b0 < b1: tid < nparts)
+    int run = part[tid], prun = ppart[tid];
     for (int b = b0; b < b1; ++b) {
         const int c = cnt[b];
         bin_ptr[b] = run;
@@ -175,7 +199,21 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
         run += c; prun += (c + 31) / 32 * 32;
     }
     __syncthreads();
-    for (int i = tid; i < K; i += 1024) {
+#pragma unroll
+    for (int t = 0; t < kReg; ++t) {
+        const int i = tid + 1024 * t;
+        if (ra[t] >= 0 && ra[t] < B) {
+            const int e = atomicAdd(&cnt[ra[t]], 1);
+            memb_id[e] = bq[i];
+            memb_code[e] = lab_old ? (i + 1) : (-(1 << 30) - i);
+        }
+        if (rb[t] >= 0 && rb[t] < B) {
+            const int e = atomicAdd(&cnt[rb[t]], 1);
+            memb_id[e] = bq[i];
+            memb_code[e] = -(i + 1);
+        }
+    }
+    for (int i = tid + 1024 * kReg; i < K; i += 1024) {
         const int a = lab_prev[i];
         if (a >= 0 && a < B) {
             const int e = atomicAdd(&cnt[a], 1);
@@ -195,21 +233,38 @@ __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev,
 
 // algorithm.py:47-60: min_distance = inf, min_cluster = current label; strict '>' so the lowest
 // bin wins ties and NaN never wins.
-__global__ void argmin_kernel(const double *dist, const int *lab_old, int *lab_prev,
+// Eight lanes per position (bins c = j, j + 8, ... on lane j: 64 contiguous bytes per step), combined in
+// (distance, bin) order -- the result of the sequential loop over c: the lowest bin among equal minima.
+__global__ __launch_bounds__(256) void argmin_kernel(const double *dist, const int *lab_old, int *lab_prev,
                               int pos_begin, int pos_end, int B, int *lab_new, double *mind, double *second,
                               int *first_change, int in_place, Gate gate)
 {
     CHB_GATE(gate);
-    const int pos = pos_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= pos_end) return;
+    const int j = threadIdx.x & 7;
+    const int pos = pos_begin + (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 3);
+    const bool valid = pos < pos_end;
     double best = kInf, runner = kInf;   // runner: smallest distance of any OTHER bin (for the margin report)
-    int bc = lab_old[pos];
-    const double *row = dist + (size_t)pos * B;
-    for (int c = 0; c < B; ++c) {
-        const double d = row[c];
-        if (best > d) { runner = best; best = d; bc = c; }
-        else if (runner > d) runner = d;
+    int bc = -1;                         // -1: no bin beat +inf (the label stays)
+    if (valid) {
+        const double *row = dist + (size_t)pos * B;
+        for (int c = j; c < B; c += 8) {
+            const double d = row[c];
+            if (best > d) { runner = best; best = d; bc = c; }
+            else if (runner > d) runner = d;
+        }
     }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const double ob = __shfl_xor(best, off, 64), orr = __shfl_xor(runner, off, 64);
+        const int oc = __shfl_xor(bc, off, 64);
+        // the other side wins on a smaller distance, or on the same (finite) distance with the lower bin
+        const bool take = ob < best || (ob == best && oc >= 0 && (bc < 0 || oc < bc));
+        const double lose = take ? best : ob;
+        runner = fmin(fmin(runner, orr), lose);
+        if (take) { best = ob; bc = oc; }
+    }
+    if (!valid || j != 0) return;
+    if (bc < 0) bc = lab_old[pos];
     lab_new[pos] = bc;
     mind[pos] = best;
     if (second != nullptr) second[pos] = runner;
@@ -479,7 +534,8 @@ void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int po
 {
     const int n = pos_end - pos_begin;
     if (n > 0)
-        hipLaunchKernelGGL(argmin_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dist, lab_old, lab_prev, pos_begin, pos_end, B, lab_new, mind, second, first_change, in_place ? 1 : 0, g_gate);
+        hipLaunchKernelGGL(argmin_kernel, dim3((n + 31) / 32), dim3(256), 0, s, dist, lab_old, lab_prev, pos_begin, pos_end, B,
+                           lab_new, mind, second, first_change, in_place ? 1 : 0, g_gate);   // 8 lanes per position
 }
 
 }  // namespace chb

@@ -354,16 +354,29 @@ __global__ __launch_bounds__(256) void query_norms_kernel(const double *X, int D
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    // the global loads of the next 16 features are in flight while the current ones are used (the kernel is a
+    // chain of memory round trips otherwise: 9 of them at D = 136)
+    double cnx[4], xnx[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cnx[t] = (crow && ck + t < D) ? crow[ck + t] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) xnx[t] = (xrow && xk + t < D) ? xrow[xk + t] : 0.0;
     for (int k0 = 0; k0 < D; k0 += KC) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k = k0 + ck + t;
-            cs[crow_i][ck + t] = (crow && k < D) ? crow[k] * S : 0.0;
-        }
+        for (int t = 0; t < 4; ++t) cs[crow_i][ck + t] = cnx[t] * S;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int k = k0 + xk + t;
-            xs[xrow_i][xk + t] = (xrow && k < D) ? xrow[k] * S : 0.0;
+        for (int t = 0; t < 2; ++t) xs[xrow_i][xk + t] = xnx[t] * S;
+        if (k0 + KC < D) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = k0 + KC + ck + t;
+                cnx[t] = (crow && k < D) ? crow[k] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = k0 + KC + xk + t;
+                xnx[t] = (xrow && k < D) ? xrow[k] : 0.0;
+            }
         }
         __syncthreads();
 #pragma unroll
