@@ -15,18 +15,6 @@ __global__ void fill_i32_kernel(int *p, int v, int n, Gate gate)
     if (i < n) p[i] = v;
 }
 
-// batch start: remember the members' labels and mark them as "in the batch at position i"
-__global__ void batch_open_kernel(const int *labels, int *inb, const int *bq, int K, int *lab_old, Gate gate)
-{
-    CHB_GATE(gate);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < K) {
-        const int p = bq[i];
-        lab_old[i] = labels[p];
-        inb[p] = i;
-    }
-}
-
 // batch end (without the shadow refresh): final labels out, marks cleared
 __global__ void batch_close_kernel(int *labels, int *inb, const int *bq, const int *lab, int K)
 {
@@ -40,15 +28,32 @@ __global__ void batch_close_kernel(int *labels, int *inb, const int *bq, const i
 
 // ---- base members: every labelled sample that is not in the current batch
 
-__global__ void count_base_kernel(const int *labels, const int *inb, int N, int B, int *cnt, Gate gate)
+// bq != nullptr: the batch is opened in the same launch (labels remembered, members marked) -- the count then takes every labelled sample and the batch's own entries are subtracted again, so
+// that neither part reads what the other writes.
+__global__ void count_base_kernel(const int *labels, int *inb, int N, int B, int *cnt, const int *bq, int K,
+                                  int *lab_old, Gate gate)
 {
     CHB_GATE(gate);
     extern __shared__ int hist[];
     for (int b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
     __syncthreads();
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
-        const int l = labels[p];
-        if (l >= 0 && l < B && inb[p] < 0) atomicAdd(&hist[l], 1);
+    if (bq == nullptr) {
+        for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
+            const int l = labels[p];
+            if (l >= 0 && l < B && inb[p] < 0) atomicAdd(&hist[l], 1);
+        }
+    } else {
+        for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
+            const int l = labels[p];
+            if (l >= 0 && l < B) atomicAdd(&hist[l], 1);
+        }
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
+            const int p = bq[i];
+            const int l = labels[p];
+            lab_old[i] = l;
+            inb[p] = i;
+            if (l >= 0 && l < B) atomicSub(&hist[l], 1);
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x)
@@ -499,22 +504,20 @@ void launch_fill_i32(int *p, int v, int n, hipStream_t s)
 {
     if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n, g_gate);
 }
-void launch_batch_open(const int *labels, int *inb, const int *bq, int K, int *lab_old, hipStream_t s)
-{
-    if (K > 0) hipLaunchKernelGGL(batch_open_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, inb, bq, K, lab_old, g_gate);
-}
 void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, int K, hipStream_t s)
 {
     if (K > 0) hipLaunchKernelGGL(batch_close_kernel, dim3((K + 255) / 256), dim3(256), 0, s, labels, inb, bq, lab, K);
 }
 
-void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
-                        int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s)
+void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int *bin_ptr,
+                        int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s, const int *open_bq,
+                        int open_K, int *open_lab_old)
 {
     // (cnt is all zero here: allocated zeroed, and scan_kernel clears what it has read)
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt, g_gate);
+    hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt, open_bq,
+                       open_K, open_lab_old, g_gate);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr, zero_me, g_gate);
     hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * sizeof(int), s, labels, inb, N, B, cursor, memb_id, g_gate);
 }

@@ -428,11 +428,11 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
     h->K = K; h->q_lo = q_lo; h->q_hi = q_hi;
     h->round_in_batch = 0;
     hipStream_t s = h->stream;
-    launch_batch_open(h->labels.p, h->inb.p, h->bq_cur, K, h->lab_old.p, s);
     {
+        // (the batch is opened -- labels remembered, members marked -- inside the CSR count's launch)
         Timed t(h, "bucket", (double)h->N);
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
-                           h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, h->nflag.p, s);
+                           h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, h->nflag.p, s, h->bq_cur, K, h->lab_old.p);
     }
     TopmArgs a{};
     a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = q_lo; a.pos_end = q_hi;

@@ -210,14 +210,16 @@ void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const 
 
 // label / bucket helpers
 void launch_fill_i32(int *p, int v, int n, hipStream_t s);
-// batch start: lab_old[i] = labels[bq[i]], inb[bq[i]] = i;  batch end: labels[bq[i]] = lab[i], inb[bq[i]] = -1
-void launch_batch_open(const int *labels, int *inb, const int *bq, int K, int *lab_old, hipStream_t s);
+// batch end: labels[bq[i]] = lab[i], inb[bq[i]] = -1  (batch start -- lab_old[i] = labels[bq[i]], inb[bq[i]] = i --
+// rides in launch_bucket_base)
 void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, int K, hipStream_t s);
 // CSR of all labelled samples outside the batch
 // (pad_ptr, optional: the same CSR with every bin padded to a multiple of 32 rows -> MemberPack)
 // (zero_me, optional: one int the scan also resets -- the fallback list's counter of the coming shortlist launch)
-void launch_bucket_base(const int *labels, const int *inb, int N, int B, int *cnt, int *bin_ptr,
-                        int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s);
+// (open_bq, optional: the batch is opened in the count's launch: lab_old[i] = labels[bq[i]], inb[bq[i]] = i)
+void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int *bin_ptr,
+                        int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s,
+                        const int *open_bq = nullptr, int open_K = 0, int *open_lab_old = nullptr);
 // CSR of the batch's own members: earlier positions under lab_prev, later positions under lab_old
 // (also starts the round's scalars: *first_change = K, *n_slow = 0, *nflag = 0 where the pointers are non-null)
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
