@@ -631,7 +631,7 @@ def test_hull_distance_more_than_16_vertices(ctx, O, m):
         assert abs(np.linalg.norm(alpha @ P - x) - d) <= QP_TOL + 1e-7 * scale * (d < 1e-6 * scale)
 
 
-@pytest.mark.parametrize("N,D,B,m,batch", [(500, 40, 3, 20, 0), (400, 136, 2, 33, 60), (300, 24, 2, 64, 0)])
+@pytest.mark.parametrize("N,D,B,m,batch", [(500, 40, 3, 20, 0), (400, 136, 2, 33, 60), (220, 24, 2, 64, 0)])
 def test_fit_cluster_more_than_16_neighbors(ctx, O, N, D, B, m, batch):
     """AlgoNumNeighbors beyond the tuned kernels' 16: plain kernels, same labels as the oracle."""
     X, initial, _ = _synth(N, D, B, seed=N + m, sigma=6e-3, mix=0.5, n_seed=m + 6)
@@ -705,8 +705,8 @@ def test_small_batch_fewer_seeds_than_batch(ctx, O, batch, n_seed):
 
 F16_CASES = [
     # N, D, B, m, n_seed, batch, dup  (sigma 6e-3, mix 0.5: overlapping bins, several rounds per batch)
-    (1500, 136, 6, 15, 20, 0, False),      # one matrix-core tile (+ 1..2 extra rows) per pair
-    (1500, 136, 6, 16, 20, 0, False),      # m = 16: every tile row is a vertex
+    (1000, 136, 5, 15, 20, 0, False),      # one matrix-core tile (+ 1..2 extra rows) per pair
+    (1000, 136, 5, 16, 20, 0, False),      # m = 16: every tile row is a vertex
     (1500, 136, 6, 6, 8, 0, False),        # short lists on the 16-lane kernel
     (1200, 140, 5, 9, 12, 600, False),
     (1200, 40, 4, 12, 3, 800, False),      # few seeds, large batches: most candidates are batch entries (two tiles, exact path)

@@ -139,3 +139,48 @@ def test_affine_hull_distance_matches_reference_formula():
             P[2] = 0.5 * (P[0] + P[1])
         assert abs(O.affine_hull_distance(x, P) - ref(x, P)) < 1e-11
         assert O.affine_hull_distance(x, P) <= O.convex_hull_distance(x, P) + 1e-9
+
+
+def test_affine_hull_distance_16_vertices_fixture(golden_dir):
+    """tests/golden/affine_16_vertices.npz (made by tests/golden/make_affine_case.py): 16 vertices in D = 40 whose
+    centred matrix has one pure-noise singular value.  scipy.linalg.orth drops it (rank 15); a Gram-Schmidt
+    restatement with the cutoff on residual norms kept it and returned 0.024124 instead of 0.024251 (found by
+    tools/fuzz_fit.py in round 2, where every GPU path agreed with the scipy value)."""
+    import scipy.linalg
+    g = np.load(os.path.join(golden_dir, "affine_16_vertices.npz"))
+    x, P = g["x"], g["P"]
+    mean = P.mean(axis=0)
+    basis = scipy.linalg.orth((P - mean).T)
+    assert basis.shape[1] == int(g["rank"]) == 15
+    proj = basis @ np.linalg.inv(basis.T @ basis) @ basis.T
+    live = np.linalg.norm((np.eye(proj.shape[0]) - proj) @ (x - mean))
+    assert abs(live - float(g["expected"])) < 1e-13
+    assert abs(O.affine_hull_distance(x, P) - float(g["expected"])) < 1e-12
+
+
+def test_affine_hull_distance_many_vertices_with_common_offset():
+    """The shape that separates a faithful restatement of scipy.linalg.orth from Gram-Schmidt with a cutoff on
+    residual norms: 12 .. 16 vertices whose features share a large offset (coverage columns of 0.2 next to k-mer
+    frequencies of 0.004).  The centred rows sum to zero only up to rounding; orth drops that direction (its
+    singular value is far below sigma_max * eps * max(m, D)), a residual-norm cutoff can keep it and return a
+    distance that is too small (found by tools/fuzz_fit.py in round 2)."""
+    import scipy.linalg
+
+    def ref(q, P):
+        mean = P.mean(axis=0)
+        basis = scipy.linalg.orth((P - mean).T)
+        proj = basis @ np.linalg.inv(basis.T @ basis) @ basis.T
+        return np.linalg.norm((np.eye(proj.shape[0]) - proj) @ (q - mean))
+
+    rng = np.random.default_rng(11)
+    for t in range(200):
+        m = int(rng.integers(12, 17))
+        # (D >= 40: with fewer features the cutoff sigma_max * eps * max(m, D) sits below the rounding noise itself and
+        #  the reference formula has no stable value -- LAPACK's noise direction is as good as anybody's)
+        D = int(rng.choice([40, 100, 136]))
+        base = np.concatenate([np.full(D // 8, 0.2), np.full(D - D // 8, 0.004)])
+        P = base + 0.004 * rng.standard_normal((m, D))
+        x = base + 0.01 * rng.standard_normal(D)
+        want = ref(x, P)
+        got = O.affine_hull_distance(x, P)
+        assert abs(got - want) <= 1e-12 + 1e-10 * want, (t, m, D, got, want)

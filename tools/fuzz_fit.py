@@ -1,5 +1,6 @@
 """Developer soak: random small configurations, HIP fit_cluster vs the CPU oracle (labels, sweep
-counts, per-sweep change counts must be identical).  usage: python tools/fuzz_fit.py [n_cases] [seed] [big]   (big: bins of > 512 members, few bins)"""
+counts, per-sweep change counts must be identical).  usage: python tools/fuzz_fit.py [n_cases] [seed] [big|m16]   (big: bins of > 512 members, few bins; m16: the fused
+16-lane kernel, 6 <= m <= 16)"""
 import os
 import sys
 
@@ -12,6 +13,7 @@ from oracle import oracle as O  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
+m16 = len(sys.argv) > 3 and sys.argv[3] == "m16"
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ctx = _lib.default_context()
 bad = 0
@@ -31,6 +33,10 @@ for t in range(n_cases):
         iters = int(rng.integers(1, 4)); batch = int(rng.choice([0, 512, 2048])); n_seed = int(rng.integers(5, 40))
         D = int(rng.choice([100, 136, 140, 146]))
         S = 1 if D < 140 else (5 if D < 146 else 10)
+    if m16:
+        N = int(rng.integers(200, 1100)); m = int(rng.integers(6, 17)); D = int(rng.choice([24, 40, 100, 136, 140, 146, 160]))
+        S = 1 if D < 140 else (5 if D < 146 else 10)
+        iters = int(rng.integers(1, 4)); n_seed = int(rng.integers(1, 24))
     metric = str(rng.choice(["convex", "convex", "convex", "affine"]))
     if m > D or D < 24:
         # m > D: the affine hull of > D generic points is the whole space, every distance is rounding
