@@ -74,16 +74,28 @@ __global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int *bin_ptr
     for (int b = b0; b < b1; ++b) { s += cnt[b]; sp += (cnt[b] + 31) / 32 * 32; }
     part[threadIdx.x] = s; ppart[threadIdx.x] = sp;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nparts = (B + per - 1) / per;   // (threads beyond own no bin)
-        int run = 0, prun = 0;
-        for (int i = 0; i < nparts; ++i) {
-            const int v = part[i], pv = ppart[i];
-            part[i] = run; ppart[i] = prun;
+    if (threadIdx.x < 64) {
+        // exclusive scan of the 256 partials by one wavefront: lane l owns parts 4 l .. 4 l + 3
+        // (threads beyond ceil(B / per) own no bin and contribute zeros)
+        const int l = threadIdx.x;
+        int loc = 0, ploc = 0;
+        for (int i = 0; i < 4; ++i) { loc += part[4 * l + i]; ploc += ppart[4 * l + i]; }
+        int inc = loc, pinc = ploc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off, 64), po = __shfl_up(pinc, off, 64);
+            if (l >= off) { inc += o; pinc += po; }
+        }
+        int run = inc - loc, prun = pinc - ploc;
+        for (int i = 0; i < 4; ++i) {
+            const int v = part[4 * l + i], pv = ppart[4 * l + i];
+            part[4 * l + i] = run; ppart[4 * l + i] = prun;
             run += v; prun += pv;
         }
-        bin_ptr[B] = run;   // (the totals)
-        if (pad_ptr) pad_ptr[B] = prun;
+        if (l == 63) {
+            bin_ptr[B] = run;   // (the totals)
+            if (pad_ptr) pad_ptr[B] = prun;
+        }
     }
     __syncthreads();
     int run = part[threadIdx.x], prun = ppart[threadIdx.x];
