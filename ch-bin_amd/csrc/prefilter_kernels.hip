@@ -245,6 +245,15 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs
                                                         const int *pad_ptr, int B, MemberPack P, Gate gate)
 {
     CHB_GATE(gate);
+    // the two CSR offset tables go through LDS (up to 2048 bins): the bin search of every row is then a chain of LDS
+    // reads instead of six dependent global loads in front of the row's own gather
+    constexpr int kLdsBins = 2048;
+    __shared__ int s_pad[kLdsBins + 1], s_bin[kLdsBins + 1];
+    if (B <= kLdsBins) {
+        for (int b = threadIdx.x; b <= B; b += blockDim.x) { s_pad[b] = pad_ptr[b]; s_bin[b] = bin_ptr[b]; }
+        __syncthreads();
+        pad_ptr = s_pad; bin_ptr = s_bin;
+    }
     const int total = pad_ptr[B];
     const int cpr = Dz >> 3;
     const int l16 = threadIdx.x & 15;
