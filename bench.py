@@ -373,16 +373,23 @@ def main():
                                          "note": "d2 - d1 (runner-up minus winning hull distance) at each movable contig's "
                                                  "last visit; QP distances agree with the CPU oracle to <= 1e-9 (tests), "
                                                  "north-star tolerance 1e-5"}
-            # (c) overlapping bins: mix = 0.5, sigma = 6e-3 (labels close to random, many movers per sweep)
-            Xh, inith, _ = synth.make_synthetic(N, D, B, S=S, seed=0, mix=0.5, sigma=6e-3)
-            permsh = synth.draw_permutations(inith, 3, seed=0)
-            ctx.set_samples(Xh)
-            th = sweep_time(ctx, inith, permsh, m)
-            sth = ctx.fit_stats()
-            extra["overlapping_bins"] = {"generator": "mix=0.5 sigma=6e-3", "ms_per_sweep": th * 1e3,
-                                         "qp_per_s": int(permsh.shape[1]) * B / th,
-                                         "rounds_per_batch": sth["rounds"] / max(sth["batches"], 1),
-                                         "hull_evaluated_per_needed": sth["hull_evaluated"] / max(sth["hull_needed"], 1)}
+            # (c) overlapping bins.  Two generator settings: one where the bins overlap but the algorithm still
+            # recovers them (speculation has to repeat rounds), and one where the reference algorithm itself
+            # collapses into a few giant bins (bin-size skew on top of failing speculation).
+            for key, mixh, sigh in (("overlapping_bins", 0.3, 4.5e-3), ("collapsed_bins", 0.5, 6e-3)):
+                Xh, inith, trueh = synth.make_synthetic(N, D, B, S=S, seed=0, mix=mixh, sigma=sigh)
+                permsh = synth.draw_permutations(inith, 3, seed=0)
+                ctx.set_samples(Xh)
+                th = sweep_time(ctx, inith, permsh, m)
+                sth = ctx.fit_stats()
+                labh, _, _ = ctx.fit_cluster(B, inith, permsh[:1], m, 1)
+                sizes = np.sort(np.bincount(labh[labh >= 0], minlength=B))[::-1]
+                extra[key] = {"generator": f"mix={mixh} sigma={sigh}", "ms_per_sweep": th * 1e3,
+                              "qp_per_s": int(permsh.shape[1]) * B / th,
+                              "rounds_per_batch": sth["rounds"] / max(sth["batches"], 1),
+                              "hull_evaluated_per_needed": sth["hull_evaluated"] / max(sth["hull_needed"], 1),
+                              "accuracy_vs_truth_after_sweep_1": float((labh == trueh).mean()),
+                              "largest_bins": [int(v) for v in sizes[:3]]}
 
         out = {
             "metric": f"convex-hull QP distances/sec (+ end-to-end bin-assign wall-clock), N={N} D={D} B={B}",
