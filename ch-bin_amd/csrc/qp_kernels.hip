@@ -839,15 +839,16 @@ __device__ __forceinline__ void group_argmin16(double key, int lane, double &kmi
 // broadcasts are independent of each other -- a few LDS rounds deep, where an elimination from
 // scratch is a 16-step dependent chain.  The pivot of the update is the Schur complement delta, the
 // same quantity whose collapse marks an affinely dependent support in solve_affine<M>.
-// developer builds (tools/m15_probe.py): CHB_DEV_KNOBS = iteration statistics of the 16-lane solver (its atomics
-// distort timings), CHB_DEV_CLK = cycle stamps of the fused 16-lane kernel's phases only
-#if defined(CHB_DEV_KNOBS) || defined(CHB_DEV_CLK)
+// developer variants (tools/m15_probe.py; tools/build_variant.sh <name> "-DCHB_DEV_QP16_STAT" or "-DCHB_DEV_CLK"):
+// CHB_DEV_QP16_STAT = iteration statistics of the 16-lane solver (its atomics distort timings), CHB_DEV_CLK = cycle
+// stamps of the fused 16-lane kernel's phases only
+#if defined(CHB_DEV_QP16_STAT) || defined(CHB_DEV_CLK)
 __device__ unsigned long long g_qp16_stats[16];
 #endif
 #ifdef CHB_DEV_CLK
 __device__ unsigned long long g_qp16_clk[131072][8];   // per-wavefront cycle stamps of the last launch (no atomics)
 #endif
-#ifdef CHB_DEV_KNOBS
+#ifdef CHB_DEV_QP16_STAT
 #define QP16_STAT(i, v) do { if (l16 == 0) atomicAdd(&g_qp16_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define QP16_STAT(i, v) do { } while (0)
@@ -915,7 +916,7 @@ __device__ __forceinline__ bool inv16_insert(Inv16 &I, const double *Qt, double 
     double delta = avv - group_sum16(a_own * u);
     double ug[16];
     if (!(delta > 1e-6 * avv)) {
-#ifdef CHB_DEV_KNOBS
+#ifdef CHB_DEV_QP16_STAT
         if (l16 == 0) atomicAdd(&g_qp16_stats[4], 1ull);
 #endif
         // A small pivot is decided after one step of iterative refinement against the ORIGINAL rows
@@ -1950,8 +1951,8 @@ void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const 
 
 }  // namespace chb
 
-#if defined(CHB_DEV_KNOBS) || defined(CHB_DEV_CLK)
-// developer builds only: [0] problems solved, [1] major iterations, [2] ratio-test removals, [3] final support
+#if defined(CHB_DEV_QP16_STAT) || defined(CHB_DEV_CLK)
+// developer variants only: [0] problems solved, [1] major iterations, [2] ratio-test removals, [3] final support
 // sizes (sum), [4] small-pivot refinements of inv16_insert
 #ifdef CHB_DEV_CLK
 // sums of the per-wavefront stamps of the last launch: [0] sweeps [1] selection [2] slow list + solver [3] id loads

@@ -1,6 +1,8 @@
 """Developer probe: m = 15 sweep timing, 16-lane solver iteration statistics (developer library only), shortlist
 width histogram, parity against the oracle on a prefix.
-usage: CHBIN_LIB=ch-bin_amd/libchbin_hip_dev.so python tools/m15_probe.py [m]"""
+usage: python tools/m15_probe.py [m], with CHBIN_LIB pointing at a variant built by
+  tools/build_variant.sh stat "-DCHB_DEV_QP16_STAT" qp_kernels   (solver iteration statistics; distorts timings) or
+  tools/build_variant.sh clk "-DCHB_DEV_CLK" qp_kernels           (cycle stamps of the fused 16-lane kernel)"""
 import ctypes
 import os
 import sys
