@@ -259,7 +259,7 @@ def main():
         traffic = {}
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))["kernels"]
-            tmap = {"prefilter": "shortlist_kernel<5, false, 9>", "hull_qp": "hull_select_qp_kernel<5, 7, 4>",
+            tmap = {"prefilter": "shortlist_kernel<5, false, 9>", "hull_qp": "hull_select_qp_kernel<5, 7, 4, true>",
                     "prefilter_update": "shortlist_kernel<1, true, 9>", "query_norms": "query_norms_kernel"}
             if (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist and fused:
                 for name, src in tmap.items():

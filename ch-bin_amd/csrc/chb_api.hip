@@ -545,7 +545,7 @@ int batch_round_dev(chb_ctx *h, int active)
                 launch_topm_flagged(a, h->flags64.p, h->flaglist.p, h->nflag.p, s);
             }
             FusedArgs f{};
-            f.X = h->X.p; f.D = h->D; f.Dp = h->Dp; f.bq = h->bq_cur; f.pos_begin = lo; f.pos_end = hi;
+            f.X = h->X.p; f.n_samples = h->N; f.D = h->D; f.Dp = h->Dp; f.bq = h->bq_cur; f.pos_begin = lo; f.pos_end = hi;
             f.B = h->B; f.m = h->m; f.Kcap = h->Kcap;
             f.cand = h->cand.p; f.cand_cnt = h->cand_cnt.p;
             f.candu = h->candu[cur].p; f.candu_cnt = h->candu_cnt[cur].p;

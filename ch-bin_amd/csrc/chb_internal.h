@@ -178,6 +178,7 @@ void launch_hull_qp(const QpArgs &a, hipStream_t s);
 // (rescore_kernel + hull_qp_kernel on that list).
 struct FusedArgs {
     const double *X;
+    long long n_samples;   // rows of X (the m <= 5 kernel addresses rows by 32-bit byte offsets below 4 GiB)
     int D, Dp;
     const int *bq;
     int pos_begin, pos_end;

@@ -19,6 +19,7 @@
 // The result is the same projection distance the reference's QP defines (unique even when alpha
 // is not); agreement with the CPU oracle's Goldfarb-Idnani restatement is ~1e-13 relative.
 #include "chb_internal.h"
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -416,31 +417,42 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
 // beyond rounding.
 constexpr double kTieRel = 1e-11;
 
-template <int CC, int NR>
+// OFF32: the rows are addressed as 32-bit byte offsets from the (uniform) base of X -- half the registers of
+// 64-bit row pointers, which is what keeps the kernel free of spills at 3 wavefronts per SIMD (the launcher picks
+// it when the sample matrix is smaller than 4 GiB).
+template <int CC, int NR, bool OFF32>
 __device__ __forceinline__ void gram_rows(const double *X, int Dp, int qid, int idm, int gbase, int l16,
                                           double (&r)[NR])
 {
     constexpr int NP = CC * (CC + 1) / 2;
     static_assert(NP <= 16 * NR, "result registers");
+    const char *Xb = reinterpret_cast<const char *>(X);
     const double *xrow = X + (size_t)qid * Dp;
-    const double *vrow[CC];
+    const unsigned xoff = (unsigned)qid * (unsigned)Dp * 8u;
+    const double *vrow[OFF32 ? 1 : CC];
+    unsigned voff[OFF32 ? CC : 1];
 #pragma unroll
     for (int v = 0; v < CC; ++v) {
         const int idv = __shfl(idm, gbase + v, 64);
         // a missing candidate reads the query row: y = 0, its Gram row / column stays 0 (never used)
-        vrow[v] = X + (size_t)(idv >= 0 ? idv : qid) * Dp;
+        if (OFF32) voff[v] = (unsigned)(idv >= 0 ? idv : qid) * (unsigned)Dp * 8u;
+        else vrow[v] = X + (size_t)(idv >= 0 ? idv : qid) * Dp;
     }
+    auto xat = [&](int k) { return OFF32 ? reinterpret_cast<const double *>(Xb + (size_t)(xoff + 8u * (unsigned)k)) : xrow + k; };
+    auto vat = [&](int v, int k) {
+        return OFF32 ? reinterpret_cast<const double *>(Xb + (size_t)(voff[OFF32 ? v : 0] + 8u * (unsigned)k)) : vrow[OFF32 ? 0 : v] + k;
+    };
     double acc[NP];
 #pragma unroll
     for (int e = 0; e < NP; ++e) acc[e] = 0.0;
     const int Dmain = Dp & ~31;
 #pragma unroll 1
     for (int k = 2 * l16; k < Dmain; k += 32) {
-        const double2 xk = *reinterpret_cast<const double2 *>(xrow + k);
+        const double2 xk = *reinterpret_cast<const double2 *>(xat(k));
         double2 y[CC];
 #pragma unroll
         for (int v = 0; v < CC; ++v) {
-            const double2 pv = *reinterpret_cast<const double2 *>(vrow[v] + k);
+            const double2 pv = *reinterpret_cast<const double2 *>(vat(v, k));
             y[v] = double2{pv.x - xk.x, pv.y - xk.y};
         }
 #pragma unroll
@@ -453,10 +465,10 @@ __device__ __forceinline__ void gram_rows(const double *X, int Dp, int qid, int 
             }
     }
     for (int k = Dmain + l16; k < Dp; k += 16) {
-        const double xk = xrow[k];
+        const double xk = *xat(k);
         double y[CC];
 #pragma unroll
-        for (int v = 0; v < CC; ++v) y[v] = vrow[v][k] - xk;
+        for (int v = 0; v < CC; ++v) y[v] = *vat(v, k) - xk;
 #pragma unroll
         for (int i = 0; i < CC; ++i)
 #pragma unroll
@@ -484,41 +496,50 @@ constexpr int kFusedWide = CHB_FUSED_WIDE;   // widest shortlist the fused kerne
 
 // squared distances only: candidate v (v < 8) of every 16-lane group is the one held by lane gbase + v0 + v;
 // on return lane l16 < 8 holds the squared distance of candidate v0 + l16
+template <bool OFF32>
 __device__ __forceinline__ double diag_rows8(const double *X, int Dp, int qid, int idm, int gbase, int l16, int v0)
 {
+    const char *Xb = reinterpret_cast<const char *>(X);
     const double *xrow = X + (size_t)qid * Dp;
-    const double *vrow[8];
+    const unsigned xoff = (unsigned)qid * (unsigned)Dp * 8u;
+    const double *vrow[OFF32 ? 1 : 8];
+    unsigned voff[OFF32 ? 8 : 1];
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
         const int idv = __shfl(idm, gbase + v0 + v, 64);
-        vrow[v] = X + (size_t)(idv >= 0 ? idv : qid) * Dp;
+        if (OFF32) voff[v] = (unsigned)(idv >= 0 ? idv : qid) * (unsigned)Dp * 8u;
+        else vrow[v] = X + (size_t)(idv >= 0 ? idv : qid) * Dp;
     }
+    auto xat = [&](int k) { return OFF32 ? reinterpret_cast<const double *>(Xb + (size_t)(xoff + 8u * (unsigned)k)) : xrow + k; };
+    auto vat = [&](int v, int k) {
+        return OFF32 ? reinterpret_cast<const double *>(Xb + (size_t)(voff[OFF32 ? v : 0] + 8u * (unsigned)k)) : vrow[OFF32 ? 0 : v] + k;
+    };
     double acc[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0;
     const int Dmain = Dp & ~31;
 #pragma unroll 1
     for (int k = 2 * l16; k < Dmain; k += 32) {
-        const double2 xk = *reinterpret_cast<const double2 *>(xrow + k);
+        const double2 xk = *reinterpret_cast<const double2 *>(xat(k));
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
-            const double2 pv = *reinterpret_cast<const double2 *>(vrow[v] + k);
+            const double2 pv = *reinterpret_cast<const double2 *>(vat(v, k));
             const double dx = pv.x - xk.x, dy = pv.y - xk.y;
             acc[v] = fma(dy, dy, fma(dx, dx, acc[v]));
         }
     }
     for (int k = Dmain + l16; k < Dp; k += 16) {
-        const double xk = xrow[k];
+        const double xk = *xat(k);
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
-            const double d = vrow[v][k] - xk;
+            const double d = *vat(v, k) - xk;
             acc[v] = fma(d, d, acc[v]);
         }
     }
     return reduce_scatter16(acc, l16);
 }
 
-template <int M, int C, int WAVES>
+template <int M, int C, int WAVES, bool OFF32>
 __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kernel(FusedArgs a, int nprob, Gate gate)
 {
     CHB_GATE(gate);
@@ -612,10 +633,10 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             // the widest shortlist of the pass (the last problem: they are sorted)
             const int cw = __builtin_amdgcn_readfirstlane(__shfl(n, sOrd[w][min(p0 + 3, nnarrow - 1)], 64));
             double r[NR];
-            if (cw <= M) gram_rows<M, NR>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
-            else if (C >= M + 1 && cw == M + 1) gram_rows<(C >= M + 1 ? M + 1 : M), NR>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
-            else if (C >= M + 2 && cw == M + 2) gram_rows<(C >= M + 2 ? M + 2 : M), NR>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
-            else gram_rows<C, NR>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
+            if (cw <= M) gram_rows<M, NR, OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
+            else if (C >= M + 1 && cw == M + 1) gram_rows<(C >= M + 1 ? M + 1 : M), NR, OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
+            else if (C >= M + 2 && cw == M + 2) gram_rows<(C >= M + 2 ? M + 2 : M), NR, OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
+            else gram_rows<C, NR, OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
             bool tie = false;
             if (has && n_g <= m) {
                 // every candidate is a hull vertex: the candidate Gram is the hull's (any vertex order)
@@ -692,9 +713,9 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             nmax = max(nmax, __shfl_xor(nmax, 16, 64));
             nmax = max(nmax, __shfl_xor(nmax, 32, 64));
             nmax = __builtin_amdgcn_readfirstlane(nmax);
-            double sv = diag_rows8(a.X, a.Dp, qid_g, idm, gbase, l16, 0);
+            double sv = diag_rows8<OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, 0);
             if (nmax > 8) {
-                const double s_hi = diag_rows8(a.X, a.Dp, qid_g, idm, gbase, l16, 8);
+                const double s_hi = diag_rows8<OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, 8);
                 const double moved = __shfl(s_hi, gbase + (l16 & 7), 64);
                 sv = l16 < 8 ? sv : moved;
             }
@@ -722,7 +743,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
                 if (l16 < m) idm2 = sSel[w][grp][l16];
             }
             double r[NR];
-            gram_rows<M, NR>(a.X, a.Dp, qid_g, idm2, gbase, l16, r);
+            gram_rows<M, NR, OFF32>(a.X, a.Dp, qid_g, idm2, gbase, l16, r);
             if (has && !tie) {
 #pragma unroll
                 for (int t = 0; t < NR; ++t)
@@ -1923,7 +1944,13 @@ void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
         return;
     }
     const int grid = (nprob + 64 * WV - 1) / (64 * WV);
-    hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
+    // (rows as 32-bit byte offsets while the sample matrix is smaller than 4 GiB: see gram_rows; CHB_FUSED_PTR64=1
+    //  selects the 64-bit-pointer instantiation regardless, for the tests)
+    static const bool ptr64 = getenv("CHB_FUSED_PTR64") != nullptr && atoi(getenv("CHB_FUSED_PTR64")) != 0;
+    if (!ptr64 && (unsigned long long)a.n_samples * (unsigned long long)a.Dp * 8ull < (1ull << 32))
+        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, true>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
+    else
+        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, false>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
 }
 
 void launch_hull_generic(const QpArgs &a, hipStream_t s)

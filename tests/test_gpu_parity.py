@@ -758,3 +758,27 @@ def test_fused_16_lane_kernel_vs_oracle_and_lists(O, N, D, B, m, n_seed, batch, 
         b.close()
     assert its_l == its and np.array_equal(ch_l, ch) and np.array_equal(got_l, got)
     assert np.allclose(mind_l, mind, rtol=0, atol=QP_TOL, equal_nan=True)
+
+
+def test_fused_kernel_64bit_row_pointers(O):
+    """The m <= 5 fused kernel addresses the rows of X by 32-bit byte offsets below 4 GiB; the 64-bit-pointer
+    instantiation (what a larger sample matrix gets) is selected here by CHB_FUSED_PTR64=1 in a child process (the
+    switch is read once per process) and must give the same fit."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import chbin_amd\n"
+        "from chbin_amd import _lib, synth\n"
+        "from oracle import oracle as O\n"
+        "X, initial, _ = synth.make_synthetic(1200, 136, 6, S=1, seed=5, sigma=6e-3, mix=0.5, n_seed=8)\n"
+        "perms = synth.draw_permutations(initial, 3, seed=0)\n"
+        "want, its_o, ch_o = O.fit_cluster(X, 6, initial, perms, 5, 3)\n"
+        "c = _lib.Context(0); c.set_samples(X)\n"
+        "got, its, ch = c.fit_cluster(6, initial, perms, 5, 3, batch=300)\n"
+        "assert c.counter('fused_enabled') == 1\n"
+        "assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, CHB_FUSED_PTR64="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
