@@ -107,6 +107,7 @@ class Context:
         self._lib = lib
         self.device = int(device)
         self.N = self.D = 0
+        self._metric = "convex"
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -125,6 +126,25 @@ class Context:
         if metric not in self.METRICS:
             raise NotImplementedError(f"Metric {metric} not implemented")   # hull_distance.py:108
         check(self._lib.chb_set_metric(self._h, self.METRICS[metric]))
+        self._metric = metric
+
+    def get_metric(self) -> str:
+        return self._metric
+
+    def using_metric(self, metric: str):
+        """with ctx.using_metric("affine"): ... -- selects the metric and puts the caller's back afterwards
+        (the mirror functions share one default context)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            before = self._metric
+            self.set_metric(metric)
+            try:
+                yield self
+            finally:
+                self.set_metric(before)
+        return scope()
 
     # ---- samples
     def set_samples(self, X):

@@ -45,12 +45,9 @@ def fit_cluster(
 
     ctx = default_context()
     ctx.set_samples_cached(samples)
-    ctx.set_metric(metric)
-    try:
+    with ctx.using_metric(metric):
         labels, iters, changed = ctx.fit_cluster(int(num_clusters), initial, perms.astype(np.int64),
                                                  int(num_neighbors), int(max_iterations), batch=batch)
-    finally:
-        ctx.set_metric("convex")
 
     np.random.set_state(state)
     for _ in range(iters):

@@ -16,12 +16,8 @@ def convex_hull_distance(query: np.ndarray, points: np.ndarray, solver: str = "q
 def _distance(query, points, metric):
     points = np.asarray(points, dtype=np.float64)
     query = np.asarray(query, dtype=np.float64)
-    ctx = default_context()
-    ctx.set_metric(metric)
-    try:
+    with default_context().using_metric(metric) as ctx:
         return float(ctx.hull_distance_points(query, points.reshape(-1, query.shape[0])))
-    finally:
-        ctx.set_metric("convex")
 
 
 def affine_hull_distance(query: np.ndarray, points: np.ndarray) -> float:

@@ -4,7 +4,8 @@ In the reference `solve_qp` (solve_qp.py:96-132) hands a dense (P, q, G, h, A, b
 Its only callers are the two hull distances of hull_distance.py, which build exactly two forms:
 
   * convex hull  (hull_distance.py:17-33):  P = 2 X X^T, q = -2 X x, G = -I, h = 0, A = 1^T, b = 1
-  * affine hull  (hull_distance.py:48-64):  the same P, q, A, b and no inequality (G = h = None)
+  * affine hull  (hull_distance.py:48-64):  the same P, q, A, b and an inequality block of ZERO rows
+                                            (G = np.zeros((0, m)), h = np.zeros(0); None / None is accepted too)
 
 On the HIP path these QPs are normally never materialised (the kernel builds the Gram of a hull and solves it
 in one pass).  This function keeps the seam callable: it recognises the two forms and solves them on the GPU
@@ -36,9 +37,13 @@ def _recognise(mat_p, vec_q, mat_g, vec_h, mat_a, vec_b):
         return None
     if np.asarray(vec_b, dtype=np.float64).reshape(-1).tolist() != [1.0]:
         return None
-    if mat_g is None and vec_h is None:
+    # "no inequality" is G = h = None or, as hull_distance.py:54-55 really passes it, a block of zero rows
+    # (np.zeros((0, n)), np.zeros(0))
+    no_g = mat_g is None or np.size(mat_g) == 0
+    no_h = vec_h is None or np.size(vec_h) == 0
+    if no_g and no_h:
         return "affine"
-    if mat_g is None or vec_h is None:
+    if no_g or no_h:
         return None
     g = np.asarray(mat_g, dtype=np.float64)
     hv = np.asarray(vec_h, dtype=np.float64).reshape(-1)
@@ -68,10 +73,6 @@ def solve_qp(mat_p, vec_q, mat_g=None, vec_h=None, mat_a=None, vec_b=None, solve
             "sum-to-one-only least squares); a general QP is not part of the accelerated path")
     from .._lib import default_context
     z_rows, z = _surrogate_points(mat_p, vec_q)
-    ctx = default_context()
-    ctx.set_metric(form)
-    try:
+    with default_context().using_metric(form) as ctx:   # (the caller's metric is put back afterwards)
         _, alpha = ctx.hull_distance_points(z, z_rows, want_alpha=True)
-    finally:
-        ctx.set_metric("convex")
     return alpha

@@ -222,7 +222,7 @@ struct chb_ctx {
     bool pf_base = true, pf_update = true;   // developer switches (CHB_PF_BASE / CHB_PF_UPDATE; -DCHB_DEV_KNOBS builds only)
     DevBuf<int> cand, cand_cnt, flags64, flaglist, nflag, overflow;
     DevBuf<int> active, n_active, act_blk;
-    // fused selection + hull distance (m <= 5): batch-entry candidates of this / the previous round,
+    // fused selection + hull distance (m <= 16): batch-entry candidates of this / the previous round,
     // the base stage's tau (bound of the m-th nearest distance), the exact path's work list
     bool fused = false, allow_fused = true;
     bool pf_fit = false;        // this fit uses the shortlist stage (use_prefilter, D <= 160, m <= 16)
@@ -380,6 +380,8 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     if (B > 8192) return fail(CHB_EUNSUPPORTED, "more than 8192 bins (per-block LDS histograms of the CSR build)");
     if (m < 1 || m > CHB_MAX_NEIGHBORS)
         return fail(CHB_EUNSUPPORTED, "num_neighbors must be in [1, 64]");
+    if (m > kMaxM && !hull_generic_supported())
+        return fail(CHB_EUNSUPPORTED, "num_neighbors > 16 needs 68 KB of LDS per workgroup, which this device does not grant");
     h->B = (int)B; h->m = m;
     // the fp16 shortlist stage and the tuned kernels hold lists of up to 16 entries; beyond that the plain
     // one-wavefront-per-problem kernels run (brute-force selection, LDS-resident solver)
@@ -420,7 +422,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
 }
 
 // bq already holds the K sample indices (device).  need_lists: the caller wants the exact base lists
-// L0 (chb_topm_per_bin); the fit loop of the fused path (m <= 5) works on the shortlists directly.
+// L0 (chb_topm_per_bin); the fit loop of the fused path (m <= 16) works on the shortlists directly.
 int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
 {
     const bool fusedp = h->fused && !need_lists;
@@ -698,7 +700,7 @@ int chb_create(int device_id, chb_ctx **out)
     h->dev = device_id;
     if (const char *e = getenv("CHB_PREFILTER")) h->use_prefilter = atoi(e) != 0;
     if (const char *e = getenv("CHB_FORCE_GATHER")) h->force_gather = atoi(e) != 0;
-    // CHB_FUSED=0: m <= 5 also takes the list-based path (exact rescoring of every shortlist, then the hull
+    // CHB_FUSED=0: m <= 16 also takes the list-based path (exact rescoring of every shortlist, then the hull
     // kernel); like CHB_PREFILTER=0 a switch to the slower, independent formulation for the tests' A/B checks
     if (const char *e = getenv("CHB_FUSED")) h->allow_fused = atoi(e) != 0;
 #ifdef CHB_DEV_KNOBS   // developer builds only (tools/): the product library reads no tuning knob
@@ -941,11 +943,25 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     if (n_move > 0 && !perms) return fail(CHB_EINVAL, "perms is null");
     if (max_iter < 0 || n_move < 0 || n_move > h->N) return fail(CHB_EINVAL, "bad n_move/max_iter");
     HIPCHK(hipSetDevice(h->dev));
+    if (h->world > 1 && !h->comm && !h->hook) return fail(CHB_ESTATE, "world > 1 but chb_comm_init was not called");
+    if (!h->X.p) return fail(CHB_ESTATE, "chb_set_samples has not been called");
+    // every permutation entry is range-checked BEFORE anything runs (a min / max pass the compiler vectorises), so a
+    // bad entry in a late sweep cannot surface after earlier sweeps have already run; duplicates inside a sweep
+    // are rejected while that sweep is converted for its upload (bitmap), and any error return closes the fit
+    {
+        int64_t lo = 0, hi = 0;
+        const int64_t tot = (int64_t)max_iter * n_move;
+        for (int64_t i = 0; i < tot; ++i) { lo = std::min(lo, perms[i]); hi = std::max(hi, perms[i]); }
+        if (lo < 0 || hi >= h->N) return fail(CHB_EINVAL, "perm entry out of range");
+    }
     int rc = fit_begin_impl(h, B, initial_bins, m);
     if (rc) return rc;
+    struct FitCloser {   // an error return must not leave an open fit / batch behind
+        chb_ctx *h; bool ok = false;
+        ~FitCloser() { if (!ok) { (void)hipStreamSynchronize(h->stream); h->fit_open = false; h->batch_open = false; } }
+    } fit_closer{h};
     const int64_t N = h->N;
-    // (the permutations are range-checked sweep by sweep, while they are converted for the upload)
-    if (h->world > 1 && !h->comm && !h->hook) return fail(CHB_ESTATE, "world > 1 but chb_comm_init was not called");
+    std::vector<uint64_t> seen_bits;
     // default batch: 8192 positions on one GPU, growing with sqrt(world): the batch-member
     // (update) work per rank is ~K^2/world, the per-rank grids ~K/world
     int Kmax = batch > 0 ? batch : 8192 * std::max(1, (int)std::lround(std::sqrt((double)h->world)));
@@ -979,13 +995,17 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         HIPCHK(h->pin_a.ensure((size_t)std::max<int64_t>(n_move, 1)));
         if (n_move) {
             HIPCHK(hipStreamSynchronize(s));   // (pin_a may still be the source of the previous upload)
-            int64_t bad = 0;
+            seen_bits.assign((size_t)(N + 63) / 64, 0);
+            uint64_t dup = 0;
             for (int64_t i = 0; i < n_move; ++i) {
-                const int64_t v = perm[i];
-                bad |= (v < 0) | (v >= N);
+                const int64_t v = perm[i];          // (in range: checked up front)
+                uint64_t &wd = seen_bits[(size_t)(v >> 6)];
+                const uint64_t bit = 1ull << (v & 63);
+                dup |= wd & bit;
+                wd |= bit;
                 h->pin_a.p[i] = (int)v;
             }
-            if (bad) return fail(CHB_EINVAL, "perm entry out of range");
+            if (dup) return fail(CHB_EINVAL, "a sweep's permutation lists a sample twice");
             HIPCHK(hipMemcpyAsync(h->perm.p, h->pin_a.p, sizeof(int) * n_move, hipMemcpyHostToDevice, s));
         }
         // ---- the batches of this sweep.  A batch = start (selection against the members outside it), a
@@ -1058,11 +1078,11 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         };
         struct Snap {   // host-side batch state (the device side of a gated-off batch never changed)
             int K, q_lo, q_hi, round_in_batch; bool lists_valid, batch_open; int *bq_cur, *fc_cur;
-            double hb, he; int64_t st[4];
+            double hb, he; int64_t st[4]; size_t n_pending;
         };
         auto save = [&]() {
             Snap v{h->K, h->q_lo, h->q_hi, h->round_in_batch, h->lists_valid, h->batch_open, h->bq_cur, h->fc_cur,
-                   h->hint_base_members, h->hint_batch_entries, {0, 0, 0, 0}};
+                   h->hint_base_members, h->hint_batch_entries, {0, 0, 0, 0}, h->pending.size()};
             memcpy(v.st, h->stats, sizeof(v.st));
             return v;
         };
@@ -1071,6 +1091,13 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             h->lists_valid = v.lists_valid; h->batch_open = v.batch_open; h->bq_cur = v.bq_cur; h->fc_cur = v.fc_cur;
             h->hint_base_members = v.hb; h->hint_batch_entries = v.he;
             memcpy(h->stats, v.st, sizeof(v.st));
+            // the launches recorded inside the window were gated off (they returned at once): they are neither
+            // launches nor work of the profile
+            for (size_t i = v.n_pending; i < h->pending.size(); ++i) {
+                (void)hipEventDestroy(h->pending[i].a);
+                (void)hipEventDestroy(h->pending[i].b);
+            }
+            if (h->pending.size() > v.n_pending) h->pending.resize(v.n_pending);
         };
         struct GateReset { ~GateReset() { g_gate = Gate{}; } } gate_reset;   // (error returns inside the window)
 
@@ -1154,6 +1181,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     if (it == 0) cur = prev;
     for (int64_t i = 0; i < N; ++i) labels_out[i] = cur[(size_t)i];
     if (iters_run) *iters_run = it;
+    fit_closer.ok = true;
     return CHB_OK;
 }
 
@@ -1230,6 +1258,8 @@ static int hull_indexed(chb_ctx *h, const double *Xdev, int D, int Dp, int64_t n
 {
     if (m_max < 1 || m_max > CHB_MAX_NEIGHBORS) return fail(CHB_EUNSUPPORTED, "m_max must be in [1, 64]");
     if (P <= 0) return CHB_OK;
+    if (m_max > kMaxM && !hull_generic_supported())
+        return fail(CHB_EUNSUPPORTED, "more than 16 hull vertices need 68 KB of LDS per workgroup, which this device does not grant");
     hipStream_t s = h->stream;
     // compact each vertex list (padding may sit anywhere at the ABI) and remember the slots
     std::vector<int> q((size_t)P), hx((size_t)P * m_max, -1), slot((size_t)P * m_max, -1), hn((size_t)P, 0);

@@ -61,7 +61,7 @@ void launch_topm_flagged(const TopmArgs &a, int *flags64, const int *flaglist, c
 
 // ---- two-stage exact selection (prefilter_kernels.hip + rescore in topm_kernels.hip)
 constexpr int kCandCap = 128;   // shortlist capacity per (bin, batch position)
-constexpr int kCandCapU = 32;   // same for the batch's own entries in the fused selection path (m <= 8)
+constexpr int kCandCapU = 32;   // same for the batch's own entries in the fused selection path (m <= 16)
 
 // fp16 shadow data of the shortlist stage (prefilter_kernels.hip explains the quantities).
 // Members of all bins, grouped by bin, every bin padded to a multiple of 32 rows:
@@ -170,7 +170,7 @@ struct QpArgs {
 };
 void launch_hull_qp(const QpArgs &a, hipStream_t s);
 
-// Fused selection + hull distance (m <= 8): per (position, bin) pair the candidates of the shortlist
+// Fused selection + hull distance (m <= 16): per (position, bin) pair the candidates of the shortlist
 // stage (base members + this round's batch entries) are gathered ONCE; their full shifted Gram gives
 // both the squared distances (diagonal) that pick the m nearest and the m x m Gram of the hull QP.
 // Pairs with more than the kernel's candidate capacity, or whose m-th / (m+1)-th candidates are too
@@ -201,6 +201,8 @@ void launch_hull_select_qp(const FusedArgs &a, hipStream_t s);
 // explicit problems: query sample q[p], hull_idx[p][m_max] compacted, hull_cnt[p] vertices
 // 16 < m <= kMaxMGeneric: one wavefront per problem, Gram and the solver's inverse in LDS (slow, see
 // qp_kernels.hip); same argument meaning as launch_hull_qp / launch_hull_qp_indexed
+// false: the current device does not grant the ~68 KB of dynamic LDS per workgroup these kernels need
+bool hull_generic_supported();
 void launch_hull_generic(const QpArgs &a, hipStream_t s);
 void launch_hull_generic_indexed(const double *X, int D, int Dp, const int *q, const int *hull_idx,
                                  const int *hull_cnt, int P, int m_max, int metric, double *dist,

@@ -1884,12 +1884,10 @@ void launch_generic(const QpArgs &a, int nprob, int m, const int *xq, const int 
                     double *xalpha, hipStream_t s)
 {
     if (nprob <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hull_generic_kernel<INDEXED>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GenLds));
-        attr_set = true;
-    }
+    // per launch (cheap, and the attribute is per device: a process may hold contexts on several); whether the
+    // device grants it at all is asked up front by hull_generic_supported()
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hull_generic_kernel<INDEXED>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GenLds));
     hipLaunchKernelGGL((hull_generic_kernel<INDEXED>), dim3(nprob), dim3(64), sizeof(GenLds), s, a, nprob, xq, xhull, xn, m,
                        xdist, xalpha, g_gate);
 }
@@ -1951,6 +1949,16 @@ void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
         hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, true>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
     else
         hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, false>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
+}
+
+bool hull_generic_supported()
+{
+    const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(hull_generic_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GenLds));
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(hull_generic_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GenLds));
+    if (e0 != hipSuccess || e1 != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
 }
 
 void launch_hull_generic(const QpArgs &a, hipStream_t s)

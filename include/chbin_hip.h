@@ -18,6 +18,13 @@
  *   - calls are blocking; a context is not thread-safe (the reference caller is single-threaded).
  *   - there is NO CPU fallback: without a gfx950 device every compute call fails with
  *     CHB_ENODEVICE.
+ *   - environment switches read once by chb_create (none is a tuning knob, none touches an error bound: each
+ *     selects a slower, independently written formulation of the same exact result, for A/B tests):
+ *       CHB_PREFILTER=0     brute-force fp64 selection instead of the fp16 shortlist stage
+ *       CHB_FUSED=0         list-based path (exact rescoring + hull kernel) instead of the fused kernels
+ *       CHB_FUSED_PTR64=1   64-bit row pointers in the m <= 5 fused kernel (what a matrix >= 4 GiB gets)
+ *       CHB_SPECULATE=0     no look-ahead across batches in chb_fit_cluster
+ *       CHB_FORCE_GATHER=1  exchange path of the sharded loop even with one rank
  */
 #ifndef CHBIN_HIP_H
 #define CHBIN_HIP_H

@@ -58,3 +58,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not bad.search(src), (dirpath, f)
+
+
+def test_solve_qp_recognises_the_reference_tuples():
+    """Host logic of the solve_qp seam (no GPU): the argument tuples hull_distance.py:17-33 and :45-55 build are
+    recognised -- the affine form arrives with a ZERO-ROW inequality block, not with None."""
+    import numpy as np
+    from chbin_amd.clustering.solve_qp import _recognise, check_solver
+    m = 4
+    P, q, A, b = 2.0 * np.eye(m), np.zeros(m), np.ones((1, m)), np.ones(1)
+    assert _recognise(P, q, -np.eye(m), np.zeros(m), A, b) == "convex"
+    assert _recognise(P, q, np.zeros(shape=(0, m)), np.zeros(0), A, b) == "affine"
+    assert _recognise(P, q, None, None, A, b) == "affine"
+    assert _recognise(P, q, np.eye(m), np.ones(m), A, b) is None            # a general inequality
+    assert _recognise(P, q, -np.eye(m), np.zeros(m), 2.0 * A, b) is None    # not the sum-to-one row
+    assert _recognise(P, q, None, np.zeros(m), A, b) is None
+    with pytest.raises(NotImplementedError):
+        check_solver("nosuch")

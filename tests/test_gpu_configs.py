@@ -12,7 +12,10 @@ size-independent properties of the reference loop (algorithm.py:43-76):
         the brute-force kernel (CHB_PREFILTER=0) on a sample of contigs under the final labels;
   (iv)  the fused selection + hull-distance kernel and the list-based formulation (CHB_FUSED=0) give the
         same labels for the whole fit, and the speculation statistics stay in the expected range
-        (rounds per batch, hull distances evaluated per needed one, shortlist overflows).
+        (rounds per batch, hull distances evaluated per needed one, shortlist overflows);
+  (v)   the call exactly as bench.py makes it (no min_dist: look-ahead across batches with gated kernels and
+        host-side snapshot / restore) returns the labels, sweep count and change counts of the call that
+        (i)-(iv) pin (want_min_dist=True switches the look-ahead off).
 """
 import os
 
@@ -72,10 +75,13 @@ def test_config1_whole_fit_vs_oracle(O):
         got, its, ch, mind = c.fit_cluster(B, initial, perms, m, 4, want_min_dist=True)
         assert c.counter("fused_enabled") == 1
         st = c.fit_stats()
+        # the call bench.py times: no min_dist => look-ahead across batches (gated kernels, snapshot / restore)
+        got_t, its_t, ch_t = c.fit_cluster(B, initial, perms, m, 4)
     finally:
         c.close()
     assert its == its_o and np.array_equal(ch, ch_o)
     assert np.array_equal(got, want)
+    assert its_t == its_o and np.array_equal(ch_t, ch_o) and np.array_equal(got_t, want)
     assert (got == true).mean() > 0.99
     assert st["hull_needed"] == its * perms.shape[1] * B
     # winning distances of the last sweep against the oracle's sequential replay
@@ -128,6 +134,9 @@ def test_large_configs_full_size(O, idx, N, D, B, S):
         assert c.counter("fused_enabled") == 1
         st = c.fit_stats()
         overflow = c.counter("prefilter_overflow")
+        # the call bench.py times (no min_dist => look-ahead across batches): the whole fit once more
+        got_t, its_t, changed_t = c.fit_cluster(B, initial, perms, m, 4)
+        st_t = c.fit_stats()
         # (iii) two-stage selection == brute force on a sample of contigs under the final labels
         rng = np.random.default_rng(idx)
         q = rng.choice(np.flatnonzero(initial < 0), 256, replace=False)
@@ -135,6 +144,9 @@ def test_large_configs_full_size(O, idx, N, D, B, S):
     finally:
         c.close()
     assert changed[-1] == 0 and its < 4                       # stopped at a fixed point
+    # the look-ahead path returns what the path pinned by the oracle properties below returns
+    assert its_t == its and np.array_equal(changed_t, changed) and np.array_equal(got_t, got)
+    assert st_t["hull_needed"] == st["hull_needed"] and st_t["batches"] == st["batches"]
     assert np.all(got >= 0)
     assert np.array_equal(got[initial >= 0], initial[initial >= 0])   # seeds never move
     assert (got == true).mean() > 0.99

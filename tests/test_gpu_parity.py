@@ -327,6 +327,62 @@ def test_full_size_fixed_point_property(ctx, O):
         lab_j, md = O.sweep(X, B, got, np.array([j]), m)
         assert lab_j[j] == got[j]
         assert abs(md[0] - mind[j]) < QP_TOL
+    # the call exactly as bench.py times it (no min_dist => look-ahead across batches: gated kernels, host-side
+    # snapshot / restore) returns the fit pinned above; the first sweep alone equals sweep 1 of that fit
+    got_t, its_t, changed_t = ctx.fit_cluster(B, initial, perms, m, 4)
+    st_t = ctx.fit_stats()
+    assert its_t == its and np.array_equal(changed_t, changed) and np.array_equal(got_t, got)
+    assert st_t["batches"] >= 13 * its                        # every sweep ran its 13+ gated batches
+    one, _, ch1, mind1 = ctx.fit_cluster(B, initial, perms[:1], m, 1, want_min_dist=True)
+    assert np.array_equal(first, one) and ch1[0] == changed[0]
+
+
+def _spec_off_ctx():
+    from chbin_amd import _lib
+    old = os.environ.get("CHB_SPECULATE")
+    os.environ["CHB_SPECULATE"] = "0"
+    try:
+        return _lib.Context(0)
+    finally:
+        if old is None:
+            del os.environ["CHB_SPECULATE"]
+        else:
+            os.environ["CHB_SPECULATE"] = old
+
+
+def test_lookahead_on_overlapping_bins_full_size(ctx, O):
+    """N=100k on overlapping bins (mix 0.3 / sigma 4.5e-3: ~3.5 rounds per batch, so the look-ahead of
+    chb_fit_cluster keeps failing, restoring the host-side batch state and re-enqueueing the next batch).  The
+    default context must return exactly what a context without look-ahead (CHB_SPECULATE=0) returns, and the
+    oracle replays a prefix of sweep 1 and checks the fixed-point property of sweep 2's visits on a sample."""
+    N, D, B, m = 100_000, 136, 64, 5
+    X, initial, true = _synth(N, D, B, seed=0, mix=0.3, sigma=4.5e-3)
+    perms = _perms(initial, 2)
+    ctx.set_samples(X)
+    got, its, changed = ctx.fit_cluster(B, initial, perms, m, 2)
+    st = ctx.fit_stats()
+    assert st["rounds"] > 1.5 * st["batches"]                 # rounds did repeat: the restore path ran
+    plain = _spec_off_ctx()
+    try:
+        plain.set_samples(X)
+        want, its_w, changed_w, mind = plain.fit_cluster(B, initial, perms, m, 2, want_min_dist=True)
+        st_w = plain.fit_stats()
+    finally:
+        plain.close()
+    assert its == its_w and np.array_equal(changed, changed_w) and np.array_equal(got, want)
+    assert st["hull_needed"] == st_w["hull_needed"]
+    n_pref = 40
+    first, _, _ = ctx.fit_cluster(B, initial, perms[:1], m, 1)
+    lab_o, _ = O.sweep(X, B, initial, perms[0][:n_pref], m)
+    assert np.array_equal(first[perms[0][:n_pref]], lab_o[perms[0][:n_pref]])
+    # the LAST contigs of the last sweep were visited when every other label was already final
+    tail = perms[its - 1][-24:]
+    for k, j in enumerate(tail):
+        lab_now = got.copy()
+        lab_now[tail[k:]] = first[tail[k:]] if its == 2 else initial[tail[k:]]   # labels at j's visit
+        lab_j, md = O.sweep(X, B, lab_now, np.array([j]), m)
+        assert lab_j[j] == got[j]
+        assert abs(md[0] - mind[j]) < QP_TOL
 
 
 # ------------------------------------------------------------------ two-stage selection
@@ -588,9 +644,15 @@ def test_solve_qp_reference_forms(ctx, O, golden_dir):
             assert abs(np.linalg.norm(alpha @ P - x) - d_gi) < 1e-9
             assert abs(np.linalg.norm(alpha @ P - x) - g["dist_with_oracle_gi"][k]) < 1e-9
         # equality-only form (affine hull, hull_distance.py:48-64)
-        beta = clustering.solve_qp(mat_p, vec_q, None, None, np.ones((1, m)), np.ones(1), solver="quadprog")
-        assert abs(beta.sum() - 1) < 1e-10
-        assert abs(np.linalg.norm(beta @ P - x) - O.affine_hull_distance(x, P)) < 1e-9
+        # ... with the tuple hull_distance.py:45-55 really builds (a ZERO-ROW inequality block), and with None / None
+        from chbin_amd._lib import default_context
+        default_context().set_metric("affine")       # a caller's metric must survive the call
+        for gz, hz in ((np.zeros(shape=(0, m)), np.zeros(0)), (None, None)):
+            beta = clustering.solve_qp(mat_p, vec_q, gz, hz, np.ones((1, m)), np.ones(1), solver="quadprog")
+            assert abs(beta.sum() - 1) < 1e-10
+            assert abs(np.linalg.norm(beta @ P - x) - O.affine_hull_distance(x, P)) < 1e-9
+        assert default_context().get_metric() == "affine"
+        default_context().set_metric("convex")
     with pytest.raises(NotImplementedError):
         clustering.solve_qp(np.eye(3), np.zeros(3), -np.eye(3), np.zeros(3), np.ones((1, 3)), np.ones(1), solver="nosuch")
     with pytest.raises(NotImplementedError):   # not a form the reference poses
@@ -782,3 +844,27 @@ def test_fused_kernel_64bit_row_pointers(O):
     env = dict(os.environ, CHB_FUSED_PTR64="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_fit_cluster_rejects_bad_permutations(ctx, O):
+    """C ABI: an out-of-range entry in ANY sweep's permutation is reported before anything runs; a sweep that lists a
+    sample twice is rejected; the context stays usable and returns the oracle's labels afterwards."""
+    from chbin_amd import _lib
+    X, initial, _ = _synth(600, 40, 4, seed=2, sigma=8e-3, mix=0.4, n_seed=6)
+    perms = _perms(initial, 3)
+    ctx.set_samples(X)
+    bad = perms.copy()
+    bad[2, 7] = len(X)                       # last sweep: would only be reached after two sweeps have run
+    with pytest.raises(_lib.ChbError, match="out of range"):
+        ctx.fit_cluster(4, initial, bad, 5, 3)
+    bad = perms.copy()
+    bad[0, 5] = -1
+    with pytest.raises(_lib.ChbError, match="out of range"):
+        ctx.fit_cluster(4, initial, bad, 5, 3)
+    dup = perms.copy()
+    dup[0, 11] = dup[0, 3]
+    with pytest.raises(_lib.ChbError, match="twice"):
+        ctx.fit_cluster(4, initial, dup, 5, 3)
+    want, its_o, _ = O.fit_cluster(X, 4, initial, perms, 5, 3)
+    got, its, _ = ctx.fit_cluster(4, initial, perms, 5, 3)
+    assert its == its_o and np.array_equal(got, want)

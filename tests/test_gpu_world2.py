@@ -36,7 +36,7 @@ res = {}
 for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate([
         (900, 136, 8, 5, 4, 6e-3, 0.6, 8, 200),        # overlapping bins: several rounds per batch
         (3000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 0),   # SURVEY 8(d) generator
-        (700, 40, 6, 15, 3, 9e-3, 0.5, 20, 150)]):     # m = 15: list-based path
+        (700, 40, 6, 15, 3, 9e-3, 0.5, 20, 150)]):     # m = 15: fused 16-lane kernel (hull_select_qp16_kernel)
     X, initial, _ = synth.make_synthetic(N, D, B, seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
     perms = synth.draw_permutations(initial, iters, seed=0)
     ctx = _lib.Context(0)
