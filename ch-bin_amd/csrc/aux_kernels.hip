@@ -142,55 +142,12 @@ __global__ __launch_bounds__(256) void fill_base_kernel(const int *labels, const
 __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev, const int *lab_old, const int *bq,
                                                             int K, int B, int *bin_ptr, int *pad_ptr, int *memb_id,
                                                             int *memb_code, int *first_change, int *n_slow, int *nflag,
-                                                            int *ord, int ord_lo, int ord_hi, Gate gate)
+                                                            Gate gate)
 {
     CHB_GATE(gate);
-    extern __shared__ int sh[];   // [B] counts -> cursors, [1024] scan partials x 2, [B + 1] counts of the work order
+    extern __shared__ int sh[];   // [B] counts -> cursors, [1024] scan partials x 2
     int *cnt = sh, *part = sh + B, *ppart = part + 1024;
     const int tid = threadIdx.x;
-    if (ord != nullptr) {
-        // work order of the fused hull kernel: the positions [ord_lo, ord_hi) grouped by their label of the
-        // previous round (unlabelled ones last), so that a wavefront's pairs share their candidate rows
-        int *oc = ppart + 1024;   // [B + 1]
-        for (int b = tid; b <= B; b += 1024) oc[b] = 0;
-        __syncthreads();
-        for (int i = ord_lo + tid; i < ord_hi; i += 1024) {
-            const int a = lab_prev[i];
-            atomicAdd(&oc[(a >= 0 && a < B) ? a : B], 1);
-        }
-        __syncthreads();
-        const int per_o = (B + 1 + 1023) / 1024;
-        const int o0 = min(B + 1, tid * per_o), o1 = min(B + 1, o0 + per_o);
-        int so = 0;
-        for (int b = o0; b < o1; ++b) so += oc[b];
-        part[tid] = so;
-        __syncthreads();
-        if (tid < 64) {
-            int loc = 0;
-            for (int i = 0; i < 16; ++i) loc += part[16 * tid + i];
-            int inc = loc;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(inc, off, 64);
-                if (tid >= off) inc += o;
-            }
-            int run = inc - loc;
-            for (int i = 0; i < 16; ++i) {
-                const int v = part[16 * tid + i];
-                part[16 * tid + i] = run;
-                run += v;
-            }
-        }
-        __syncthreads();
-        int run_o = part[tid];
-        for (int b = o0; b < o1; ++b) { const int c = oc[b]; oc[b] = run_o; run_o += c; }
-        __syncthreads();
-        for (int i = ord_lo + tid; i < ord_hi; i += 1024) {
-            const int a = lab_prev[i];
-            ord[atomicAdd(&oc[(a >= 0 && a < B) ? a : B], 1)] = i;
-        }
-        __syncthreads();
-    }
     if (tid == 0) {   // the round's scalars
         if (first_change) *first_change = K;
         if (n_slow) *n_slow = 0;
@@ -579,12 +536,11 @@ void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int
 
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
-                         int *first_change, int *n_slow, int *nflag, hipStream_t s, int *ord, int ord_lo, int ord_hi)
+                         int *first_change, int *n_slow, int *nflag, hipStream_t s)
 {
     (void)cnt; (void)cursor;   // (scratch of the former three-kernel form)
-    hipLaunchKernelGGL(bucket_batch_kernel, dim3(1), dim3(1024), sizeof(int) * (2 * (size_t)B + 2049), s, lab_prev,
-                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow, nflag, ord, ord_lo,
-                       ord_hi, g_gate);
+    hipLaunchKernelGGL(bucket_batch_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 2048), s, lab_prev,
+                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow, nflag, g_gate);
 }
 
 void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int pos_begin,

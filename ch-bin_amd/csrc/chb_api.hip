@@ -225,10 +225,9 @@ struct chb_ctx {
     // fused selection + hull distance (m <= 16): batch-entry candidates of this / the previous round,
     // the base stage's tau (bound of the m-th nearest distance), the exact path's work list
     bool fused = false, allow_fused = true;
-    bool group_order = true;    // CHB_GROUP_ORDER=0: position-major work order in the m <= 5 fused kernel (A/B tests)
     bool pf_fit = false;        // this fit uses the shortlist stage (use_prefilter, D <= 160, m <= 16)
     bool lists_valid = false;   // the open batch was started with need_lists (chb_topm_per_bin)
-    DevBuf<int> candu[2], candu_cnt[2], slow, n_slow, ord;
+    DevBuf<int> candu[2], candu_cnt[2], slow, n_slow;
     DevBuf<float> tau;
     // scratch for the indexed / explicit-point entry points
     DevBuf<int> xq, xhull, xcnt;
@@ -367,7 +366,6 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
             }
             HIPCHK(h->slow.ensure(K * B));
             HIPCHK(h->n_slow.ensure(1));
-            HIPCHK(h->ord.ensure(K));
             HIPCHK(h->tau.ensure(K * B));
         }
     }
@@ -507,15 +505,12 @@ int batch_round_dev(chb_ctx *h, int active)
     const int lo = std::max(active, h->q_lo), hi = h->q_hi;
     if (hi <= lo) launch_fill_i32(h->fc_cur, h->K, 1, s);
     const bool fusedp = h->fused && h->lists_valid == false;
-    // m <= 5 fused kernel: positions grouped by their label of the previous round, 64 of them x one bin per wavefront
-    const bool grouped = fusedp && h->m <= 5 && h->group_order;
     if (hi > lo) {
         {
             Timed t(h, "bucket", (double)h->K);
             launch_bucket_batch(h->lab_prev.p, h->lab_old.p, h->bq_cur, h->K, h->B, h->cnt2.p,
                                 h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, h->pk2.pad_ptr.p,
-                                h->fc_cur, fusedp ? h->n_slow.p : nullptr, h->nflag.p, s,
-                                grouped ? h->ord.p : nullptr, lo, hi);
+                                h->fc_cur, fusedp ? h->n_slow.p : nullptr, h->nflag.p, s);
         }
         TopmArgs a{};
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = lo; a.pos_end = hi;
@@ -558,7 +553,6 @@ int batch_round_dev(chb_ctx *h, int active)
             f.candu = h->candu[cur].p; f.candu_cnt = h->candu_cnt[cur].p;
             if (h->round_in_batch > 0) { f.candp = h->candu[cur ^ 1].p; f.candp_cnt = h->candu_cnt[cur ^ 1].p; }
             f.dist = h->dist.p; f.metric = h->metric; f.slow = h->slow.p; f.n_slow = h->n_slow.p;
-            f.ord = grouped ? h->ord.p : nullptr;
             {
                 Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
                 launch_hull_select_qp(f, s);
@@ -717,7 +711,6 @@ int chb_create(int device_id, chb_ctx **out)
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->fc_host, 64, hipHostMallocDefault);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->fc_event[i], hipEventDisableTiming);
     if (const char *ev = getenv("CHB_SPECULATE")) h->speculate = atoi(ev) != 0;
-    if (const char *ev = getenv("CHB_GROUP_ORDER")) h->group_order = atoi(ev) != 0;
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
     return CHB_OK;
@@ -742,7 +735,7 @@ int chb_destroy(chb_ctx *h)
     h->centers.release();
     h->active.release(); h->n_active.release(); h->act_blk.release();
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
-    h->slow.release(); h->n_slow.release(); h->tau.release(); h->ord.release();
+    h->slow.release(); h->n_slow.release(); h->tau.release();
     (void)hipStreamDestroy(h->stream);
     if (h->fc_host) (void)hipHostFree(h->fc_host);
     for (int i = 0; i < 2; ++i) if (h->fc_event[i]) (void)hipEventDestroy(h->fc_event[i]);

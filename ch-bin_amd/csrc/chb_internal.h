@@ -191,11 +191,6 @@ struct FusedArgs {
     int metric;
     int *slow;        // pair indices (pos - pos_begin) * B + bin
     int *n_slow;      // zeroed by the caller
-    // work order (m <= 5 kernel; nullptr: position-major): the positions [pos_begin, pos_end) grouped by their
-    // label of the previous round.  A wavefront then takes 64 consecutive entries of `ord` against ONE bin: its
-    // pairs mostly draw their candidates from the same few members of that bin (the ones extreme towards the
-    // queries' own bin), so the row gather hits L1 / L2 instead of the Infinity Cache.
-    const int *ord = nullptr;
 };
 // false: not supported by the fused kernels (caller uses the list-based path): m <= 16, padded rows of at most
 // kFusedMaxDp doubles (the 16-lane kernel stages the query row in LDS)
@@ -232,9 +227,7 @@ void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int
 // (also starts the round's scalars: *first_change = K, *n_slow = 0, *nflag = 0 where the pointers are non-null)
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
-                         int *first_change, int *n_slow, int *nflag, hipStream_t s, int *ord = nullptr, int ord_lo = 0,
-                         int ord_hi = 0);
-// (ord, optional: the positions [ord_lo, ord_hi) grouped by lab_prev -- the work order of the fused hull kernel)
+                         int *first_change, int *n_slow, int *nflag, hipStream_t s);
 // first position in [p0,K) whose label changed (atomicMin into *first_change)
 void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,
                          hipStream_t s);

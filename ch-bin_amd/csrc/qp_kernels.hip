@@ -539,23 +539,6 @@ __device__ __forceinline__ double diag_rows8(const double *X, int Dp, int qid, i
     return reduce_scatter16(acc, l16);
 }
 
-// work item g -> (batch position, bin).  Natural order: position-major.  With a.ord: wavefront tile t = g / 64
-// takes the 64 consecutive entries [64 (t / B), +64) of the grouped position list against bin t % B.
-__device__ __forceinline__ bool fused_pair_of(const FusedArgs &a, int g, int nprob, int &pos, int &c)
-{
-    if (a.ord == nullptr) {
-        pos = a.pos_begin + g / a.B;
-        c = g - (g / a.B) * a.B;
-        return g < nprob;
-    }
-    const int t = g >> 6, grp64 = t / a.B;
-    c = t - grp64 * a.B;
-    const int r = grp64 * 64 + (g & 63);
-    const bool ok = g < nprob && r < a.pos_end - a.pos_begin;
-    pos = ok ? a.ord[r] : a.pos_begin;
-    return ok;
-}
-
 template <int M, int C, int WAVES, bool OFF32>
 __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kernel(FusedArgs a, int nprob, Gate gate)
 {
@@ -578,22 +561,18 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
     const int m = a.m;
     if (threadIdx.x == 0) sSlowN = 0;
     __syncthreads();
-    // consecutive workgroups alternate over the 8 XCDs: with a grouped work order every XCD gets one contiguous
-    // range of work (the same queries' bins, and neighbouring queries of the same guessed bin, share an L2)
-    int vblock = blockIdx.x;
-    if (a.ord != nullptr) vblock = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    const int g0 = (vblock * WAVES + w) * 64;
+    const int g0 = (blockIdx.x * WAVES + w) * 64;
     unsigned long long slowmask = 0ull;        // problems of this wavefront left to the exact path
 
     if (g0 < nprob) {
         // ---- classification, one problem per lane
         const int g = g0 + lane;
-        int pos, c;
-        const bool valid = fused_pair_of(a, g, nprob, pos, c);
+        const bool valid = g < nprob;
         int nb = 0, nu = 0, qid = 0;
         size_t slot = 0;
         bool changed = valid;
         if (valid) {
+            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
             qid = a.bq[pos];
             slot = (size_t)c * a.Kcap + pos;
             nb = a.cand_cnt[slot];
@@ -646,7 +625,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             const int n_g = has ? n_s : 0;
             const int nb_g = __shfl(nb, pl, 64);
             const int qid_g = __shfl(qid, pl, 64);
-            const size_t slot_g = (size_t)__shfl(c, pl, 64) * a.Kcap + (size_t)__shfl(pos, pl, 64);
+            const int gg = g0 + pl;
+            const size_t slot_g = (size_t)(gg - (gg / a.B) * a.B) * a.Kcap + (a.pos_begin + gg / a.B);
             int idm = -1;
             if (l16 < n_g)
                 idm = l16 < nb_g ? a.cand[slot_g * kCandCap + l16] : a.candu[slot_g * kCandCapU + (l16 - nb_g)];
@@ -724,7 +704,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             const int n_g = has ? n_s : 0;
             const int nb_g = __shfl(nb, pl, 64);
             const int qid_g = __shfl(qid, pl, 64);
-            const size_t slot_g = (size_t)__shfl(c, pl, 64) * a.Kcap + (size_t)__shfl(pos, pl, 64);
+            const int gg = g0 + pl;
+            const size_t slot_g = (size_t)(gg - (gg / a.B) * a.B) * a.Kcap + (a.pos_begin + gg / a.B);
             int idm = -1;
             if (l16 < n_g)
                 idm = l16 < nb_g ? a.cand[slot_g * kCandCap + l16] : a.candu[slot_g * kCandCapU + (l16 - nb_g)];
@@ -782,10 +763,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
     // ---- phase 2: one problem per lane
     {
         const int g = g0 + lane;
-        int pos, c;
-        const bool valid = g0 < nprob && fused_pair_of(a, g, nprob, pos, c);
-        const int n = valid ? sN[w][lane] : -1;
-        if (valid && n != -1 && !((sm >> lane) & 1ull)) {   // else: distance kept, or written by the exact path
+        const int n = g < nprob ? sN[w][lane] : -1;
+        if (g < nprob && n != -1 && !((sm >> lane) & 1ull)) {   // else: distance kept, or written by the exact path
             double Q[NPM];
 #pragma unroll
             for (int e = 0; e < NPM; ++e) Q[e] = sQ[w][e][lane];
@@ -797,6 +776,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
                 const double val = a.metric == 0 ? min_norm_point<M>(Q, n, alpha) : affine_min_norm<M>(Q, n, alpha);
                 dist = sqrt(fmax(val, 0.0));
             }
+            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
             a.dist[(size_t)pos * a.B + c] = dist;
         }
     }
@@ -812,9 +792,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
     wbase = __shfl(wbase, 0, 64) + sSlowBase;
     if (nsl > 0 && ((sm >> lane) & 1ull)) {
         const int before = __popcll(sm & ((1ull << lane) - 1ull));
-        int pos, c;
-        (void)fused_pair_of(a, g0 + lane, nprob, pos, c);
-        a.slow[wbase + before] = (pos - a.pos_begin) * a.B + c;   // (position-major pair index, whatever the work order)
+        a.slow[wbase + before] = g0 + lane;
     }
 }
 
@@ -1963,16 +1941,14 @@ void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
                            nprob, g_gate);
         return;
     }
-    int np5 = nprob;
-    if (a.ord != nullptr) np5 = ((a.pos_end - a.pos_begin + 63) / 64) * a.B * 64;   // whole 64-position groups x bins
-    const int grid = ((np5 + 64 * WV - 1) / (64 * WV) + 7) / 8 * 8;                // (whole rounds over the 8 XCDs)
+    const int grid = (nprob + 64 * WV - 1) / (64 * WV);
     // (rows as 32-bit byte offsets while the sample matrix is smaller than 4 GiB: see gram_rows; CHB_FUSED_PTR64=1
     //  selects the 64-bit-pointer instantiation regardless, for the tests)
     static const bool ptr64 = getenv("CHB_FUSED_PTR64") != nullptr && atoi(getenv("CHB_FUSED_PTR64")) != 0;
     if (!ptr64 && (unsigned long long)a.n_samples * (unsigned long long)a.Dp * 8ull < (1ull << 32))
-        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, true>), dim3(grid), dim3(64 * WV), 0, s, a, np5, g_gate);
+        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, true>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
     else
-        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, false>), dim3(grid), dim3(64 * WV), 0, s, a, np5, g_gate);
+        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, false>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
 }
 
 bool hull_generic_supported()
