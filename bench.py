@@ -30,8 +30,34 @@ sys.path.insert(0, ROOT)
 
 # MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-L2_GATHER_PEAK_GBS = 17800.0   # indexed-row gather served by the XCDs' L2: 16.8-18.8 TB/s chip-wide
 F16_PEAK_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak
+TRAFFIC_FILE = "r03_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this round (tools/traffic_from_pmc.py)
+
+
+def gather_ceiling_gbs(table_mb):
+    """MI355X_MICROARCH.md, 'Indexed rows: gather into LDS', chip-wide, by the size of the table the rows come from:
+    2,048 shared rows (2.3 MB, one XCD's L2) 16.8-18.8 TB/s; 38 MB (Infinity Cache) 8.6; 151 MB 7.4-7.9; 1.2 GB swept
+    (HBM) 6.0-6.1.  Piecewise-linear in between (mid-points of the quoted ranges)."""
+    pts = [(2.3, 17800.0), (38.0, 8600.0), (151.0, 7650.0), (1200.0, 6050.0)]
+    if table_mb <= pts[0][0]:
+        return pts[0][1]
+    for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+        if table_mb <= x1:
+            return y0 + (y1 - y0) * (table_mb - x0) / (x1 - x0)
+    return pts[-1][1]
+
+
+def kernel_source_stamp():
+    """sha256 over the kernel sources: profiles/*_traffic.json carries the stamp of the build it was measured on, and
+    its numbers are only quoted while the sources are still the same."""
+    import glob
+    import hashlib
+    hh = hashlib.sha256()
+    src = os.path.join(ROOT, "ch-bin_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+        hh.update(os.path.basename(f).encode())
+        hh.update(open(f, "rb").read())
+    return hh.hexdigest()[:16]
 FP64_PEAK_TFLOPS = 78.6        # fp64 vector == matrix peak (AMD public spec; the local guide lists no fp64 row)
 
 # BASELINE.json configs: index -> (contigs, dim, bins)
@@ -197,16 +223,22 @@ def main():
         fused = ctx.counter("fused_enabled") == 1
         bytes_qp = 8.0 * (m * D + D / B + 1)      # no-reuse gather model per hull distance
         x_mb = N * ((D + 7) // 8 * 8) * 8 / 1e6
-        gather_note = (f"gather of fp64 sample rows out of the resident matrix ({x_mb:.0f} MB: served by the XCDs' L2 and the "
-                       "256 MiB Infinity Cache, not by HBM); peak = MI355X_MICROARCH.md's indexed-row gather ceiling for "
-                       "L2-served rows (16.8-18.8 TB/s), frac_of_hbm_peak = the same bytes against the 8 TB/s HBM spec")
+        gather_peak = gather_ceiling_gbs(x_mb)
+        gather_note = ("achieved = ALGORITHMIC bytes of SURVEY 8(d)'s no-reuse gather model (every candidate row counted as "
+                       f"read from memory) / the measured launch time, peak = the 8 TB/s HBM spec.  The rows come out of a {x_mb:.0f} MB "
+                       "resident matrix, i.e. from the XCDs' L2 and the 256 MiB Infinity Cache rather than HBM: `traffic` is what "
+                       "really crossed the fabric, and `gather_ceiling` is MI355X_MICROARCH.md's indexed-row gather rate for a "
+                       "table of this size")
 
         def gather_entry(name, p, bytes_unit, unit_name, note):
             ach = p["work"] * bytes_unit / (p["ms"] * 1e-3) / 1e9
-            return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / L2_GATHER_PEAK_GBS, "frac_of_hbm_peak": ach / HBM_PEAK_GBS, "traffic": None,
+            return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "gather_ceiling": {"peak": gather_peak, "unit": "GB/s", "frac": ach / gather_peak,
+                                       "table_mb": x_mb},
                     "avg_launch_ms": p["ms"] / p["launches"], "launches": p["launches"], "total_ms": p["ms"],
                     unit_name + "_per_s_kernel": p["work"] / (p["ms"] * 1e-3), "bytes_per_" + unit_name: bytes_unit,
+                    "algorithmic_bytes_per_launch": p["work"] * bytes_unit / p["launches"],
                     "note": note}
 
         def kernel_entries(pr):
@@ -256,17 +288,26 @@ def main():
             k["ms_per_step"] = k["total_ms"] / prof_steps
         # HBM-side traffic per launch from the committed PMC profile of this round (separate rocprofv3 --pmc
         # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null when unavailable
+        # (quoted only while the kernel sources are byte-identical to the build the counters were collected on, and
+        #  only for the configuration they were collected on; otherwise null)
         traffic = {}
+        traffic_note = None
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))["kernels"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+            tr = tj["kernels"]
             tmap = {"prefilter": "shortlist_kernel<5, false, 9>", "hull_qp": "hull_select_qp_kernel<5, 7, 4, true>",
-                    "prefilter_update": "shortlist_kernel<1, true, 9>", "query_norms": "query_norms_kernel"}
-            if (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist and fused:
+                    "prefilter_update": "shortlist_kernel<1, true, 9>"}
+            stamp = kernel_source_stamp()
+            if tj.get("kernel_source_stamp") != stamp:
+                traffic_note = (f"profiles/{TRAFFIC_FILE} was measured on kernel sources {tj.get('kernel_source_stamp')}, "
+                                f"this build is {stamp}: not quoted")
+            elif (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist and fused:
                 for name, src in tmap.items():
                     if src in tr:
-                        traffic[name] = (tr[src]["traffic_bytes_per_launch"], "profiles/r02_traffic.json (" + src + ")")
-        except Exception:  # noqa: BLE001
-            pass
+                        traffic[name] = (tr[src]["traffic_bytes_per_launch"],
+                                         f"profiles/{TRAFFIC_FILE} ({src}; kernel sources {stamp})")
+        except Exception as e:  # noqa: BLE001
+            traffic_note = f"no traffic file ({e})"
         for k in kern:
             if k["kernel"] in traffic:
                 k["traffic"], k["traffic_source"] = traffic[k["kernel"]]
@@ -282,6 +323,8 @@ def main():
             roofline["measured"] = "HIP events on the library's stream inside the timed steps"
             if roofline["kernel"] in traffic:
                 roofline["traffic"], roofline["traffic_source"] = traffic[roofline["kernel"]]
+            elif traffic_note:
+                roofline["traffic_note"] = traffic_note
             if len(timed) > 1:
                 o = timed[1]
                 roofline["runner_up"] = {"kernel": o["kernel"], "ms_per_step": o["total_ms"] / max(args.steps, 1),
@@ -325,15 +368,31 @@ def main():
             # contigs are evaluated independently against the frozen seed-state labels, so this times
             # the per-(contig, bin) work of a sweep in parallel; it is not itself a sequential sweep
             try:
-                nthr = max(1, min(len(os.sched_getaffinity(0)), 16))   # the GPU box grants ~16 cores per GPU
+                affinity = len(os.sched_getaffinity(0))
             except AttributeError:
-                nthr = max(1, min(os.cpu_count() or 1, 16))
+                affinity = os.cpu_count() or 1
+            nthr = max(1, min(affinity, 16))   # a one-GPU box's CPU share is 16 cores, whatever the host has
+            cpu["affinity_cpus"] = affinity
+            # parity of the TIMED configuration beyond the prefix: the end-to-end fit above ran exactly like the timed
+            # steps (look-ahead across batches on); once it stopped at a sweep that changed nothing, every movable
+            # contig's label must be the strict-'>' argmin of its hull distances given everyone else's final label
+            # (algorithm.py:46-60) -- checked by the oracle on a random sample of the final labels
+            if e2e is not None and e2e["changed_per_sweep"] and e2e["changed_per_sweep"][-1] == 0:
+                rng = np.random.default_rng(7)
+                fp_ids = rng.choice(np.flatnonzero(initial < 0), min(384, n_move), replace=False)
+                bb_o, _ = O.eval_frozen_mt(X, B, lab_full, fp_ids, m, nthr)
+                if not np.array_equal(bb_o, lab_full[fp_ids]):
+                    raise SystemExit("PARITY FAILURE: final labels of the end-to-end fit are not a fixed point of the "
+                                     "reference sweep on the oracle's sample")
+                cpu["fixed_point_check"] = (f"{len(fp_ids)} random movable contigs of the converged end-to-end fit: label == "
+                                            "oracle argmin over all bins given the other final labels")
             if nthr > 1:
                 ids_mt = perms[0][:min(ns * nthr, n_move)]
                 t3 = time.perf_counter()
                 O.eval_frozen_mt(X, B, initial, ids_mt, m, nthr)
                 mdt = time.perf_counter() - t3
-                cpu["all_cores"] = {"value": len(ids_mt) * B / mdt, "unit": "QP/s", "cores": nthr, "kind": "port",
+                cpu["multi_core"] = {"value": len(ids_mt) * B / mdt, "unit": "QP/s", "cores": nthr, "kind": "port",
+                                     "cores_note": f"{nthr} threads = this box's CPU share (affinity {affinity}, host {os.cpu_count()})",
                                     "sample": f"{len(ids_mt)} contigs x all {B} bins against the full N={N}, frozen "
                                               f"seed-state labels, OpenMP over contigs (chbo_eval_frozen_mt, {mdt:.1f} s)"}
 

@@ -845,8 +845,18 @@ int chb_batch_begin(chb_ctx *h, const int64_t *perm_slice, int64_t K, int64_t q_
     if (K <= 0 || K > (1 << 24) || q_lo < 0 || q_hi > K || q_lo > q_hi)
         return fail(CHB_EINVAL, "bad batch geometry");
     HIPCHK(hipSetDevice(h->dev));
-    for (int64_t i = 0; i < K; ++i)
-        if (perm_slice[i] < 0 || perm_slice[i] >= h->N) return fail(CHB_EINVAL, "perm entry out of range");
+    {
+        // (the batch start counts every labelled sample and subtracts the batch's own entries: a sample listed twice
+        //  would be subtracted twice)
+        std::vector<uint64_t> seen((size_t)(h->N + 63) / 64, 0);
+        for (int64_t i = 0; i < K; ++i) {
+            const int64_t v = perm_slice[i];
+            if (v < 0 || v >= h->N) return fail(CHB_EINVAL, "perm entry out of range");
+            uint64_t &wd = seen[(size_t)(v >> 6)];
+            if (wd & (1ull << (v & 63))) return fail(CHB_EINVAL, "a batch lists a sample twice");
+            wd |= 1ull << (v & 63);
+        }
+    }
     if ((int)K > h->Kcap) { int rc = ensure_batch_buffers(h, (int)K); if (rc) return rc; }
     std::vector<int> v = to_i32(perm_slice, (size_t)K);
     h->bq_cur = h->bq.p;

@@ -332,7 +332,7 @@ def test_full_size_fixed_point_property(ctx, O):
     got_t, its_t, changed_t = ctx.fit_cluster(B, initial, perms, m, 4)
     st_t = ctx.fit_stats()
     assert its_t == its and np.array_equal(changed_t, changed) and np.array_equal(got_t, got)
-    assert st_t["batches"] >= 13 * its                        # every sweep ran its 13+ gated batches
+    assert st_t["batches"] >= 12 * its                        # every sweep ran its 12-13 gated batches
     one, _, ch1, mind1 = ctx.fit_cluster(B, initial, perms[:1], m, 1, want_min_dist=True)
     assert np.array_equal(first, one) and ch1[0] == changed[0]
 

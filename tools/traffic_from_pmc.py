@@ -9,8 +9,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_stamp  # noqa: E402  (bench.py quotes the table only for byte-identical kernel sources)
 
 src, prefix = sys.argv[1], sys.argv[2]
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -38,5 +42,6 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
                      "bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-e2e; FETCH_SIZE doubled per "
                      "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); fabric-side "
                      "counters, Infinity-Cache hits included",
+           "kernel_source_stamp": kernel_source_stamp(),
            "kernels": kern}, open(prefix + "_traffic.json", "w"), indent=1)
 print("kernels:", ", ".join(kern))
