@@ -142,12 +142,14 @@ __global__ __launch_bounds__(256) void fill_base_kernel(const int *labels, const
 __global__ __launch_bounds__(1024) void bucket_batch_kernel(const int *lab_prev, const int *lab_old, const int *bq,
                                                             int K, int B, int *bin_ptr, int *pad_ptr, int *memb_id,
                                                             int *memb_code, int *first_change, int *n_slow, int *nflag,
-                                                            Gate gate)
+                                                            float4 *bb_zero, Gate gate)
 {
     CHB_GATE(gate);
     extern __shared__ int sh[];   // [B] counts -> cursors, [1024] scan partials x 2
     int *cnt = sh, *part = sh + B, *ppart = part + 1024;
     const int tid = threadIdx.x;
+    if (bb_zero != nullptr)   // (the pack kernel of the batch's own entries accumulates the per-bin bounds into it)
+        for (int b = tid; b < B; b += 1024) bb_zero[b] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid == 0) {   // the round's scalars
         if (first_change) *first_change = K;
         if (n_slow) *n_slow = 0;
@@ -536,11 +538,12 @@ void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int
 
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
-                         int *first_change, int *n_slow, int *nflag, hipStream_t s)
+                         int *first_change, int *n_slow, int *nflag, hipStream_t s, void *bb_zero)
 {
     (void)cnt; (void)cursor;   // (scratch of the former three-kernel form)
     hipLaunchKernelGGL(bucket_batch_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 2048), s, lab_prev,
-                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow, nflag, g_gate);
+                       lab_old, bq, K, B, bin_ptr, pad_ptr, memb_id, memb_code, first_change, n_slow, nflag,
+                       reinterpret_cast<float4 *>(bb_zero), g_gate);
 }
 
 void launch_argmin(const double *dist, const int *lab_old, int *lab_prev, int pos_begin,

@@ -449,14 +449,11 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         (void)nq64;   // (flags64 is all zero here: launch_topm_flagged clears what it serves)
         if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
         {
-            Timed t(h, "query_norms", (double)(q_hi - q_lo) * h->B);
-            launch_query_norms(h->X.p, h->D, h->Dp, h->bq_cur, q_lo, q_hi, h->B, h->Kcap, h->centers.p,
-                               h->shadow_scale, h->qn.p, s);
-        }
-        // the members' shadow rows (relative to their bin's centre) gathered into padded CSR order
-        {
+            // the members' shadow rows (relative to their bin's centre) gathered into padded CSR order, the per-bin
+            // bounds, and the batch's query-to-centre norms: one launch
             Timed t(h, "bucket", 0.0);
-            launch_pack_rows(h->Zs.p, h->ms.p, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->pk.view(), s);
+            launch_pack_build(h->Zs.p, h->ms.p, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->pk.view(), h->X.p,
+                              h->D, h->Dp, h->bq_cur, q_lo, q_hi, h->Kcap, h->centers.p, h->shadow_scale, h->qn.p, s);
         }
         ShortlistArgs pa{};
         pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
@@ -510,7 +507,8 @@ int batch_round_dev(chb_ctx *h, int active)
             Timed t(h, "bucket", (double)h->K);
             launch_bucket_batch(h->lab_prev.p, h->lab_old.p, h->bq_cur, h->K, h->B, h->cnt2.p,
                                 h->bin_ptr2.p, h->cursor2.p, h->memb2_id.p, h->memb2_code.p, h->pk2.pad_ptr.p,
-                                h->fc_cur, fusedp ? h->n_slow.p : nullptr, h->nflag.p, s);
+                                h->fc_cur, fusedp ? h->n_slow.p : nullptr, h->nflag.p, s,
+                                (h->pf_fit && h->pk2.bb.p) ? h->pk2.bb.p : nullptr);
         }
         TopmArgs a{};
         a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = lo; a.pos_end = hi;

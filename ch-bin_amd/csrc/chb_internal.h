@@ -100,6 +100,11 @@ void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, co
 // qn[B][Kcap] = float2 {||(x_j - mu_c) S||^2 rounded up, rounded down}
 void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
                         int Kcap, const double *centers, double S, void *qn, hipStream_t s);
+// launch_pack_rows (rows + per-bin bounds) and launch_query_norms in ONE launch: three independent pieces, each too
+// small to fill the chip on its own
+void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
+                       int B, int rows_hint, const MemberPack &P, const double *X, int D, int Dp, const int *bq,
+                       int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s);
 
 struct ShortlistArgs {
     const unsigned short *Gs;  // [N][Dz] query-side rows
@@ -227,7 +232,8 @@ void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int
 // (also starts the round's scalars: *first_change = K, *n_slow = 0, *nflag = 0 where the pointers are non-null)
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,
                          int *cnt, int *bin_ptr, int *cursor, int *memb_id, int *memb_code, int *pad_ptr,
-                         int *first_change, int *n_slow, int *nflag, hipStream_t s);
+                         int *first_change, int *n_slow, int *nflag, hipStream_t s, void *bb_zero = nullptr);
+// (bb_zero, optional: float4[B] per-bin bounds of the batch-entry pack, reset here for launch_pack_centered)
 // first position in [p0,K) whose label changed (atomicMin into *first_change)
 void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change,
                          hipStream_t s);

@@ -83,6 +83,12 @@ __device__ __forceinline__ unsigned short f16_shadow(double zs, double &back)
     return __builtin_bit_cast(unsigned short, hv);
 }
 
+// maximum of non-negative floats through an integer atomic on the float bits (NaN never enters)
+__device__ __forceinline__ void bound_max(float *slot, float v)
+{
+    if (v == v && v > 0.f) atomicMax(reinterpret_cast<unsigned int *>(slot), __float_as_uint(v));
+}
+
 // ---------------------------------------------------------------------------------------------
 // fit-level preparation
 
@@ -240,11 +246,10 @@ __device__ __forceinline__ int bin_of_row(const int *pad_ptr, int B, int r)
 
 // Gathers the per-sample member rows of the CSR-ordered base members into the padded layout;
 // 16 lanes per row.  Padding rows: zero features, bias = +inf (never selectable).
-__global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs, const float4 *ms, int Dz,
-                                                        const int *memb_id, const int *bin_ptr,
-                                                        const int *pad_ptr, int B, MemberPack P, Gate gate)
+__device__ __forceinline__ void pack_rows_block(const unsigned short *Zs, const float4 *ms, int Dz,
+                                                const int *memb_id, const int *bin_ptr,
+                                                const int *pad_ptr, int B, const MemberPack &P, int block, int nblocks)
 {
-    CHB_GATE(gate);
     // the two CSR offset tables go through LDS (up to 2048 bins): the bin search of every row is then a chain of LDS
     // reads instead of six dependent global loads in front of the row's own gather
     constexpr int kLdsBins = 2048;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs
     const int total = pad_ptr[B];
     const int cpr = Dz >> 3;
     const int l16 = threadIdx.x & 15;
-    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < total; r += gridDim.x * 16) {
+    for (int r = block * 16 + (threadIdx.x >> 4); r < total; r += nblocks * 16) {
         const int c = bin_of_row(pad_ptr, B, r);
         const int e = r - pad_ptr[c];
         const bool real = e < bin_ptr[c + 1] - bin_ptr[c];
@@ -275,6 +280,14 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs
     }
 }
 
+__global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs, const float4 *ms, int Dz,
+                                                        const int *memb_id, const int *bin_ptr,
+                                                        const int *pad_ptr, int B, MemberPack P, Gate gate)
+{
+    CHB_GATE(gate);
+    pack_rows_block(Zs, ms, Dz, memb_id, bin_ptr, pad_ptr, B, P, blockIdx.x, gridDim.x);
+}
+
 // Update mode: the batch's own entries (CSR over bins, eligibility code per entry, see
 // aux_kernels.hip) relative to the centre of the bin they are listed under, into the padded layout,
 // with the code rewritten as (s, b): "eligible for position q  <=>  s q + b >= 0".
@@ -289,11 +302,13 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b0 = bin_ptr[c], cnt = bin_ptr[c + 1] - b0, r0 = pad_ptr[c];
     const int padded = pad_ptr[c + 1] - r0;
+    float m_rho = 0.f, m_nrm = 0.f, m_amax = 0.f;   // this wavefront's share of the bin's bounds
     for (int e = blockIdx.y * 4 + w; e < padded; e += gridDim.y * 4) {
         const int r = r0 + e;
         if (e < cnt) {
             const float4 o = member_shadow_row(X + (size_t)memb_id[b0 + e] * Dp, centers + (size_t)c * Dp, mu_g,
                                                S, D, Dz, lane, P.Z + (size_t)r * Dz);
+            m_rho = fmaxf(m_rho, o.y); m_nrm = fmaxf(m_nrm, o.z); m_amax = fmaxf(m_amax, o.w);
             if (lane == 0) {
                 P.bias[r] = o.x; P.rho[r] = o.y; P.nrm[r] = o.z; P.amax[r] = o.w;
                 P.sn[r] = sqrtf(o.z) * (1.0f + 1e-6f);
@@ -312,6 +327,16 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
                 P.cs[r] = 0.f; P.cb[r] = 0.f;
             }
         }
+    }
+    // the bin's bounds {max rho, max ||zh||^2, max amax} accumulate in P.bb[c] (zeroed by the batch-CSR kernel of this
+    // round; the shortlist kernel takes the root of .y): the four wavefronts meet in LDS, three atomics per block --
+    // a same-address device atomic costs ~0.25 us, so never one per wavefront
+    __shared__ float sbd[3][4];
+    if (lane == 0) { sbd[0][w] = m_rho; sbd[1][w] = m_nrm; sbd[2][w] = m_amax; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float v = fmaxf(fmaxf(sbd[threadIdx.x][0], sbd[threadIdx.x][1]), fmaxf(sbd[threadIdx.x][2], sbd[threadIdx.x][3]));
+        bound_max(reinterpret_cast<float *>(P.bb) + 4 * c + threadIdx.x, v);
     }
 }
 
@@ -341,18 +366,51 @@ __global__ __launch_bounds__(256) void bin_bounds_kernel(MemberPack P, const int
         P.bb[c] = make_float4(red[0][0], sqrtf(red[1][0]) * (1.0f + 1e-6f), red[2][0], 0.f);
 }
 
+// the same bounds from the per-sample rows the pack is gathered FROM (ms[memb_id[..]]): independent of the pack
+// kernel's output, so that both can share one launch
+__device__ __forceinline__ void bin_bounds_from_source(const float4 *ms, const int *memb_id, const int *bin_ptr, int c,
+                                                       float4 *bb)
+{
+    __shared__ float red[3][256];
+    const int b0 = bin_ptr[c], cnt = bin_ptr[c + 1] - b0;
+    float v = 0.f, u = 0.f, a = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const float4 o = ms[memb_id[b0 + e]];
+        v = fmaxf(v, o.y); u = fmaxf(u, o.z); a = fmaxf(a, o.w);
+    }
+    red[0][threadIdx.x] = v; red[1][threadIdx.x] = u; red[2][threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int q = 0; q < 3; ++q)
+                red[q][threadIdx.x] = fmaxf(red[q][threadIdx.x], red[q][threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bb[c] = make_float4(red[0][0], sqrtf(red[1][0]) * (1.0f + 1e-6f), red[2][0], 0.f);
+}
+
 // qn[c][pos] = ||(x_j - mu_c) S||^2 in fp64, rounded {up, down}.  A 32 positions x 64 bins tile per
 // block, features staged through LDS 16 at a time (already scaled by S: exact, and keeps tiny
 // feature scales away from underflow); each thread owns a 2 x 4 micro-tile.
-__global__ __launch_bounds__(256) void query_norms_kernel(const double *X, int D, int Dp, const int *bq,
-                                                          int pos_begin, int pos_end, int B, int Kcap,
-                                                          const double *centers, double S, float2 *qn, Gate gate)
+struct QnArgs {
+    const double *X;
+    int D, Dp;
+    const int *bq;
+    int pos_begin, pos_end, B, Kcap;
+    const double *centers;
+    double S;
+    float2 *qn;
+};
+
+__device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, int tile_y)
 {
-    CHB_GATE(gate);
+    const double *X = q.X; const int D = q.D, Dp = q.Dp; const int *bq = q.bq;
+    const int pos_begin = q.pos_begin, pos_end = q.pos_end, B = q.B, Kcap = q.Kcap;
+    const double *centers = q.centers; const double S = q.S; float2 *qn = q.qn;
     constexpr int KC = 16;
     __shared__ double xs[32][KC + 1], cs[64][KC + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int p0 = pos_begin + blockIdx.x * 32, c0 = blockIdx.y * 64;
+    const int p0 = pos_begin + tile_x * 32, c0 = tile_y * 64;
     // staging roles: centre row tid / 4 with four consecutive features, query row tid / 8 with two
     const int crow_i = tid >> 2, ck = (tid & 3) * 4;
     const int xrow_i = tid >> 3, xk = (tid & 7) * 2;
@@ -414,6 +472,26 @@ __global__ __launch_bounds__(256) void query_norms_kernel(const double *X, int D
                 qn[(size_t)c * Kcap + pos] = make_float2(round_up_f32(acc[i][j] * (1.0 + 1e-12)),
                                                         (float)(acc[i][j] * (1.0 - 1e-6)));
         }
+}
+
+__global__ __launch_bounds__(256) void query_norms_kernel(QnArgs q, Gate gate)
+{
+    CHB_GATE(gate);
+    query_norms_tile(q, blockIdx.x, blockIdx.y);
+}
+
+// One launch for three independent pieces of a batch start (each used to be a launch of its own, each too small to fill
+// the chip): blocks [0, npack) gather the base members' shadow rows into the padded pack (pack_rows_block); blocks
+// [npack, npack + B) reduce the per-bin bounds from the same source rows; the rest are the query-norm tiles.
+__global__ __launch_bounds__(256) void pack_build_kernel(const unsigned short *Zs, const float4 *ms, int Dz,
+                                                         const int *memb_id, const int *bin_ptr, const int *pad_ptr,
+                                                         int B, MemberPack P, int npack, QnArgs q, int nqx, Gate gate)
+{
+    CHB_GATE(gate);
+    const int b = blockIdx.x;
+    if (b < npack) pack_rows_block(Zs, ms, Dz, memb_id, bin_ptr, pad_ptr, B, P, b, npack);
+    else if (b < npack + B) bin_bounds_from_source(ms, memb_id, bin_ptr, b - npack, P.bb);
+    else query_norms_tile(q, (b - npack - B) % nqx, (b - npack - B) / nqx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -642,7 +720,8 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
         const int ntile = (a.P.pad_ptr[c + 1] - row0) / kPfP;
         const size_t slot = (size_t)c * a.Kcap + (qvalid ? qpos : a.pos_end - 1);
         // ---- per-(query, bin) bounds
-        const float4 bb = a.P.bb[c];                      // {rho_bin, snb, Bmax, -}
+        float4 bb = a.P.bb[c];                            // {rho_bin, snb, Bmax, -}
+        if (UPD) bb.y = sqrtf(bb.y) * (1.0f + 1e-6f);     // (the batch-entry pack accumulates the largest ||zh||^2)
         const float2 qn2 = a.qn[slot];                    // N_jc {up, down}
         const float E = (1.2e-7f * bb.z + a.gamma * (bb.z + 2.0f * snq * bb.y)) *
                         (1.0f + 4.0f * kSlack);
@@ -923,8 +1002,7 @@ void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, co
     int gy = ((rows_hint + 31 * B) / std::max(B, 1) + 15) / 16;   // ~4 entries per wavefront per bin
     gy = std::max(1, std::min(gy, 64));
     hipLaunchKernelGGL(pack_centered_kernel, dim3(B, gy), dim3(256), 0, s, X, D, Dp, memb_id, memb_code, bin_ptr,
-                       P.pad_ptr, centers, mu_g, S, Dz, P, g_gate);
-    hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, P, bin_ptr, g_gate);
+                       P.pad_ptr, centers, mu_g, S, Dz, P, g_gate);   // (bounds: into P.bb, zeroed by the batch-CSR kernel)
 }
 
 void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
@@ -932,8 +1010,23 @@ void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_b
 {
     const int nq = pos_end - pos_begin;
     if (nq <= 0 || B <= 0) return;
-    hipLaunchKernelGGL(query_norms_kernel, dim3((nq + 31) / 32, (B + 63) / 64), dim3(256), 0, s, X, D, Dp, bq,
-                       pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn), g_gate);
+    const QnArgs q{X, D, Dp, bq, pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn)};
+    hipLaunchKernelGGL(query_norms_kernel, dim3((nq + 31) / 32, (B + 63) / 64), dim3(256), 0, s, q, g_gate);
+}
+
+void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
+                       int B, int rows_hint, const MemberPack &P, const double *X, int D, int Dp, const int *bq,
+                       int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s)
+{
+    if (B <= 0) return;
+    const long long rows = (long long)rows_hint + 32LL * B;
+    const int npack = (int)std::max<long long>(1, std::min<long long>((rows + 15) / 16, 16384));
+    const int nq = pos_end - pos_begin;
+    const int nqx = nq > 0 ? (nq + 31) / 32 : 0, nqy = (B + 63) / 64;
+    const QnArgs q{X, D, Dp, bq, pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn)};
+    hipLaunchKernelGGL(pack_build_kernel, dim3(npack + B + nqx * nqy), dim3(256), 0, s, Zs,
+                       reinterpret_cast<const float4 *>(ms), Dz, memb_id, bin_ptr, P.pad_ptr, B, P, npack, q,
+                       std::max(nqx, 1), g_gate);
 }
 
 void launch_shortlist(const ShortlistArgs &a_, int *flags64, hipStream_t s)
