@@ -759,7 +759,7 @@ static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D,
     h->shadow_ok = false;
     const int Dz = shadow_row_elems((int)D);
     if (h->use_prefilter && Dz > 0) {
-        // global mean, the power-of-two scale that puts every centred feature inside +-2^14, and the
+        // global mean, the power-of-two scale that puts every centred feature inside +-2^11, and the
         // query-side shadow row of every sample: functions of X alone
         const int part_blocks = 1024;
         HIPCHK(h->mu_g.ensure((size_t)Dp));
@@ -780,7 +780,8 @@ static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D,
         if (R > 0.f && std::isfinite(R)) {
             int e = 0;
             (void)std::frexp((double)R, &e);   // R < 2^e
-            S = std::ldexp(1.0, 13 - e);       // |x - mu_c| S <= 2 R S < 2^14
+            S = std::ldexp(1.0, 10 - e);       // |x - mu_c| S <= 2 R S < 2^11: every member's -bias / 2 then fits the three
+                                               // fp16 bias columns of its shadow row (prefilter_kernels.hip, kBiasExp)
         }
         h->shadow_scale = S;
         launch_global_shadow(h->X.p, (int)N, (int)D, Dp, h->mu_g.p, S, h->Gs.p, Dz, h->gq.p, h->stream);

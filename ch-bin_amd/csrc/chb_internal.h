@@ -67,14 +67,16 @@ constexpr int kCandCapU = 32;   // same for the batch's own entries in the fused
 // Members of all bins, grouped by bin, every bin padded to a multiple of 32 rows:
 struct MemberPack {
     unsigned short *Z;        // [rows][Dz] fp16 bits of (x_p - mu_c) S; zero rows in the padding
-    float *bias;              // [rows] ||zh||^2 + 2 <(mu_c - mu_g) S, zh>; +inf in the padding
+    float *bias;              // [rows] batch-entry pack: ||zh||^2 + 2 <(mu_c - mu_g) S, zh>; base pack: residual of
+                              // the bias pieces the row carries in its columns D .. D + 2; +inf in the padding
     float *rho, *nrm, *amax;  // [rows] rounding distance, ||zh||^2, ||zh||^2 + 2 |<..>|
     float *sn;                // [rows] ||zh|| (rounded up)
     float *cs, *cb;           // [rows] update mode: entry eligible for position q <=> cs q + cb >= 0
     int *pad_ptr;             // [B+1] first row of each bin (multiples of 32)
-    float4 *bb;               // [B] {largest rho, largest ||zh||, largest amax, -}
+    float4 *bb;               // [B] {largest rho, largest ||zh||, largest amax, largest residual of the bias pieces}
+                              // (the batch-entry pack accumulates the largest ||zh||^2 in .y; its .w is unused)
 };
-int shadow_row_elems(int D);   // Dz: 144 or 160 (0: D too large for the shortlist stage)
+int shadow_row_elems(int D);   // Dz: 144 or 160, at least three spare columns (0: D too large for the shortlist stage)
 // mu_g = column means (deterministic two-pass sum), *rmax = float bits of max |x - mu_g|
 void launch_global_center(const double *X, int N, int D, int Dp, double *part, int part_blocks, double *mu_g,
                           unsigned int *rmax, hipStream_t s);
@@ -90,18 +92,13 @@ void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, cons
 void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n, int *labels,
                           int B, const double *centers, const double *mu_g, double S, unsigned short *Zs,
                           int Dz, void *ms, const int *new_lab, int *inb, hipStream_t s);
-// base members (CSR; P.pad_ptr from launch_bucket_base) -> padded pack (+ per-bin bounds)
-void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
-                      int B, int rows_hint, const MemberPack &P, hipStream_t s);
 // the batch's own entries (CSR + eligibility codes; P.pad_ptr from launch_bucket_batch) -> padded pack
 void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *memb_code,
                           const int *bin_ptr, int B, int rows_hint, const double *centers, const double *mu_g,
                           double S, int Dz, const MemberPack &P, hipStream_t s);
-// qn[B][Kcap] = float2 {||(x_j - mu_c) S||^2 rounded up, rounded down}
-void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
-                        int Kcap, const double *centers, double S, void *qn, hipStream_t s);
-// launch_pack_rows (rows + per-bin bounds) and launch_query_norms in ONE launch: three independent pieces, each too
-// small to fill the chip on its own
+// Three independent pieces of a batch start in ONE launch (each too small to fill the chip on its own): the base
+// members' shadow rows (CSR; P.pad_ptr from launch_bucket_base) gathered into the padded pack; the per-bin bounds
+// P.bb; qn[B][Kcap] = float2 {||(x_j - mu_c) S||^2 rounded up, rounded down} of the batch's queries
 void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
                        int B, int rows_hint, const MemberPack &P, const double *X, int D, int Dp, const int *bq,
                        int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s);

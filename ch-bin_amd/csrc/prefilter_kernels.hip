@@ -22,15 +22,23 @@
 //     T(j,p) := ||z_j - zh_p||^2 = N_jc + bias_p - 2 <qh_j, zh_p> - 2 <(x_j - mu_g) S - qh_j, zh_p>
 // and the matrix core returns acc = -bias_p / 2 + <qh_j, zh_p> (v_mfma_f32_32x32x16_f16: fp16
 // products are exact in fp32), so that | T - (N_jc - 2 acc) | <= E(j,c) + 2 rho_j ||zh_p|| with
-//     E = 2^-24 Bmax_c + g (Bmax_c + 2 ||qh_j|| snb_c)
-// (rounding of bias to fp32; accumulation error: g = 2.5e-5 exceeds the worst case (n - 1) u of summing
+//     E = 2 r_c + g (Bmax_c + 2 ||qh_j|| snb_c)
+// Base members (round 3): -bias_p / 2 rides INSIDE the dot product.  The shadow rows have at least three spare
+// columns (D + 3 <= Dz); a member row carries three fp16 pieces h1 + h2 + h3 ~ -bias_p / 2^(kBiasExp + 1) there,
+// every query row the constant 2^kBiasExp, so the matrix core adds (h1 + h2 + h3) 2^kBiasExp = -bias_p / 2 - r_p
+// with the residual r_p measured exactly when the row is built (r_c = its maximum over the bin; S keeps every
+// centred feature inside +-2^11, so |bias_p / 2| < 2^29.4 and the pieces never overflow).  The tile loop then reads
+// nothing but the fragments: no bias / norm columns through LDS, no accumulator start values.  The batch's own
+// entries (update mode) keep the explicit start value -- they also carry their eligibility columns.
+// (accumulation error: g = 2.5e-5 exceeds the worst case (n - 1) u of summing
 // the n <= 161 fp32 terms in ANY order with one-ulp truncating adds, u = 2^-23 -- round-to-nearest
 // halves it, and the observed error is two orders of magnitude smaller; the terms are the start
 // value and the Dz <= 160 exact products; snb_c = max ||zh_p||, Bmax_c = max (||zh_p||^2 + 2 |<..>|)
 // over the bin).  The last term is Cauchy-Schwarz on the query's rounding error, damped by the small
-// norm of the bin-centred member -- per member: it is folded into the accumulator's start value,
+// norm of the bin-centred member.  Update mode folds it per member into the accumulator's start value,
 // -bias_p / 2 -+ rho_j ||zh_p||, minus for the upper bounds of sweep 0, plus for the lower bounds of
-// sweep 1, so the tile loop does not see it.
+// sweep 1; base mode uses the bin's largest norm, d_jc = rho_j snb_c: one constant per (query, bin) that moves
+// the two thresholds instead of every accumulator.
 // By the triangle inequality | S d(j,p) - sqrt(T) | <= rho_p <= rho_bin, hence for every member
 //     LB(j,p) <= S d(j,p) <= UB(j,p),   UB/LB = sqrt(N_jc - 2 acc' +- E) +- rho_bin .
 // Sweep 0 over a bin learns tau = (an upper bound of) the m-th smallest UB -- at least m members
@@ -57,6 +65,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #ifndef CHB_SL_DMAREP
 #define CHB_SL_DMAREP 1   // developer experiment: issue every tile's DMA this many times
 #endif
+constexpr int kBiasCols = 3;         // spare shadow columns that carry -bias / 2 of a base member
+constexpr int kBiasExp = 14;         // ... as (h1 + h2 + h3) 2^kBiasExp; the query rows hold 2^kBiasExp there
 constexpr float kGamma = 2.5e-5f;
 constexpr float kSlack = 1e-6f;
 #ifndef CHB_SL_WAVES
@@ -147,6 +157,8 @@ __global__ __launch_bounds__(256) void global_shadow_kernel(const double *X, int
             hb = f16_shadow(z, zh);
             n2 += zh * zh;
             e2 += (zh - z) * (zh - z);
+        } else if (k < D + kBiasCols) {
+            hb = (unsigned short)((kBiasExp + 15) << 10);   // fp16 2^kBiasExp: multiplies a member's bias pieces
         }
         Gs[(size_t)p * Dz + k] = hb;
     }
@@ -177,8 +189,11 @@ __global__ __launch_bounds__(256) void bin_center_kernel(const double *X, int D,
 
 // Member-side shadow of one sample relative to bin c's centre, computed by one wavefront.
 // Returns (on every lane) {bias, rho, ||zh||^2, ||zh||^2 + 2 |<(mu_c - mu_g) S, zh>|}.
+// bias_cols: the row also gets -bias / 2 as three fp16 pieces in columns D .. D + 2 (base members); *resid then
+// receives | -bias / 2 - (h1 + h2 + h3) 2^kBiasExp |, rounded up.  Without: those columns stay zero.
 __device__ __forceinline__ float4 member_shadow_row(const double *x, const double *mu, const double *mu_g,
-                                                    double S, int D, int Dz, int lane, unsigned short *zrow)
+                                                    double S, int D, int Dz, int lane, unsigned short *zrow,
+                                                    bool bias_cols = false, float *resid = nullptr)
 {
     double n2 = 0.0, e2 = 0.0, sp = 0.0;
     for (int k = lane; k < Dz; k += 64) {
@@ -199,6 +214,16 @@ __device__ __forceinline__ float4 member_shadow_row(const double *x, const doubl
         e2 += __shfl_xor(e2, off, 64);
         sp += __shfl_xor(sp, off, 64);
     }
+    if (bias_cols) {
+        const double v = -0.5 * (n2 + 2.0 * sp) * (1.0 / (double)(1 << kBiasExp));   // (exact scaling)
+        double b1, b2, b3;
+        const unsigned short h1 = f16_shadow(v, b1);
+        const unsigned short h2 = f16_shadow(v - b1, b2);
+        const unsigned short h3 = f16_shadow(v - b1 - b2, b3);
+        if (lane == 0) { zrow[D] = h1; zrow[D + 1] = h2; zrow[D + 2] = h3; }
+        if (resid != nullptr)
+            *resid = round_up_f32(fabs(v - b1 - b2 - b3) * (double)(1 << kBiasExp) * (1.0 + 1e-12) + 1e-300);
+    }
     float4 o;
     o.x = (float)(n2 + 2.0 * sp);
     o.y = round_up_f32(sqrt(e2) * (1.0 + 1e-9) + 1e-300);
@@ -207,7 +232,8 @@ __device__ __forceinline__ float4 member_shadow_row(const double *x, const doubl
     return o;
 }
 
-// Per-sample member rows relative to the centre of the sample's CURRENT bin (labels[p] >= 0).
+// Per-sample member rows relative to the centre of the sample's CURRENT bin (labels[p] >= 0), with the bias
+// columns filled; ms[p] = {residual of the bias pieces, rho, ||zh||^2, amax}.
 // ids == nullptr: all samples 0..n-1; otherwise the n listed samples (the batch just committed).
 __global__ __launch_bounds__(256) void sample_shadow_kernel(const double *X, int D, int Dp, const int *ids,
                                                             int n, int *labels, int B,
@@ -228,8 +254,10 @@ __global__ __launch_bounds__(256) void sample_shadow_kernel(const double *X, int
         c = labels[p];
     }
     if (c < 0 || c >= B) return;
-    const float4 o = member_shadow_row(X + (size_t)p * Dp, centers + (size_t)c * Dp, mu_g, S, D, Dz, lane,
-                                       Zs + (size_t)p * Dz);
+    float resid = 0.f;
+    float4 o = member_shadow_row(X + (size_t)p * Dp, centers + (size_t)c * Dp, mu_g, S, D, Dz, lane,
+                                 Zs + (size_t)p * Dz, true, &resid);
+    o.x = resid;   // (-bias / 2 itself sits in the row's bias columns; .x carries how far the pieces miss it)
     if (lane == 0) ms[p] = o;
 }
 
@@ -246,7 +274,7 @@ __device__ __forceinline__ int bin_of_row(const int *pad_ptr, int B, int r)
 
 // Gathers the per-sample member rows of the CSR-ordered base members into the padded layout;
 // 16 lanes per row.  Padding rows: zero features, bias = +inf (never selectable).
-__device__ __forceinline__ void pack_rows_block(const unsigned short *Zs, const float4 *ms, int Dz,
+__device__ __forceinline__ void pack_rows_block(const unsigned short *Zs, const float4 *ms, int D, int Dz,
                                                 const int *memb_id, const int *bin_ptr,
                                                 const int *pad_ptr, int B, const MemberPack &P, int block, int nblocks)
 {
@@ -270,22 +298,21 @@ __device__ __forceinline__ void pack_rows_block(const unsigned short *Zs, const 
         for (int cc = l16; cc < cpr; cc += 16) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (real) v = *reinterpret_cast<const uint4 *>(Zs + (size_t)id * Dz + cc * 8);
+            else if (cc == (D >> 3)) {
+                // padding row: first bias piece = fp16 -inf, so that its accumulator comes out as -inf
+                const unsigned hw = 0xFC00u << (16 * (D & 1));
+                const int wd = (D & 7) >> 1;
+                if (wd == 0) v.x = hw; else if (wd == 1) v.y = hw; else if (wd == 2) v.z = hw; else v.w = hw;
+            }
             *reinterpret_cast<uint4 *>(P.Z + (size_t)r * Dz + cc * 8) = v;
         }
         if (l16 == 0) {
+            // (.bias of the base pack = residual of the row's bias pieces; +inf marks a padding row)
             const float4 o = real ? ms[id] : make_float4(INFINITY, 0.f, 0.f, 0.f);
             P.bias[r] = o.x; P.rho[r] = o.y; P.nrm[r] = o.z; P.amax[r] = o.w;
             P.sn[r] = sqrtf(o.z) * (1.0f + 1e-6f);
         }
     }
-}
-
-__global__ __launch_bounds__(256) void pack_rows_kernel(const unsigned short *Zs, const float4 *ms, int Dz,
-                                                        const int *memb_id, const int *bin_ptr,
-                                                        const int *pad_ptr, int B, MemberPack P, Gate gate)
-{
-    CHB_GATE(gate);
-    pack_rows_block(Zs, ms, Dz, memb_id, bin_ptr, pad_ptr, B, P, blockIdx.x, gridDim.x);
 }
 
 // Update mode: the batch's own entries (CSR over bins, eligibility code per entry, see
@@ -340,53 +367,29 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
     }
 }
 
-// bb[c] = {largest rounding distance, largest ||zh|| (rounded up), largest ||zh||^2 + 2|<..>|, 0}
-// over the members of bin c; one block per bin
-__global__ __launch_bounds__(256) void bin_bounds_kernel(MemberPack P, const int *bin_ptr, Gate gate)
-{
-    CHB_GATE(gate);
-    __shared__ float red[3][256];
-    const int c = blockIdx.x;
-    const int r0 = P.pad_ptr[c], cnt = bin_ptr[c + 1] - bin_ptr[c];
-    float v = 0.f, u = 0.f, a = 0.f;
-    for (int e = threadIdx.x; e < cnt; e += 256) {
-        v = fmaxf(v, P.rho[r0 + e]);
-        u = fmaxf(u, P.nrm[r0 + e]);
-        a = fmaxf(a, P.amax[r0 + e]);
-    }
-    red[0][threadIdx.x] = v; red[1][threadIdx.x] = u; red[2][threadIdx.x] = a;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int q = 0; q < 3; ++q)
-                red[q][threadIdx.x] = fmaxf(red[q][threadIdx.x], red[q][threadIdx.x + off]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        P.bb[c] = make_float4(red[0][0], sqrtf(red[1][0]) * (1.0f + 1e-6f), red[2][0], 0.f);
-}
-
-// the same bounds from the per-sample rows the pack is gathered FROM (ms[memb_id[..]]): independent of the pack
-// kernel's output, so that both can share one launch
+// bb[c] = {largest rounding distance, largest ||zh|| (rounded up), largest ||zh||^2 + 2|<..>|, largest bias residual}
+// over the members of bin c, from the per-sample rows the pack is gathered FROM (ms[memb_id[..]]): independent of the
+// pack kernel's output, so that both can share one launch
 __device__ __forceinline__ void bin_bounds_from_source(const float4 *ms, const int *memb_id, const int *bin_ptr, int c,
                                                        float4 *bb)
 {
-    __shared__ float red[3][256];
+    __shared__ float red[4][256];
     const int b0 = bin_ptr[c], cnt = bin_ptr[c + 1] - b0;
-    float v = 0.f, u = 0.f, a = 0.f;
+    float v = 0.f, u = 0.f, a = 0.f, rs = 0.f;
     for (int e = threadIdx.x; e < cnt; e += 256) {
         const float4 o = ms[memb_id[b0 + e]];
-        v = fmaxf(v, o.y); u = fmaxf(u, o.z); a = fmaxf(a, o.w);
+        rs = fmaxf(rs, o.x); v = fmaxf(v, o.y); u = fmaxf(u, o.z); a = fmaxf(a, o.w);
     }
-    red[0][threadIdx.x] = v; red[1][threadIdx.x] = u; red[2][threadIdx.x] = a;
+    red[0][threadIdx.x] = v; red[1][threadIdx.x] = u; red[2][threadIdx.x] = a; red[3][threadIdx.x] = rs;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
         if ((int)threadIdx.x < off)
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < 4; ++q)
                 red[q][threadIdx.x] = fmaxf(red[q][threadIdx.x], red[q][threadIdx.x + off]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) bb[c] = make_float4(red[0][0], sqrtf(red[1][0]) * (1.0f + 1e-6f), red[2][0], 0.f);
+    // {largest rho, largest ||zh|| (rounded up), largest amax, largest residual of the bias pieces}
+    if (threadIdx.x == 0) bb[c] = make_float4(red[0][0], sqrtf(red[1][0]) * (1.0f + 1e-6f), red[2][0], red[3][0]);
 }
 
 // qn[c][pos] = ||(x_j - mu_c) S||^2 in fp64, rounded {up, down}.  A 32 positions x 64 bins tile per
@@ -474,12 +477,6 @@ __device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, in
         }
 }
 
-__global__ __launch_bounds__(256) void query_norms_kernel(QnArgs q, Gate gate)
-{
-    CHB_GATE(gate);
-    query_norms_tile(q, blockIdx.x, blockIdx.y);
-}
-
 // One launch for three independent pieces of a batch start (each used to be a launch of its own, each too small to fill
 // the chip): blocks [0, npack) gather the base members' shadow rows into the padded pack (pack_rows_block); blocks
 // [npack, npack + B) reduce the per-bin bounds from the same source rows; the rest are the query-norm tiles.
@@ -489,7 +486,7 @@ __global__ __launch_bounds__(256) void pack_build_kernel(const unsigned short *Z
 {
     CHB_GATE(gate);
     const int b = blockIdx.x;
-    if (b < npack) pack_rows_block(Zs, ms, Dz, memb_id, bin_ptr, pad_ptr, B, P, b, npack);
+    if (b < npack) pack_rows_block(Zs, ms, q.D, Dz, memb_id, bin_ptr, pad_ptr, B, P, b, npack);
     else if (b < npack + B) bin_bounds_from_source(ms, memb_id, bin_ptr, b - npack, P.bb);
     else query_norms_tile(q, (b - npack - B) % nqx, (b - npack - B) / nqx);
 }
@@ -638,7 +635,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
     int n_w = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) n_w += (w + kPfW * j < KS) ? CHB_SL_DMAREP : 0;
-    n_w += (w == 3) ? 1 : 0;
+    n_w += (UPD && w == 3) ? 1 : 0;   // (base mode moves no bias / norm columns: -bias / 2 rides in the rows)
     n_w += (UPD && w == 2) ? 1 : 0;
     const unsigned char *zall = reinterpret_cast<const unsigned char *>(a.P.Z);
 
@@ -667,8 +664,8 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
             if (w + kPfW * j < KS)                                                                 \
                 __builtin_amdgcn_global_load_lds(src_ + src_off[j],                                \
                     (__attribute__((address_space(3))) void *)(dst_ + (w + kPfW * j) * 1024), 16, 0, 0); \
-        if (w == 3) {                                                                              \
-            const float *p_ = (h ? (UPD ? a.P.cs : a.P.sn) : a.P.bias) + row_ + col;               \
+        if (UPD && w == 3) {                                                                       \
+            const float *p_ = (h ? a.P.cs : a.P.bias) + row_ + col;                                \
             __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB), 4, 0, 0); \
         }                                                                                          \
         if (UPD && w == 2) {                                                                       \
@@ -723,8 +720,13 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
         float4 bb = a.P.bb[c];                            // {rho_bin, snb, Bmax, -}
         if (UPD) bb.y = sqrtf(bb.y) * (1.0f + 1e-6f);     // (the batch-entry pack accumulates the largest ||zh||^2)
         const float2 qn2 = a.qn[slot];                    // N_jc {up, down}
-        const float E = (1.2e-7f * bb.z + a.gamma * (bb.z + 2.0f * snq * bb.y)) *
+        // base mode: bias exact up to the measured residual of its pieces (2 r_c on T = N - 2 acc); update mode: bias
+        // rounded to fp32 (2^-24 Bmax)
+        const float E = ((UPD ? 1.2e-7f * bb.z : 2.0f * bb.w) + a.gamma * (1.001f * bb.z + 2.0f * snq * bb.y)) *
                         (1.0f + 4.0f * kSlack);
+        // base mode: the query's rounding error against the LARGEST member norm of the bin, one constant per
+        // (query, bin) that shifts the thresholds (update mode: per member, in the accumulator's start value)
+        const float dl = UPD ? 0.f : rg * bb.y * (1.0f + 4.0f * kSlack);
         const float nj_hi = (qn2.x + E) * (1.0f + kSlack);
         const float nj_lo = (qn2.y - E) * (qn2.y > E ? (1.0f - kSlack) : (1.0f + kSlack));
         const float rsum = bb.x * (1.0f + kSlack);
@@ -767,10 +769,12 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                 float tau = INFINITY;
                 if (qvalid && ms > -INFINITY) {
                     // tau = m-th smallest upper bound; at least m members are provably within it
-                    const float thr = -2.0f * ms;
+                    // (base mode: the list holds RAW accumulators; the upper bound of a member's t is -2 (acc - dl),
+                    //  and a member is admitted when its lower bound -2 (acc + dl) is within reach: acc >= thr2)
+                    const float thr = -2.0f * (ms - dl);
                     tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
                     const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
-                    thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
+                    thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo) - dl;
                 }
                 // for the fused selection path: tau bounds the m-th distance among these members -- the update
                 // stage's threshold and (smallest over the bins) the label guess
@@ -784,35 +788,39 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                 const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
                 // rows held by this lane: (r & 3) + 8 (r >> 2) + 4 h
                 const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
-                f32x4 nv[4], nn[4], sv[4], bv[4];
+                f32x16 acc;
+                if (UPD) {
+                    f32x4 nv[4], nn[4], sv[4], bv[4];
 #define CHB_SL_META(G)                                                                             \
-                nv[G] = lds_read_f4<32 * (G)>(ma);                                                 \
-                nn[G] = lds_read_f4<(UPD ? 384 : 128) + 32 * (G)>(ma);                             \
-                if (UPD) { sv[G] = lds_read_f4<128 + 32 * (G)>(ma); bv[G] = lds_read_f4<256 + 32 * (G)>(ma); }
-                CHB_SL_META(0) CHB_SL_META(1) CHB_SL_META(2) CHB_SL_META(3)
+                    nv[G] = lds_read_f4<32 * (G)>(ma);                                             \
+                    nn[G] = lds_read_f4<384 + 32 * (G)>(ma);                                       \
+                    sv[G] = lds_read_f4<128 + 32 * (G)>(ma); bv[G] = lds_read_f4<256 + 32 * (G)>(ma);
+                    CHB_SL_META(0) CHB_SL_META(1) CHB_SL_META(2) CHB_SL_META(3)
 #undef CHB_SL_META
-                // (asm reads are complete once the tied s_waitcnt below returns: no use can be scheduled
-                //  ahead of it.  Two phases -- bias column, then fragments -- keep the peak register
-                //  count at four wavefronts per SIMD.)
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "+v"(nn[0]), "+v"(nn[1]), "+v"(nn[2]),
-                               "+v"(nn[3])
-                             :
-                             : "memory");
-                if (UPD)
+                    // (asm reads are complete once the tied s_waitcnt below returns: no use can be scheduled
+                    //  ahead of it.  Two phases -- bias column, then fragments -- keep the peak register count down.)
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "+v"(nn[0]), "+v"(nn[1]), "+v"(nn[2]),
+                                   "+v"(nn[3])
+                                 :
+                                 : "memory");
                     asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(bv[0]), "+v"(bv[1]),
                                       "+v"(bv[2]), "+v"(bv[3]) : : "memory");
-                f32x16 acc;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                    for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        // -bias / 2, pushed down (sweep 0: upper bounds) or up (sweep 1: lower bounds) by
-                        // the query's rounding error against THIS member's norm
-                        acc[4 * g + k] = fmaf(rgs, nn[g][k], -0.5f * nv[g][k]);
-                        // a batch member counts for this query only on the right side of the visiting order
-                        if (UPD && fmaf(sv[g][k], qposf, bv[g][k]) < 0.f) acc[4 * g + k] = -INFINITY;
+                        for (int k = 0; k < 4; ++k) {
+                            // -bias / 2, pushed up (lower bounds) by the query's rounding error against THIS member's norm
+                            acc[4 * g + k] = fmaf(rgs, nn[g][k], -0.5f * nv[g][k]);
+                            // a batch member counts for this query only on the right side of the visiting order
+                            if (fmaf(sv[g][k], qposf, bv[g][k]) < 0.f) acc[4 * g + k] = -INFINITY;
+                        }
                     }
+                } else {
+                    // base members: -bias / 2 is part of the dot product (three bias columns of the row against the
+                    // query's 2^kBiasExp) -- the tile loop touches nothing but the fragments
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 }
                 f16x8 af[KS == 9 ? 9 : 10];
                 {
@@ -946,7 +954,7 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
 
 }  // namespace
 
-int shadow_row_elems(int D) { return D <= 144 ? 144 : (D <= 160 ? 160 : 0); }
+int shadow_row_elems(int D) { return D + kBiasCols <= 144 ? 144 : (D + kBiasCols <= 160 ? 160 : 0); }
 
 void launch_global_center(const double *X, int N, int D, int Dp, double *part, int part_blocks, double *mu_g,
                           unsigned int *rmax, hipStream_t s)
@@ -983,17 +991,6 @@ void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n,
                            B, centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms), new_lab, inb, g_gate);
 }
 
-void launch_pack_rows(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
-                      int B, int rows_hint, const MemberPack &P, hipStream_t s)
-{
-    if (B <= 0) return;
-    const long long rows = (long long)rows_hint + 32LL * B;
-    const int grid = (int)std::min<long long>((rows + 15) / 16, 16384);
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, Zs,
-                       reinterpret_cast<const float4 *>(ms), Dz, memb_id, bin_ptr, P.pad_ptr, B, P, g_gate);
-    hipLaunchKernelGGL(bin_bounds_kernel, dim3(B), dim3(256), 0, s, P, bin_ptr, g_gate);
-}
-
 void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *memb_code,
                           const int *bin_ptr, int B, int rows_hint, const double *centers, const double *mu_g,
                           double S, int Dz, const MemberPack &P, hipStream_t s)
@@ -1003,15 +1000,6 @@ void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, co
     gy = std::max(1, std::min(gy, 64));
     hipLaunchKernelGGL(pack_centered_kernel, dim3(B, gy), dim3(256), 0, s, X, D, Dp, memb_id, memb_code, bin_ptr,
                        P.pad_ptr, centers, mu_g, S, Dz, P, g_gate);   // (bounds: into P.bb, zeroed by the batch-CSR kernel)
-}
-
-void launch_query_norms(const double *X, int D, int Dp, const int *bq, int pos_begin, int pos_end, int B,
-                        int Kcap, const double *centers, double S, void *qn, hipStream_t s)
-{
-    const int nq = pos_end - pos_begin;
-    if (nq <= 0 || B <= 0) return;
-    const QnArgs q{X, D, Dp, bq, pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn)};
-    hipLaunchKernelGGL(query_norms_kernel, dim3((nq + 31) / 32, (B + 63) / 64), dim3(256), 0, s, q, g_gate);
 }
 
 void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,

@@ -402,7 +402,7 @@ def _brute_ctx():
     return c
 
 
-@pytest.mark.parametrize("kind", ["offset", "tiny", "dups", "wide", "onehot", "bigbins"])
+@pytest.mark.parametrize("kind", ["offset", "tiny", "dups", "wide", "onehot", "bigbins", "d141", "d157", "spread"])
 def test_shortlist_stage_equals_brute_force(ctx, O, kind):
     """The fp16 shortlist + exact rescoring must give bit-identical lists to the brute-force
     kernel on data built to stress the error bounds and the overflow fallback."""
@@ -411,6 +411,10 @@ def test_shortlist_stage_equals_brute_force(ctx, O, kind):
     N, D, B, m = 3000, 136, 6, 5
     if kind == "bigbins":
         N, B = 9000, 4          # > 512 members per bin: the per-tile-best threshold mode of sweep 0
+    if kind == "d141":
+        D = 141                 # the widest rows of the 144-column build: exactly three spare (bias) columns
+    if kind == "d157":
+        D = 157                 # ... of the 160-column build
     X, _, true = _synth(N, D, B, seed=4, sigma=3e-3, mix=0.5)
     if kind == "offset":
         X = X + 1000.0                                   # huge common offset: centring must cope
@@ -423,6 +427,10 @@ def test_shortlist_stage_equals_brute_force(ctx, O, kind):
         X = X * rng.lognormal(0, 3, size=(1, D))         # wildly different column scales
     elif kind == "onehot":
         X = np.zeros((N, D)); X[np.arange(N), rng.integers(0, D, N)] = 1.0   # massive exact ties
+    elif kind == "spread":
+        # bins 2^17 times further apart than they are wide: the members' bias (carried as three fp16 pieces in the
+        # shadow rows) is huge against the distances that decide the selection
+        X = X + 1e3 * true[:, None] * rng.random((1, D))
     labels = true.copy()
     labels[rng.random(N) < 0.1] = -1
     queries = rng.choice(N, 700, replace=False)
@@ -772,7 +780,7 @@ F16_CASES = [
     (1500, 136, 6, 6, 8, 0, False),        # short lists on the 16-lane kernel
     (1200, 140, 5, 9, 12, 600, False),
     (1200, 40, 4, 12, 3, 800, False),      # few seeds, large batches: most candidates are batch entries (two tiles, exact path)
-    (800, 160, 3, 15, 20, 0, False),       # the longest rows the shortlist stage takes
+    (800, 157, 3, 15, 20, 0, False),       # the longest rows the shortlist stage takes (157 + 3 bias columns = 160)
     (1000, 64, 4, 15, 20, 0, True),        # duplicated members: exact ties at the selection boundary -> exact path
 ]
 
