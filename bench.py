@@ -139,18 +139,6 @@ def main():
     qp_per_step = n_move * B
 
     ctx = _lib.Context(local_rank)
-    if use_dist and xdev is not None:
-        # the feature matrix crosses the host boundary ONCE (rank 0) and reaches the other
-        # GPUs by an RCCL broadcast over xGMI; every rank then keeps its own resident copy
-        xt = torch.empty((N, D), dtype=torch.float64, device=dev)
-        if rank == 0:
-            xt.copy_(torch.from_numpy(X))
-        dist.broadcast(xt, src=0)
-        torch.cuda.synchronize()
-        ctx.set_samples_device(xt.data_ptr(), N, D)
-        del xt
-    else:
-        ctx.set_samples(X)                                    # resident in HBM before timing
 
     # N > 1: contigs of every batch sharded across the ranks inside the C++ loop, label slices
     # exchanged with RCCL all-gathers.  The Python driver (torch.distributed all_reduce between
@@ -173,6 +161,12 @@ def main():
                 dist.barrier()
                 dist.destroy_process_group()
                 raise SystemExit(3)
+    if native:
+        # the feature matrix crosses the host boundary ONCE (rank 0) and reaches the other GPUs by the
+        # library's RCCL broadcast over xGMI (chb_bcast_samples); every rank then keeps its own resident copy
+        ctx.bcast_samples(X if rank == 0 else None, N, D, root=0)
+    else:
+        ctx.set_samples(X)                                    # resident in HBM before timing
 
     def one_step():
         if use_dist and not native:
@@ -204,6 +198,19 @@ def main():
     value = qp_per_step * args.steps / dt
     dom = {k: ctx.profile_get(k) for k in ("prefilter", "hull_qp")}     # measured INSIDE the timed region
     stats = ctx.fit_stats()
+    # evidence of the exchange the timed steps ran over: what RCCL itself reports for the communicator, and how the
+    # hull evaluations of the last timed step were spread over the ranks (disjoint slices: they add up)
+    evidence = None
+    if use_dist:
+        mine = {"rank": rank, "comm": ctx.comm_info(), "hull_evaluated_last_step": int(stats["hull_evaluated"]),
+                "hull_needed_last_step": int(stats["hull_needed"]), "rounds_last_step": int(stats["rounds"])}
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+        evidence = {"transport": allv[0]["comm"]["transport"],
+                    "comm_ranks_reported_by_rccl": [v["comm"]["comm_ranks"] for v in allv],
+                    "hull_evaluated_per_rank_last_step": [v["hull_evaluated_last_step"] for v in allv],
+                    "hull_needed_last_step": allv[0]["hull_needed_last_step"],
+                    "rounds_per_rank_last_step": [v["rounds_last_step"] for v in allv]}
 
     # ---- untimed pass with an event pair around every kernel: the full table
     names = ("prefilter", "rescore", "prefilter_update", "rescore_update", "query_norms", "topm_fallback", "topm_base",
@@ -461,7 +468,8 @@ def main():
                        "n_contigs": N, "dim": D, "bins": B, "neighbors": m, "movable": int(n_move),
                        "qp_per_step": int(qp_per_step), "batch": args.batch or 8192,
                        "generator": {"mix": args.mix, "sigma": args.sigma, "coverage_columns": S},
-                       "parallelism": (f"contig-sharded x{world}, " + ("RCCL all-gather in the C++ loop, X by RCCL broadcast"
+                       "parallelism_evidence": evidence,
+                       "parallelism": (f"contig-sharded x{world}, " + ("RCCL all-gather in the C++ loop, X by the library's RCCL broadcast (chb_bcast_samples)"
                                                                        if native else "torch.distributed all_reduce (Python driver)"))
                        if use_dist else "single GPU"},
             "roofline": roofline,

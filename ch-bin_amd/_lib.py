@@ -60,6 +60,9 @@ SIGNATURES = {
     "chb_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "chb_comm_destroy": (C.c_int, [C.c_void_p]),
     "chb_comm_init_hook": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "chb_bcast_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
+    "chb_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                C.POINTER(C.c_int)]),
     "chb_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "chb_profile_reset": (C.c_int, [C.c_void_p]),
     "chb_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
@@ -301,6 +304,25 @@ class Context:
 
     def comm_destroy(self):
         check(self._lib.chb_comm_destroy(self._h))
+
+    def bcast_samples(self, X, N, D, root=0):
+        """chb_set_samples for all ranks of the RCCL communicator: the root passes its host matrix, the others None;
+        the matrix crosses the host boundary once and reaches the other GPUs by an RCCL broadcast over xGMI."""
+        ptr = None
+        if X is not None:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            if X.shape != (int(N), int(D)):
+                raise ValueError("samples must be an N x D matrix")
+            ptr = X.ctypes.data_as(C.c_void_p)
+        check(self._lib.chb_bcast_samples(self._h, ptr, int(N), int(D), int(root)))
+        self.N, self.D = int(N), int(D)
+
+    def comm_info(self):
+        """{'rank', 'world', 'comm_ranks' (what RCCL reports for the communicator; 0 without one), 'transport'}"""
+        r, w, n, t = C.c_int(0), C.c_int(1), C.c_int(0), C.c_int(0)
+        check(self._lib.chb_comm_info(self._h, C.byref(r), C.byref(w), C.byref(n), C.byref(t)))
+        return {"rank": r.value, "world": w.value, "comm_ranks": n.value,
+                "transport": {0: "none", 1: "rccl", 2: "hook"}[t.value]}
 
     # measurement
     def profile_enable(self, on=True):

@@ -50,6 +50,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -75,8 +77,11 @@ RcclApi *rccl()
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
     api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+    api.Broadcast = (decltype(api.Broadcast))dlsym(api.lib, "ncclBroadcast");
+    api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString &&
+             api.Broadcast && api.CommCount;
     return api.ok ? &api : nullptr;
 }
 
@@ -741,20 +746,31 @@ int chb_destroy(chb_ctx *h)
     return CHB_OK;
 }
 
-static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D, bool from_device)
+// the resident copy X[N][Dp] (rows zero-padded to Dp): filled from `X` (host or device), or -- X == nullptr -- left to
+// be filled by the caller (chb_bcast_samples on a receiving rank)
+static int samples_upload(chb_ctx *h, const double *X, int64_t N, int64_t D, bool from_device)
 {
-    if (!h) return fail(CHB_EINVAL, "null context");
-    if (!X || N <= 0 || D <= 0) return fail(CHB_EINVAL, "samples must be a non-empty N x D matrix");
+    if (N <= 0 || D <= 0) return fail(CHB_EINVAL, "samples must be a non-empty N x D matrix");
     if (N >= (1LL << 31) - 64 || D > (1 << 20)) return fail(CHB_EUNSUPPORTED, "N or D too large");
     HIPCHK(hipSetDevice(h->dev));
     const int Dp = (int)((D + kKChunk - 1) / kKChunk) * kKChunk;
     HIPCHK(h->X.ensure((size_t)N * Dp));
-    if (Dp != D) HIPCHK(hipMemsetAsync(h->X.p, 0, sizeof(double) * (size_t)N * Dp, h->stream));
-    HIPCHK(hipMemcpy2DAsync(h->X.p, sizeof(double) * Dp, X, sizeof(double) * D, sizeof(double) * D,
-                            (size_t)N, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                            h->stream));
+    if (X != nullptr) {
+        if (Dp != D) HIPCHK(hipMemsetAsync(h->X.p, 0, sizeof(double) * (size_t)N * Dp, h->stream));
+        HIPCHK(hipMemcpy2DAsync(h->X.p, sizeof(double) * Dp, X, sizeof(double) * D, sizeof(double) * D,
+                                (size_t)N, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                h->stream));
+    }
     h->N = N; h->D = (int)D; h->Dp = Dp;
     h->fit_open = false; h->batch_open = false;
+    return CHB_OK;
+}
+
+// everything that is a function of the resident X alone (global mean, scale, query-side shadow rows)
+static int samples_finish(chb_ctx *h)
+{
+    const int64_t N = h->N, D = h->D;
+    const int Dp = h->Dp;
     // the shortlist stage (prefilter_kernels.hip) keeps its query fragments in registers: D <= 160
     h->shadow_ok = false;
     const int Dz = shadow_row_elems((int)D);
@@ -793,6 +809,14 @@ static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D,
     return CHB_OK;
 }
 
+static int set_samples_common(chb_ctx *h, const double *X, int64_t N, int64_t D, bool from_device)
+{
+    if (!h) return fail(CHB_EINVAL, "null context");
+    if (!X) return fail(CHB_EINVAL, "samples must be a non-empty N x D matrix");
+    const int rc = samples_upload(h, X, N, D, from_device);
+    return rc ? rc : samples_finish(h);
+}
+
 int chb_set_samples(chb_ctx *h, const double *X, int64_t N, int64_t D)
 {
     return set_samples_common(h, X, N, D, false);
@@ -801,6 +825,31 @@ int chb_set_samples(chb_ctx *h, const double *X, int64_t N, int64_t D)
 int chb_set_samples_device(chb_ctx *h, const double *X, int64_t N, int64_t D)
 {
     return set_samples_common(h, X, N, D, true);
+}
+
+int chb_bcast_samples(chb_ctx *h, const double *X, int64_t N, int64_t D, int root)
+{
+    if (!h) return fail(CHB_EINVAL, "null context");
+    if (!h->comm) return fail(CHB_ESTATE, "chb_bcast_samples needs chb_comm_init (RCCL)");
+    if (root < 0 || root >= h->world) return fail(CHB_EINVAL, "bad root");
+    if (h->rank == root && !X) return fail(CHB_EINVAL, "the root rank must pass the matrix");
+    int rc = samples_upload(h, h->rank == root ? X : nullptr, N, D, false);
+    if (rc) return rc;
+    // the padded resident copy goes out as it lies on the root: one RCCL broadcast over xGMI
+    NCCLCHK(rccl()->Broadcast(h->X.p, h->X.p, (size_t)N * (size_t)h->Dp, ncclDouble, root, h->comm, h->stream));
+    return samples_finish(h);
+}
+
+int chb_comm_info(chb_ctx *h, int *rank, int *world, int *comm_ranks, int *transport)
+{
+    if (!h) return fail(CHB_EINVAL, "null context");
+    if (rank) *rank = h->rank;
+    if (world) *world = h->world;
+    int cnt = 0;
+    if (h->comm && rccl()) NCCLCHK(rccl()->CommCount(h->comm, &cnt));
+    if (comm_ranks) *comm_ranks = cnt;
+    if (transport) *transport = h->comm ? 1 : (h->hook ? 2 : 0);
+    return CHB_OK;
 }
 
 int chb_pairwise_distance(chb_ctx *h, int64_t r0, int64_t r1, double *out)

@@ -154,6 +154,16 @@ int chb_comm_destroy(chb_ctx *h);
  * share one GPU, which RCCL refuses.  Called from inside chb_fit_cluster, between device synchronisations. */
 typedef int (*chb_allgather_fn)(void *user, const void *send, void *recv, size_t bytes);
 int chb_comm_init_hook(chb_ctx *h, int rank, int world, chb_allgather_fn fn, void *user);
+/* chb_set_samples for every rank of the communicator with ONE crossing of the host boundary: rank `root` passes its host
+ * matrix X[N][D] (cli/clustering.py:53), the other ranks pass NULL; the matrix is uploaded on `root`, broadcast to the
+ * other GPUs by RCCL over xGMI (109 MB at N = 100k, 1.17 GB at N = 1M) and every rank builds its own resident copy and
+ * shadow rows.  N and D must agree on all ranks.  Needs chb_comm_init (with the hook transport every rank simply calls
+ * chb_set_samples). */
+int chb_bcast_samples(chb_ctx *h, const double *X, int64_t N, int64_t D, int root);
+/* what the context's communicator really is: *rank / *world as given to chb_comm_init*, *comm_ranks = the rank count
+ * RCCL itself reports for the communicator (ncclCommCount; 0 without an RCCL communicator), *transport = 0 none,
+ * 1 RCCL, 2 host-staged hook.  Lets a benchmark line carry evidence of the exchange it ran over. */
+int chb_comm_info(chb_ctx *h, int *rank, int *world, int *comm_ranks, int *transport);
 
 /* ---- feature assembly: canonical k-mer frequency vectors.
  * Replaces the external seq2vec run of ch_bin/core/features/kmer_count.py:65-107 (and the

@@ -509,8 +509,8 @@ def test_cli_perform_clustering_matches_oracle(ctx, O, tmp_path, golden_dir, mon
 
 
 def test_native_comm_exchange_path_world1(O):
-    """The RCCL exchange path of chb_fit_cluster (communicator of one rank, all-gathers forced on):
-    same labels and winning distances as the plain path."""
+    """The RCCL exchange path of chb_fit_cluster (communicator of one rank, all-gathers forced on), with the samples
+    set through chb_bcast_samples: same labels and winning distances as the plain path."""
     from chbin_amd import _lib
     X, initial, _ = _synth(900, 136, 8, seed=31, sigma=6e-3, mix=0.6, n_seed=8)
     perms = _perms(initial, 4)
@@ -525,8 +525,12 @@ def test_native_comm_exchange_path_world1(O):
         else:
             os.environ["CHB_FORCE_GATHER"] = old
     try:
+        with pytest.raises(_lib.ChbError, match="chb_comm_init"):
+            c.bcast_samples(X, X.shape[0], X.shape[1])       # no communicator yet
+        assert c.comm_info() == {"rank": 0, "world": 1, "comm_ranks": 0, "transport": "none"}
         c.comm_init(_lib.Context.comm_unique_id(), 0, 1)
-        c.set_samples(X)
+        assert c.comm_info() == {"rank": 0, "world": 1, "comm_ranks": 1, "transport": "rccl"}
+        c.bcast_samples(X, X.shape[0], X.shape[1], root=0)   # the library's RCCL broadcast (one rank: a copy onto itself)
         got, its, _, mind = c.fit_cluster(8, initial, perms, 5, 4, batch=200, want_min_dist=True)
         assert its == its_o and np.array_equal(got, want)
         labels = initial.copy()

@@ -1,5 +1,5 @@
-"""World-size-2 run of the SHARDED C++ loop (chb_fit_cluster with q_lo/q_hi slices and all-gathers between
-rounds, csrc/chb_api.hip) on one GPU: two processes, one context each, exchange through the host-staged hook
+"""World-size-2 and -3 runs of the SHARDED C++ loop (chb_fit_cluster with q_lo/q_hi slices and all-gathers between
+rounds, csrc/chb_api.hip) on one GPU: one process and one context per rank, exchange through the host-staged hook
 (chb_comm_init_hook) carried by gloo.  RCCL refuses two ranks on one device, so this is how the loop that the
 driver runs over RCCL on 8 GPUs is exercised with more than one rank before it gets there: same slices, same
 exchange points, same first-change logic -- only the transport differs."""
@@ -32,15 +32,20 @@ def allgather(send):                      # np.uint8[bytes] -> np.uint8[world * 
     dist.all_gather(outs, t)
     return torch.cat(outs).numpy()
 
+CASES = [
+    (900, 136, 8, 5, 4, 6e-3, 0.6, 8, 200),        # overlapping bins: several rounds per batch
+    (3000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 0),   # SURVEY 8(d) generator
+    (700, 40, 6, 15, 3, 9e-3, 0.5, 20, 150),       # m = 15: fused 16-lane kernel (hull_select_qp16_kernel)
+    (10000, 136, 32, 5, 4, 1.5e-3, 0.0, None, 0),  # BASELINE configs[1] at its stated size (seed 0 as in test_gpu_configs)
+]
 res = {}
-for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate([
-        (900, 136, 8, 5, 4, 6e-3, 0.6, 8, 200),        # overlapping bins: several rounds per batch
-        (3000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 0),   # SURVEY 8(d) generator
-        (700, 40, 6, 15, 3, 9e-3, 0.5, 20, 150)]):     # m = 15: fused 16-lane kernel (hull_select_qp16_kernel)
-    X, initial, _ = synth.make_synthetic(N, D, B, seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
+for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate(CASES):
+    seed = 0 if N == 10000 else N + B
+    X, initial, _ = synth.make_synthetic(N, D, B, seed=seed, sigma=sigma, mix=mix, n_seed=n_seed)
     perms = synth.draw_permutations(initial, iters, seed=0)
     ctx = _lib.Context(0)
     ctx.comm_init_hook(rank, world, allgather)
+    assert ctx.comm_info() == {"rank": rank, "world": world, "comm_ranks": 0, "transport": "hook"}
     ctx.set_samples(X)
     lab, its, ch, mind = ctx.fit_cluster(B, initial, perms, m, iters, batch=batch, want_min_dist=True)
     st = ctx.fit_stats()
@@ -55,24 +60,25 @@ dist.destroy_process_group()
 """
 
 
-def test_sharded_cpp_loop_world2_one_gpu():
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_cpp_loop_more_than_one_rank_one_gpu(world):
     from oracle import oracle as O
     import chbin_amd
-    world = 2
     with tempfile.TemporaryDirectory() as td:
         script = os.path.join(td, "worker.py")
         open(script, "w").write(WORKER)
-        port = str(29500 + os.getpid() % 2000)
+        port = str(29500 + (os.getpid() + 7 * world) % 2000)
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs = [subprocess.Popen([sys.executable, script, ROOT, str(r), str(world), port,
                                    os.path.join(td, f"out{r}.npz")], env=env) for r in range(world)]
         for p in procs:
-            assert p.wait(timeout=600) == 0
+            assert p.wait(timeout=900) == 0
         outs = [np.load(os.path.join(td, f"out{r}.npz")) for r in range(world)]
-    for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate([
-            (900, 136, 8, 5, 4, 6e-3, 0.6, 8, 200), (3000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 0),
-            (700, 40, 6, 15, 3, 9e-3, 0.5, 20, 150)]):
-        X, initial, _ = chbin_amd.synth.make_synthetic(N, D, B, seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
+    ns = {}
+    exec(WORKER[WORKER.index("CASES = ["):WORKER.index("res = {}")], ns)       # the worker's own case table
+    for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate(ns["CASES"]):
+        seed = 0 if N == 10000 else N + B
+        X, initial, _ = chbin_amd.synth.make_synthetic(N, D, B, seed=seed, sigma=sigma, mix=mix, n_seed=n_seed)
         perms = chbin_amd.synth.draw_permutations(initial, iters, seed=0)
         want, its_o, _ = O.fit_cluster(X, B, initial, perms, m, iters)
         labels = initial.copy()
@@ -86,5 +92,5 @@ def test_sharded_cpp_loop_world2_one_gpu():
         ev = [int(outs[r][f"evaluated{case}"]) for r in range(world)]
         needed = int(outs[0][f"needed{case}"])
         assert all(e > 0 for e in ev) and sum(ev) >= needed
-        assert max(ev) <= 0.75 * sum(ev)                                             # neither rank did (nearly) all of it
-        assert int(outs[0][f"rounds{case}"]) == int(outs[1][f"rounds{case}"])
+        assert max(ev) <= (0.75 if world == 2 else 0.6) * sum(ev)                    # no rank did (nearly) all of it
+        assert len({int(outs[r][f"rounds{case}"]) for r in range(world)}) == 1
