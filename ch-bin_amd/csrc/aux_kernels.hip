@@ -63,11 +63,13 @@ __global__ void count_base_kernel(const int *labels, int *inb, int N, int B, int
 // bin_ptr / cursor = exclusive scan of cnt; pad_ptr (optional) = the same with every count rounded
 // up to a multiple of 32 (the padded layout of the shortlist stage).  One block of 256 threads.
 __global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int *bin_ptr, int *cursor, int *pad_ptr,
-                                                    int *zero_me, Gate gate)
+                                                    int *zero_me, SegPlan seg, int *stats, Gate gate)
 {
     CHB_GATE(gate);
     if (zero_me != nullptr && threadIdx.x == 0) *zero_me = 0;   // (the fallback list's counter: saves a launch)
     __shared__ int part[256], ppart[256];
+    __shared__ int s_tot_pad, s_max_tiles, s_ng, s_ni;
+    if (threadIdx.x == 0) { s_max_tiles = 0; s_ng = 0; s_ni = 0; }
     const int per = (B + 255) / 256;
     const int b0 = min(B, (int)threadIdx.x * per), b1 = min(B, b0 + per);
     int s = 0, sp = 0;
@@ -95,15 +97,44 @@ __global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int *bin_ptr
         if (l == 63) {
             bin_ptr[B] = run;   // (the totals)
             if (pad_ptr) pad_ptr[B] = prun;
+            s_tot_pad = prun;
         }
     }
     __syncthreads();
     int run = part[threadIdx.x], prun = ppart[threadIdx.x];
+    const long long tot_tiles = s_tot_pad / 32;
     for (int b = b0; b < b1; ++b) {
         bin_ptr[b] = run; cursor[b] = run;
         if (pad_ptr) pad_ptr[b] = prun;
+        const int ntile = (cnt[b] + 31) / 32;
+        if (stats != nullptr) atomicMax(&s_max_tiles, ntile);
+        if (seg.gflag != nullptr) {
+            // the batch's segment plan: a bin far larger than the rest becomes up to 16 work items of its own
+            int g = -1;
+            if (seg.launch && ntile > kSegMinTiles && (long long)ntile * B > 4 * tot_tiles) {
+                const int len = max(kSegLenTiles, (ntile + 15) / 16);
+                const int ns = (ntile + len - 1) / len;
+                g = atomicAdd(&s_ng, 1);
+                if (g < seg.gcap) {
+                    const int i0 = atomicAdd(&s_ni, ns);
+                    for (int sgi = 0; sgi < ns; ++sgi)
+                        seg.items[i0 + sgi] = make_int4(b, sgi * len, min(ntile, (sgi + 1) * len),
+                                                        (g << 8) | (sgi << 4) | (ns - 1));
+                } else {
+                    g = -1;
+                }
+            }
+            seg.gflag[b] = g;
+        }
         run += cnt[b]; prun += (cnt[b] + 31) / 32 * 32;
         cnt[b] = 0;   // left clean for the next count (launch_bucket_base needs no separate fill)
+    }
+    if (seg.gflag != nullptr || stats != nullptr) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (seg.nseg != nullptr) *seg.nseg = s_ni;
+            if (stats != nullptr) { stats[0] = s_max_tiles; stats[1] = (int)tot_tiles; }
+        }
     }
 }
 
@@ -525,14 +556,15 @@ void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, in
 
 void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int *bin_ptr,
                         int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s, const int *open_bq,
-                        int open_K, int *open_lab_old)
+                        int open_K, int *open_lab_old, const SegPlan *seg, int *stats)
 {
     // (cnt is all zero here: allocated zeroed, and scan_kernel clears what it has read)
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt, open_bq,
                        open_K, open_lab_old, g_gate);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr, zero_me, g_gate);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr, zero_me,
+                       seg ? *seg : SegPlan{}, stats, g_gate);
     hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * sizeof(int), s, labels, inb, N, B, cursor, memb_id, g_gate);
 }
 

@@ -199,8 +199,9 @@ struct chb_ctx {
     bool batch_open = false;
     DevBuf<int> bq, lab_old, lab_prev, lab_new, first_change;
     int *bq_cur = nullptr;      // the open batch's sample indices: bq.p, or a window of perm (no copy)
-    int *fc_host = nullptr;     // pinned landing places of the two first_change slots
-    int *fc_cur = nullptr;      // first_change slot of the open batch (first_change.p + 0 / 1)
+    int *fc_host = nullptr;     // pinned landing places of the two first_change slots (4 ints each, as on the device)
+    int *fc_cur = nullptr;      // slot of the open batch (first_change.p + 0 / 4): {first changed position, tiles of the
+                                // batch's largest bin, tiles of all bins, -}: the bin sizes ride home with the verdict
     hipEvent_t fc_event[2] = {nullptr, nullptr};
     bool speculate = true;      // CHB_SPECULATE=0: never enqueue the next batch ahead of the convergence test
     bool argmin_in_place = false;   // chb_fit_cluster without exchange: argmin also stores the label to lab_prev
@@ -233,6 +234,14 @@ struct chb_ctx {
     bool pf_fit = false;        // this fit uses the shortlist stage (use_prefilter, D <= 160, m <= 16)
     bool lists_valid = false;   // the open batch was started with need_lists (chb_topm_per_bin)
     DevBuf<int> candu[2], candu_cnt[2], slow, n_slow;
+    // bins far larger than the rest are cut into segments for the shortlist stage (SegPlan, prefilter_kernels.hip): plan
+    // buffers, and the bin sizes last seen by the host (they come home with the rounds' verdicts)
+    DevBuf<int> seg_nseg, seg_gflag;
+    DevBuf<int4> seg_items;
+    DevBuf<float> seg_lists;
+    int seg_gcap = 0;
+    int hint_max_tiles = 0, hint_total_tiles = 0;
+    bool allow_segments = true;   // CHB_SEGMENTS=0: never (A/B tests)
     DevBuf<float> tau;
     // scratch for the indexed / explicit-point entry points
     DevBuf<int> xq, xhull, xcnt;
@@ -242,6 +251,7 @@ struct chb_ctx {
     std::map<std::string, ProfEntry> prof_acc;
     std::vector<Pending> pending;
     int64_t stats[4] = {0, 0, 0, 0};
+    int64_t stats_seg_batches = 0;   // batches of the last fit that ran the segment launches
     // multi-GPU: one context per process per GPU, RCCL communicator over all ranks
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -327,7 +337,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->lab_old.ensure(K));
     HIPCHK(h->lab_prev.ensure(Kpad));
     HIPCHK(h->lab_new.ensure(Kpad));
-    HIPCHK(h->first_change.ensure(2));
+    HIPCHK(h->first_change.ensure(8));
     h->fc_cur = h->first_change.p;
     HIPCHK(h->mind.ensure(Kpad));
     HIPCHK(h->mind2.ensure(Kpad));
@@ -364,6 +374,11 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->qn.ensure(K * B * 2));
         HIPCHK(h->pk.ensure((size_t)h->N + 32 * B, B, (size_t)h->Dz));
         HIPCHK(h->pk2.ensure(2 * K + 32 * B, B, (size_t)h->Dz));
+        h->seg_gcap = (int)std::min<size_t>(64, B / 4 + 1);
+        HIPCHK(h->seg_nseg.ensure(1));
+        HIPCHK(h->seg_gflag.ensure(B));
+        HIPCHK(h->seg_items.ensure(16 * (size_t)h->seg_gcap));
+        HIPCHK(h->seg_lists.ensure((size_t)h->seg_gcap * 16 * K * (size_t)shortlist_list_len((int)m)));
         if (h->fused) {
             for (int i = 0; i < 2; ++i) {
                 HIPCHK(h->candu[i].ensure(K * B * (size_t)kCandCapU));
@@ -394,10 +409,17 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     h->fused = h->allow_fused && h->pf_fit && h->pf_base && h->pf_update && fused_supported(m, h->Dp);
     HIPCHK(h->pin_a.ensure((size_t)h->N));
     int *lab = h->pin_a.p;
+    std::vector<int64_t> bin_size((size_t)B, 0);
     for (int64_t i = 0; i < h->N; ++i) {
         const int64_t v = initial[i];
         if (v >= B) return fail(CHB_EINVAL, "initial_bins contains a label >= num_clusters");
         lab[(size_t)i] = v < 0 ? -1 : (int)v;
+        if (v >= 0) ++bin_size[(size_t)v];
+    }
+    {   // bin sizes as the first batch will see them (later ones come home with the rounds' verdicts)
+        int64_t mx = 0, tot = 0;
+        for (int64_t c = 0; c < B; ++c) { const int64_t t = (bin_size[(size_t)c] + 31) / 32; mx = std::max(mx, t); tot += t; }
+        h->hint_max_tiles = (int)mx; h->hint_total_tiles = (int)std::min<int64_t>(tot, 0x7fffffff);
     }
     HIPCHK(h->labels.ensure((size_t)h->N));
     HIPCHK(h->inb.ensure((size_t)h->N));
@@ -435,11 +457,23 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
     h->K = K; h->q_lo = q_lo; h->q_hi = q_hi;
     h->round_in_batch = 0;
     hipStream_t s = h->stream;
+    // segmented bins: the plan is made by the CSR scan on the device, but only if the host will also enqueue the two
+    // segment launches -- which it does when the bin sizes it saw last (one or two batches old) say that a bin may
+    // have more than kSegMinTiles tiles and four times the average
+    SegPlan sp{};
+    const bool pf_base_path = h->pf_fit && h->pf_base && h->cand.p;
+    if (pf_base_path && h->seg_gflag.p) {
+        sp.nseg = h->seg_nseg.p; sp.items = h->seg_items.p; sp.gflag = h->seg_gflag.p; sp.lists = h->seg_lists.p;
+        sp.cap = 16 * h->seg_gcap; sp.gcap = h->seg_gcap;
+        const long long est = (long long)h->hint_max_tiles * 3 / 2 + 8;
+        sp.launch = h->allow_segments && est > kSegMinTiles && est * h->B > 3LL * std::max(1, h->hint_total_tiles);
+    }
     {
         // (the batch is opened -- labels remembered, members marked -- inside the CSR count's launch)
         Timed t(h, "bucket", (double)h->N);
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
-                           h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, h->nflag.p, s, h->bq_cur, K, h->lab_old.p);
+                           h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, h->nflag.p, s, h->bq_cur, K, h->lab_old.p,
+                           sp.gflag ? &sp : nullptr, h->fc_cur + 1);
     }
     TopmArgs a{};
     a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = q_lo; a.pos_end = q_hi;
@@ -469,6 +503,8 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
         pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.cand_cap = kCandCap; pa.overflow = h->overflow.p;
         if (fusedp) pa.tau_out = h->tau.p;
+        pa.seg = sp;
+        if (sp.launch) h->stats_seg_batches += 1;
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
             pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;   // (counter reset by the CSR scan / the batch CSR kernel)
@@ -714,6 +750,7 @@ int chb_create(int device_id, chb_ctx **out)
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->fc_host, 64, hipHostMallocDefault);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->fc_event[i], hipEventDisableTiming);
     if (const char *ev = getenv("CHB_SPECULATE")) h->speculate = atoi(ev) != 0;
+    if (const char *ev = getenv("CHB_SEGMENTS")) h->allow_segments = atoi(ev) != 0;
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
     return CHB_OK;
@@ -739,6 +776,7 @@ int chb_destroy(chb_ctx *h)
     h->active.release(); h->n_active.release(); h->act_blk.release();
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
     h->slow.release(); h->n_slow.release(); h->tau.release();
+    h->seg_nseg.release(); h->seg_gflag.release(); h->seg_items.release(); h->seg_lists.release();
     (void)hipStreamDestroy(h->stream);
     if (h->fc_host) (void)hipHostFree(h->fc_host);
     for (int i = 0; i < 2; ++i) if (h->fc_event[i]) (void)hipEventDestroy(h->fc_event[i]);
@@ -1029,6 +1067,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     if (rc) return rc;
     hipStream_t s = h->stream;
     memset(h->stats, 0, sizeof(h->stats));
+    h->stats_seg_batches = 0;
 
     // (fit_begin_impl left the converted initial labels in pin_a and has synchronised the stream)
     std::vector<int> prev(h->pin_a.p, h->pin_a.p + N), cur;
@@ -1101,13 +1140,15 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 launch_fill_i32(h->fc_cur, g.K, 1, s);
                 launch_first_change(h->lab_new.p, h->lab_prev.p, active, g.K, h->fc_cur, s);
             }
-            HIPCHK(hipMemcpyAsync(h->fc_host + slot, h->fc_cur, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(h->fc_host + 4 * slot, h->fc_cur, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(h->fc_event[slot], s));
             return CHB_OK;
         };
         auto wait_round = [&](const Geom &g, int active, int slot, int *f) -> int {
             HIPCHK(hipEventSynchronize(h->fc_event[slot]));
-            *f = h->fc_host[slot];
+            *f = h->fc_host[4 * slot];
+            // (bin sizes of that batch, for the segment decision of the batches still to be enqueued)
+            h->hint_max_tiles = h->fc_host[4 * slot + 1]; h->hint_total_tiles = h->fc_host[4 * slot + 2];
             // positions [active, K) now carry this round's labels (single rank: the argmin kernel has
             // already written them to lab_prev)
             if (xchg)
@@ -1118,7 +1159,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         // batch start + guess + round 0, nothing read back
         auto open_batch = [&](const Geom &g, int slot) -> int {
             h->bq_cur = h->perm.p + g.t0;   // the batch's sample indices: a window of the sweep's permutation
-            h->fc_cur = h->first_change.p + slot;
+            h->fc_cur = h->first_change.p + 4 * slot;
             h->hint_base_members = (double)((it == 0) ? assigned0 + g.t0 : labelled - g.K);
             h->hint_batch_entries = (double)((it == 0) ? g.K : 2 * g.K);
             h->argmin_in_place = !xchg;
@@ -1171,7 +1212,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             Snap snap{};
             if (spec) {
                 snap = save();
-                g_gate = Gate{h->first_change.p + slot, K};   // "this batch's round 0 changed nothing"
+                g_gate = Gate{h->first_change.p + 4 * slot, K};   // "this batch's round 0 changed nothing"
                 rc = batch_commit_dev(h, h->lab_prev.p);
                 if (rc) return rc;
                 rc = open_batch(geom_at(t1), slot ^ 1);
@@ -1635,6 +1676,7 @@ int chb_counter(chb_ctx *h, const char *name, int64_t *out)
         return CHB_OK;
     }
     if (!strcmp(name, "fused_enabled")) { *out = h->fused ? 1 : 0; return CHB_OK; }
+    if (!strcmp(name, "segment_batches")) { *out = h->stats_seg_batches; return CHB_OK; }
     if (!strcmp(name, "last_batch_k")) { *out = h->K; return CHB_OK; }
     if (!strcmp(name, "prefilter_enabled")) { *out = (h->use_prefilter && h->shadow_ok) ? 1 : 0; return CHB_OK; }
     return fail(CHB_EINVAL, "unknown counter");

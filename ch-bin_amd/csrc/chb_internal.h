@@ -76,6 +76,7 @@ struct MemberPack {
     float4 *bb;               // [B] {largest rho, largest ||zh||, largest amax, largest residual of the bias pieces}
                               // (the batch-entry pack accumulates the largest ||zh||^2 in .y; its .w is unused)
 };
+int shortlist_list_len(int m);  // entries per (query, segment) list of SegPlan::lists for num_neighbors = m
 int shadow_row_elems(int D);   // Dz: 144 or 160, at least three spare columns (0: D too large for the shortlist stage)
 // mu_g = column means (deterministic two-pass sum), *rmax = float bits of max |x - mu_g|
 void launch_global_center(const double *X, int N, int D, int Dp, double *part, int part_blocks, double *mu_g,
@@ -103,6 +104,20 @@ void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const i
                        int B, int rows_hint, const MemberPack &P, const double *X, int D, int Dp, const int *bq,
                        int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s);
 
+// Plan of the bins that are cut into segments for the shortlist stage (see shortlist_kernel, SEG): made on the device
+// by the CSR scan of the batch start, consumed by the three shortlist launches of the batch.
+struct SegPlan {
+    int *nseg = nullptr;     // [1] segment items of this batch
+    int4 *items = nullptr;   // [cap] {bin, first tile, end tile, giant slot << 8 | segment << 4 | (segments - 1)}
+    int *gflag = nullptr;    // [B] giant slot of a segmented bin, -1 otherwise
+    float *lists = nullptr;  // [giant slots][16][Kcap][ML] phase 1 -> phase 2: the m best accumulators per segment
+    int cap = 0;             // capacity of items (16 per giant slot)
+    int gcap = 0;            // giant slots
+    bool launch = false;     // host: this batch runs the two segment launches (else no bin is marked)
+};
+constexpr int kSegMinTiles = 256;   // a bin is segmented if it has more tiles than this AND more than 4x the average
+constexpr int kSegLenTiles = 128;   // shortest segment (a bin has at most 16)
+
 struct ShortlistArgs {
     const unsigned short *Gs;  // [N][Dz] query-side rows
     const float2 *gq;          // [N]
@@ -127,6 +142,7 @@ struct ShortlistArgs {
     int *overflow;   // [1] number of (bin, position) pairs whose shortlist overflowed
     int *flaglist;   // work items (query tile of 64, bin) whose shortlist overflowed, for launch_topm_flagged ...
     int *nflag;      // ... and their number (zeroed by the caller before the launch)
+    SegPlan seg;         // base mode: segmented bins (seg.gflag == nullptr: none)
     float gamma;         // accumulation error factor g (set by launch_shortlist)
     int tile_best_min;   // bins with at least this many tiles learn tau from per-tile bests (ditto)
 };
@@ -222,9 +238,12 @@ void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, in
 // (pad_ptr, optional: the same CSR with every bin padded to a multiple of 32 rows -> MemberPack)
 // (zero_me, optional: one int the scan also resets -- the fallback list's counter of the coming shortlist launch)
 // (open_bq, optional: the batch is opened in the count's launch: lab_old[i] = labels[bq[i]], inb[bq[i]] = i)
+// (seg + stats, optional: the scan also makes the batch's segment plan -- only if seg->launch -- and leaves
+//  stats[0] = tiles of the largest bin, stats[1] = tiles of all bins, for the host's decision about the NEXT batches)
 void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int *bin_ptr,
                         int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s,
-                        const int *open_bq = nullptr, int open_K = 0, int *open_lab_old = nullptr);
+                        const int *open_bq = nullptr, int open_K = 0, int *open_lab_old = nullptr,
+                        const SegPlan *seg = nullptr, int *stats = nullptr);
 // CSR of the batch's own members: earlier positions under lab_prev, later positions under lab_old
 // (also starts the round's scalars: *first_change = K, *n_slow = 0, *nflag = 0 where the pointers are non-null)
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,

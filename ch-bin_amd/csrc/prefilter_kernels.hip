@@ -569,11 +569,21 @@ __device__ __forceinline__ void list_insert_desc(float (&l)[ML], float v)
     }
 }
 
-template <int ML, bool UPD, int KS>
+// SEG (base mode only) -- bins much larger than the rest are not streamed by one workgroup per query tile (a bin of
+// 40k members is a 1,245-tile stream, twice, while the other workgroups have long finished) but cut into up to 16
+// SEGMENTS that run as work items of their own, in two launches:
+//   SEG = 0: the ordinary launch; skips the bins the batch's plan (a.seg.gflag) marks as segmented;
+//   SEG = 1: one sweep over the segment's tiles, the m best accumulators of every (query, segment) go to a.seg.lists;
+//   SEG = 2: merges the lists of ALL segments of the bin (members of different segments are distinct, so the m-th best
+//            of the union is exactly what one workgroup streaming the whole bin would have found), derives tau and
+//            shortlists the segment's members; segments append to the same (query, bin) shortlist through its
+//            global counter.
+template <int ML, bool UPD, int KS, int SEG = 0>
 __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
                                                                          int bpw, int *flags64, int nqt64, Gate gate)
 {
     CHB_GATE(gate);
+    static_assert(SEG == 0 || !UPD, "segments exist for base members only");
     constexpr int CPR = 2 * KS;              // 16-byte chunks per shadow row
     constexpr int ROWB = 32 * KS;            // bytes per shadow row
     constexpr int TILEB = kPfP * ROWB;       // one member tile
@@ -585,15 +595,26 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
     unsigned *sPool = reinterpret_cast<unsigned *>(smem + NBUF * BUFB);   // [kPfW][kPoolW]
     int *sCnt = reinterpret_cast<int *>(sPool + kPfW * kPoolW);           // [kPfQ]
     float *sTau = reinterpret_cast<float *>(sCnt + kPfQ);                 // [kPfQ] tau of the bin (parked: no register)
+    int *sGb = reinterpret_cast<int *>(sTau + kPfQ);                      // [kPfQ] SEG = 2: global base of a flush
 
     // consecutive workgroups alternate over the 8 XCDs: give each XCD a contiguous range of work
     // items (bins-major), so that the member tiles of a bin stay in one L2
-    const int total = nqt * nchunk;
+    // (SEG > 0: the work items are the plan's segment items, their number is read from the device)
+    const int nitem = SEG == 0 ? nchunk : min(*a.seg.nseg, a.seg.cap);
+    const int total = nqt * nitem;
     const int per = (total + 7) >> 3;
+    if ((int)(blockIdx.x >> 3) >= per) return;
     const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (W >= total) return;
     const int chunk = W / nqt, qt = W - chunk * nqt;
-    const int c0 = chunk * bpw, c1 = min(a.B, c0 + bpw);
+    int c0 = chunk * bpw, c1 = min(a.B, c0 + bpw);
+    int seg_tb = 0, seg_te = 0x3fffffff;   // tile window inside the bin (segments)
+    int seg_g = 0, seg_i = 0, seg_n = 1;   // giant-bin slot, segment number, segments of the bin
+    if (SEG != 0) {
+        const int4 itv = a.seg.items[chunk];
+        c0 = itv.x; c1 = c0 + 1; seg_tb = itv.y; seg_te = itv.z;
+        seg_g = itv.w >> 8; seg_i = (itv.w >> 4) & 15; seg_n = (itv.w & 15) + 1;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -640,7 +661,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
     const unsigned char *zall = reinterpret_cast<const unsigned char *>(a.P.Z);
 
     // ---- issue side of the tile stream: (bin ic, sweep isw, tile it), two tiles ahead of the consumer
-    int ic = c0, it = 0, isw = UPD ? 1 : 0, ibuf = 0, n_issued = 0;
+    int ic = c0, it = 0, isw = (UPD || SEG == 2) ? 1 : 0, ibuf = 0, n_issued = 0;
     int irow0 = 0, int_ = 0;   // first padded row and tile count of bin ic
     bool ivalid = false;
     // move to the first / next non-empty bin
@@ -650,6 +671,8 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
         while (ic < c1) {                                                                          \
             irow0 = a.P.pad_ptr[ic];                                                               \
             int_ = (a.P.pad_ptr[ic + 1] - irow0) / kPfP;                                           \
+            if (SEG == 0 && !UPD && a.seg.gflag != nullptr && a.seg.gflag[ic] >= 0) int_ = 0;     \
+            if (SEG != 0) { irow0 += seg_tb * kPfP; int_ = min(int_, seg_te) - seg_tb; }           \
             if (int_ > 0) { ivalid = true; break; }                                                \
             ++ic;                                                                                  \
         }                                                                                          \
@@ -676,8 +699,8 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
         if (++ibuf == NBUF) ibuf = 0;                                                              \
         if (++it == int_) {                                                                        \
             it = 0;                                                                                \
-            if (!UPD && isw == 0) isw = 1;                                                         \
-            else { isw = UPD ? 1 : 0; ++ic; CHB_SL_ISSUE_SEEK() }                                  \
+            if (!UPD && SEG == 0 && isw == 0) isw = 1;                                             \
+            else { isw = (UPD || SEG == 2) ? 1 : 0; ++ic; CHB_SL_ISSUE_SEEK() }                    \
         }                                                                                          \
     }
     CHB_SL_ISSUE_SEEK()
@@ -699,22 +722,46 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 
     // parked entries -> the queries' shortlists (entry = query of this wavefront, member offset in the
     // bin); the per-query counters keep running, so the pool can be emptied in the middle of a bin
+    // (SEG = 2: the shortlist is shared with the bin's other segments -- the parked entries are counted per query
+    //  first, one global atomic per query reserves their places, then they are written behind that base)
 #define CHB_SL_FLUSH()                                                                             \
     {                                                                                              \
         const int mb_ = a.bin_ptr[c];                                                              \
         const int npark_ = wcnt < kPoolW ? wcnt : kPoolW;                                          \
+        if (SEG == 2) {                                                                            \
+            for (int i = lane; i < npark_; i += 64)                                                \
+                atomicAdd(&sCnt[32 * w + (int)(sPool[w * kPoolW + i] >> 27)], 1);                  \
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                 \
+            if (h == 0) {                                                                          \
+                const int nq_ = sCnt[32 * w + col];                                                \
+                int gb_ = 0;                                                                       \
+                if (nq_ > 0 && qvalid) gb_ = atomicAdd(&a.cand_cnt[slot], nq_);                    \
+                seg_over = seg_over || gb_ + nq_ > a.cand_cap;                                     \
+                sGb[32 * w + col] = gb_;                                                           \
+                sCnt[32 * w + col] = 0;                                                            \
+            }                                                                                      \
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                 \
+        }                                                                                          \
         for (int i = lane; i < npark_; i += 64) {                                                  \
             const unsigned en = sPool[w * kPoolW + i];                                             \
             const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));                     \
-            const int off = atomicAdd(&sCnt[32 * w + qc], 1);                                      \
+            int off = atomicAdd(&sCnt[32 * w + qc], 1);                                            \
+            if (SEG == 2) off += sGb[32 * w + qc];                                                 \
             if (off < a.cand_cap)                                                                  \
                 a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * a.cand_cap + off] = a.memb_id[mb_ + e]; \
+        }                                                                                          \
+        if (SEG == 2) {                                                                            \
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                 \
+            if (h == 0) sCnt[32 * w + col] = 0;                                                    \
         }                                                                                          \
     }
     int cbuf = 0, n_consumed = 0;
     for (int c = c0; c < c1; ++c) {
         const int row0 = a.P.pad_ptr[c];
-        const int ntile = (a.P.pad_ptr[c + 1] - row0) / kPfP;
+        int ntile = (a.P.pad_ptr[c + 1] - row0) / kPfP;
+        if (SEG == 0 && !UPD && a.seg.gflag != nullptr && a.seg.gflag[c] >= 0) continue;   // the segment launches' bin
+        if (SEG != 0) ntile = min(ntile, seg_te) - seg_tb;
+        bool seg_over = false;   // SEG = 2: a reservation went past the shortlist's capacity
         const size_t slot = (size_t)c * a.Kcap + (qvalid ? qpos : a.pos_end - 1);
         // ---- per-(query, bin) bounds
         float4 bb = a.P.bb[c];                            // {rho_bin, snb, Bmax, -}
@@ -750,20 +797,31 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
             }
         }
         if (h == 0) sCnt[32 * w + col] = 0;
-        const bool tile_best = ntile >= a.tile_best_min;
+        const bool tile_best = SEG != 0 || ntile >= a.tile_best_min;
         int wcnt = 0;   // entries parked by this wavefront and not yet written out (wave-uniform)
+        if (SEG == 2) {
+            // the m best accumulators of every segment of this bin (phase-1 launch): their union's m-th best
+            float *sl = a.seg.lists + ((size_t)seg_g * 16 * a.Kcap + (qvalid ? qpos : a.pos_end - 1)) * ML;
+            for (int sg = 0; sg < seg_n; ++sg)
+#pragma unroll
+                for (int i = 0; i < ML; ++i)
+                    list_insert_desc<ML>(lb, i >= ML - m ? sl[(size_t)sg * a.Kcap * ML + i] : -INFINITY);
+        }
 
-        for (int sweep = UPD ? 1 : 0; sweep < 2; ++sweep) {
+        for (int sweep = (UPD || SEG == 2) ? 1 : 0; sweep < (SEG == 1 ? 1 : 2); ++sweep) {
             const float rgs = (sweep ? rg : -rg) * (1.0f + kSlack);
             if (!UPD && sweep == 1) {
                 // end of sweep 0: m-th smallest t over BOTH lane halves -> tau -> thr2
+                // (SEG = 2: both halves hold the same merged list of all segments already)
                 float mg[ML];
 #pragma unroll
                 for (int i = 0; i < ML; ++i) mg[i] = lb[i];
+                if (SEG != 2) {
 #pragma unroll
-                for (int i = 0; i < ML; ++i) {
-                    const float o = __shfl_xor(lb[i], 32, 64);
-                    list_insert_desc<ML>(mg, i >= ML - m ? o : -INFINITY);   // (not the pinned slots twice)
+                    for (int i = 0; i < ML; ++i) {
+                        const float o = __shfl_xor(lb[i], 32, 64);
+                        list_insert_desc<ML>(mg, i >= ML - m ? o : -INFINITY);   // (not the pinned slots twice)
+                    }
                 }
                 const float ms = mg[ML - 1];
                 float tau = INFINITY;
@@ -881,7 +939,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                         CHB_SL_FLUSH()
                         wcnt = 0;
                     }
-                    const unsigned ebase = ent0 + (unsigned)(ct * kPfP);
+                    const unsigned ebase = ent0 + (unsigned)((ct + seg_tb) * kPfP);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const bool hit = acc[r] >= thr2;
@@ -902,14 +960,35 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
             }
         }
 
+        if (SEG == 1) {
+            // ---- end of the segment (phase 1): its m best accumulators over BOTH lane halves go out; segment 0 also
+            // empties the bin's shortlist counters for the phase-2 launch
+            float mg[ML];
+#pragma unroll
+            for (int i = 0; i < ML; ++i) mg[i] = lb[i];
+#pragma unroll
+            for (int i = 0; i < ML; ++i) {
+                const float o = __shfl_xor(lb[i], 32, 64);
+                list_insert_desc<ML>(mg, i >= ML - m ? o : -INFINITY);
+            }
+            if (qvalid && h == 0) {
+                float *sl = a.seg.lists + (((size_t)seg_g * 16 + seg_i) * a.Kcap + qpos) * ML;
+#pragma unroll
+                for (int i = 0; i < ML; ++i) sl[i] = mg[i];
+                if (seg_i == 0) a.cand_cnt[slot] = 0;
+            }
+            continue;
+        }
         // ---- end of the bin: write the parked entries out
         CHB_SL_FLUSH()
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
         if (qvalid && h == 0) {
-            a.cand_cnt[slot] = ccount < a.cand_cap ? ccount : a.cand_cap;
-            if (!UPD && a.tau_out != nullptr) a.tau_out[slot] = sTau[32 * w + col];
-            if (ccount > a.cand_cap || wcnt > kPoolW) {
+            // (SEG = 2: the bin's counter is the sum of its segments' reservations; the last one past the capacity
+            //  flags the pair, and the brute-force fallback then rewrites list and count)
+            if (SEG != 2) a.cand_cnt[slot] = ccount < a.cand_cap ? ccount : a.cand_cap;
+            if (!UPD && a.tau_out != nullptr && (SEG != 2 || seg_i == 0)) a.tau_out[slot] = sTau[32 * w + col];
+            if (ccount > a.cand_cap || wcnt > kPoolW || seg_over) {
                 atomicAdd(a.overflow, 1);
                 const int fi = c * nqt64 + (qpos - a.pos_begin) / kQTile;
                 if (atomicExch(&flags64[fi], 1) == 0) a.flaglist[atomicAdd(a.nflag, 1)] = fi;
@@ -923,7 +1002,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 
 static size_t shortlist_lds_bytes(int ks, int ml)
 {
-    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 2 * kPfQ * 4;
+    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 3 * kPfQ * 4;
 }
 
 template <int ML, bool UPD>
@@ -950,9 +1029,29 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
     else
         hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(64 * kPfW), shortlist_lds_bytes(10, ML), s, a,
                            nqt, nchunk, bpw, flags64, nqt64, g_gate);
+    if constexpr (!UPD) {
+        // the segmented bins of this batch (usually none: the host only asks for these launches when the last batches'
+        // bin sizes say a bin may qualify): phase 1 (m best accumulators per segment), phase 2 (shortlists)
+        if (a.seg.gflag != nullptr && a.seg.launch) {
+            const int gseg = ((nqt * a.seg.cap + 7) / 8) * 8;
+            if (a.Dz == 144) {
+                hipLaunchKernelGGL((shortlist_kernel<ML, false, 9, 1>), dim3(gseg), dim3(64 * kPfW), shortlist_lds_bytes(9, ML), s,
+                                   a, nqt, 0, 1, flags64, nqt64, g_gate);
+                hipLaunchKernelGGL((shortlist_kernel<ML, false, 9, 2>), dim3(gseg), dim3(64 * kPfW), shortlist_lds_bytes(9, ML), s,
+                                   a, nqt, 0, 1, flags64, nqt64, g_gate);
+            } else {
+                hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 1>), dim3(gseg), dim3(64 * kPfW), shortlist_lds_bytes(10, ML), s,
+                                   a, nqt, 0, 1, flags64, nqt64, g_gate);
+                hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 2>), dim3(gseg), dim3(64 * kPfW), shortlist_lds_bytes(10, ML), s,
+                                   a, nqt, 0, 1, flags64, nqt64, g_gate);
+            }
+        }
+    }
 }
 
 }  // namespace
+
+int shortlist_list_len(int m) { return m <= 5 ? 5 : (m <= 8 ? 8 : 16); }
 
 int shadow_row_elems(int D) { return D + kBiasCols <= 144 ? 144 : (D + kBiasCols <= 160 ? 160 : 0); }
 

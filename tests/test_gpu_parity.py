@@ -880,3 +880,78 @@ def test_fit_cluster_rejects_bad_permutations(ctx, O):
     want, its_o, _ = O.fit_cluster(X, 4, initial, perms, 5, 3)
     got, its, _ = ctx.fit_cluster(4, initial, perms, 5, 3)
     assert its == its_o and np.array_equal(got, want)
+
+
+def _ctx_env(env):
+    from chbin_amd import _lib
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return _lib.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("m", [5, 15])
+def test_segmented_giant_bin(O, m):
+    """One bin far larger than the rest (30k of 40k contigs: 938 member tiles, the others ~50): the shortlist stage cuts it
+    into segments (two extra launches: per-segment best lists, then shortlists against their union's m-th best).
+    Whole fits must equal a context that never segments (CHB_SEGMENTS=0); the selection under the final labels must equal
+    the brute-force kernel's lists; the segment launches must really have run."""
+    from chbin_amd import _lib
+    N, D, Bt = 40_000, 136, 24
+    X, initial_t, true_t = _synth(N, D, Bt, seed=5, sigma=2e-3, mix=0.2)
+    remap = np.array([0] * 18 + [1, 2, 3, 4, 5, 6])
+    B = 7
+    initial = np.where(initial_t >= 0, remap[np.maximum(initial_t, 0)], -1).astype(np.int64)
+    true = remap[true_t]
+    perms = _perms(initial, 2)
+    a = _lib.Context(0)
+    try:
+        a.set_samples(X)
+        got, its, changed = a.fit_cluster(B, initial, perms, m, 2)
+        seg_batches = a.counter("segment_batches")
+        overflow = a.counter("prefilter_overflow")
+        rng = np.random.default_rng(2)
+        q = rng.choice(np.flatnonzero(initial < 0), 300, replace=False)
+        lists = a.topm_per_bin(got, B, m, q)
+        seg_topm = a.counter("segment_batches")
+    finally:
+        a.close()
+    assert seg_batches > 0, "the giant bin was never segmented"
+    assert (got == true).mean() > 0.95
+    b = _ctx_env({"CHB_SEGMENTS": "0"})
+    try:
+        b.set_samples(X)
+        want, its_w, changed_w = b.fit_cluster(B, initial, perms, m, 2)
+        assert b.counter("segment_batches") == 0
+    finally:
+        b.close()
+    assert its == its_w and np.array_equal(changed, changed_w) and np.array_equal(got, want)
+    assert overflow <= 1e-3 * its * perms.shape[1] * B
+    c = _brute_ctx()
+    try:
+        c.set_samples(X)
+        want_lists = c.topm_per_bin(got, B, m, q)
+    finally:
+        c.close()
+    for g, w_ in zip(lists, want_lists):
+        assert np.array_equal(g, w_)
+    # the oracle replays the LAST contigs of sweep 2 (the giant bin is at full size there)
+    tail = perms[its - 1][-12:]
+    first = None
+    d = _lib.Context(0)
+    try:
+        d.set_samples(X)
+        first, _, _ = d.fit_cluster(B, initial, perms[:1], m, 1)
+    finally:
+        d.close()
+    for k, j in enumerate(tail):
+        lab_now = got.copy()
+        lab_now[tail[k:]] = first[tail[k:]] if its == 2 else initial[tail[k:]]
+        lab_j, _ = O.sweep(X, B, lab_now, np.array([j]), m)
+        assert lab_j[j] == got[j]
