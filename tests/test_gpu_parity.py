@@ -932,7 +932,7 @@ def test_segmented_giant_bin(O, m):
     finally:
         b.close()
     assert its == its_w and np.array_equal(changed, changed_w) and np.array_equal(got, want)
-    assert overflow <= 1e-3 * its * perms.shape[1] * B
+    assert overflow <= (1e-3 if m <= 5 else 2e-2) * its * perms.shape[1] * B   # (m = 15 overflows ~0.4 % of its pairs on any data)
     c = _brute_ctx()
     try:
         c.set_samples(X)
