@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the round's profile set on the GPU box into gpurun_out/<tag>/ (copy what is to be judged into profiles/).
+# usage (through gpurun): bash tools/collect_profiles.sh r03prof [quick]
+#   kernel stats (rocprofv3 --kernel-trace --stats) + the bench line of the same run, HBM-side counters (separate --pmc
+#   passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes), the default bench line, and the other configs.
+set -o pipefail
+tag=${1:-r03prof}; quick=$2
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py"
+echo "[1] kernel stats, config 2"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg2 -o t -- $B --steps 3 --warmup 1 --cpu-sample 0 --no-e2e --no-extra > $O/bench_under_rocprof.json 2> $O/err_stats_cfg2.txt || exit 1
+echo "[2] pmc fetch"; rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o t -- $B --steps 1 --warmup 0 --cpu-sample 0 --no-e2e --no-extra > $O/bench_pmc_fetch.json 2> $O/err_pmc_fetch.txt || exit 1
+echo "[3] pmc write"; rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o t -- $B --steps 1 --warmup 0 --cpu-sample 0 --no-e2e --no-extra > $O/bench_pmc_write.json 2> $O/err_pmc_write.txt || exit 1
+echo "[4] default bench"; $B > $O/bench_default.json 2> $O/err_default.txt || exit 1
+[ -n "$quick" ] && exit 0
+echo "[5] m = 15"; $B --neighbors 15 --steps 3 --warmup 1 --no-extra > $O/m15_bench.json 2> $O/err_m15.txt || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_m15 -o t -- $B --neighbors 15 --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-extra > $O/m15_bench_under_rocprof.json 2> $O/err_stats_m15.txt || exit 1
+echo "[6] configs[1]"; $B --contigs 10000 --bins 32 --steps 5 --warmup 2 --cpu-sample 200 --no-extra > $O/cfg1_bench.json 2> $O/err_cfg1.txt || exit 1
+echo "[7] configs[3]"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg3 -o t -- $B --contigs 500000 --dim 140 --bins 128 --steps 2 --warmup 1 --cpu-sample 0 --no-extra > $O/cfg3_bench_under_rocprof.json 2> $O/err_cfg3.txt || exit 1
+echo "[8] configs[4]"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -o t -- $B --contigs 1000000 --dim 146 --bins 200 --steps 2 --warmup 1 --cpu-sample 0 --no-extra > $O/cfg4_bench_under_rocprof.json 2> $O/err_cfg4.txt || exit 1
+find $O -name "*kernel_trace.csv" -size +8M -delete
+echo done
