@@ -158,7 +158,7 @@ struct PinBuf {
 // device storage behind a MemberPack
 struct PackBufs {
     DevBuf<unsigned short> Z;
-    DevBuf<float> bias, rho, nrm, amax, sn, cs, cb, bb;
+    DevBuf<float> bias, rho, nrm, amax, sn, cs, cb, bb, tsn;
     DevBuf<int> pad_ptr;
     hipError_t ensure(size_t rows, size_t B, size_t Dz)
     {
@@ -168,16 +168,17 @@ struct PackBufs {
         for (auto *b : f)
             if ((e = b->ensure(rows + 64)) != hipSuccess) return e;
         if ((e = bb.ensure(4 * B)) != hipSuccess) return e;
+        if ((e = tsn.ensure(rows / 32 + B + 4)) != hipSuccess) return e;
         return pad_ptr.ensure(B + 1);
     }
     void release()
     {
         Z.release(); bias.release(); rho.release(); nrm.release(); amax.release(); sn.release(); cs.release(); cb.release();
-        bb.release(); pad_ptr.release();
+        bb.release(); tsn.release(); pad_ptr.release();
     }
     chb::MemberPack view()
     {
-        return chb::MemberPack{Z.p, bias.p, rho.p, nrm.p, amax.p, sn.p, cs.p, cb.p, pad_ptr.p,
+        return chb::MemberPack{Z.p, bias.p, rho.p, nrm.p, amax.p, sn.p, cs.p, cb.p, tsn.p, pad_ptr.p,
                                reinterpret_cast<float4 *>(bb.p)};
     }
 };

@@ -72,6 +72,7 @@ struct MemberPack {
     float *rho, *nrm, *amax;  // [rows] rounding distance, ||zh||^2, ||zh||^2 + 2 |<..>|
     float *sn;                // [rows] ||zh|| (rounded up)
     float *cs, *cb;           // [rows] update mode: entry eligible for position q <=> cs q + cb >= 0
+    float *tsn;               // [rows / 32] base pack: largest ||zh|| (rounded up) of each 32-row tile
     int *pad_ptr;             // [B+1] first row of each bin (multiples of 32)
     float4 *bb;               // [B] {largest rho, largest ||zh||, largest amax, largest residual of the bias pieces}
                               // (the batch-entry pack accumulates the largest ||zh||^2 in .y; its .w is unused)

@@ -37,8 +37,9 @@
 // over the bin).  The last term is Cauchy-Schwarz on the query's rounding error, damped by the small
 // norm of the bin-centred member.  Update mode folds it per member into the accumulator's start value,
 // -bias_p / 2 -+ rho_j ||zh_p||, minus for the upper bounds of sweep 0, plus for the lower bounds of
-// sweep 1; base mode uses the bin's largest norm, d_jc = rho_j snb_c: one constant per (query, bin) that moves
-// the two thresholds instead of every accumulator.
+// sweep 1; base mode uses the largest norm of the member's 32-row TILE, d = rho_j sn_tile (P.tsn): one constant per
+// (query, tile) that moves the two thresholds instead of every accumulator -- per tile and not per bin, so that a
+// stray member (a contig far from the centre of the bin it sits in for the moment) loosens its own tile only.
 // By the triangle inequality | S d(j,p) - sqrt(T) | <= rho_p <= rho_bin, hence for every member
 //     LB(j,p) <= S d(j,p) <= UB(j,p),   UB/LB = sqrt(N_jc - 2 acc' +- E) +- rho_bin .
 // Sweep 0 over a bin learns tau = (an upper bound of) the m-th smallest UB -- at least m members
@@ -370,15 +371,24 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
 // bb[c] = {largest rounding distance, largest ||zh|| (rounded up), largest ||zh||^2 + 2|<..>|, largest bias residual}
 // over the members of bin c, from the per-sample rows the pack is gathered FROM (ms[memb_id[..]]): independent of the
 // pack kernel's output, so that both can share one launch
+// tsn[tile] (tiles of the padded layout, first tile of the bin = pad0 / 32): the largest ||zh|| of each 32-row tile --
+// the query-rounding term of the shortlist kernel is taken per TILE, so that one stray member (a contig far from the
+// centre of the bin it sits in for the moment) loosens the bounds of its own tile only, not of the whole bin
 __device__ __forceinline__ void bin_bounds_from_source(const float4 *ms, const int *memb_id, const int *bin_ptr, int c,
-                                                       float4 *bb)
+                                                       float4 *bb, float *tsn, int pad0)
 {
     __shared__ float red[4][256];
     const int b0 = bin_ptr[c], cnt = bin_ptr[c + 1] - b0;
     float v = 0.f, u = 0.f, a = 0.f, rs = 0.f;
-    for (int e = threadIdx.x; e < cnt; e += 256) {
-        const float4 o = ms[memb_id[b0 + e]];
+    for (int e0 = 0; e0 < cnt; e0 += 256) {   // (whole wavefronts: the tile maximum is a half-wavefront reduction)
+        const int e = e0 + (int)threadIdx.x;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < cnt) o = ms[memb_id[b0 + e]];
         rs = fmaxf(rs, o.x); v = fmaxf(v, o.y); u = fmaxf(u, o.z); a = fmaxf(a, o.w);
+        float tn = o.z;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) tn = fmaxf(tn, __shfl_xor(tn, off, 64));
+        if ((threadIdx.x & 31) == 0 && e < cnt) tsn[pad0 / 32 + e / 32] = sqrtf(tn) * (1.0f + 1e-6f);
     }
     red[0][threadIdx.x] = v; red[1][threadIdx.x] = u; red[2][threadIdx.x] = a; red[3][threadIdx.x] = rs;
     __syncthreads();
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(256) void pack_build_kernel(const unsigned short *Z
     CHB_GATE(gate);
     const int b = blockIdx.x;
     if (b < npack) pack_rows_block(Zs, ms, q.D, Dz, memb_id, bin_ptr, pad_ptr, B, P, b, npack);
-    else if (b < npack + B) bin_bounds_from_source(ms, memb_id, bin_ptr, b - npack, P.bb);
+    else if (b < npack + B) bin_bounds_from_source(ms, memb_id, bin_ptr, b - npack, P.bb, P.tsn, pad_ptr[b - npack]);
     else query_norms_tile(q, (b - npack - B) % nqx, (b - npack - B) / nqx);
 }
 
@@ -771,9 +781,10 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
         // rounded to fp32 (2^-24 Bmax)
         const float E = ((UPD ? 1.2e-7f * bb.z : 2.0f * bb.w) + a.gamma * (1.001f * bb.z + 2.0f * snq * bb.y)) *
                         (1.0f + 4.0f * kSlack);
-        // base mode: the query's rounding error against the LARGEST member norm of the bin, one constant per
-        // (query, bin) that shifts the thresholds (update mode: per member, in the accumulator's start value)
-        const float dl = UPD ? 0.f : rg * bb.y * (1.0f + 4.0f * kSlack);
+        // base mode: the query's rounding error against the largest member norm of each TILE (P.tsn) -- one constant per
+        // (query, tile) that shifts the thresholds (update mode: per member, in the accumulator's start value)
+        const float rgq = rg * (1.0f + 4.0f * kSlack);
+        const float *tsn_c = UPD ? nullptr : a.P.tsn + (row0 >> 5) + seg_tb;
         const float nj_hi = (qn2.x + E) * (1.0f + kSlack);
         const float nj_lo = (qn2.y - E) * (qn2.y > E ? (1.0f - kSlack) : (1.0f + kSlack));
         const float rsum = bb.x * (1.0f + kSlack);
@@ -827,12 +838,13 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                 float tau = INFINITY;
                 if (qvalid && ms > -INFINITY) {
                     // tau = m-th smallest upper bound; at least m members are provably within it
-                    // (base mode: the list holds RAW accumulators; the upper bound of a member's t is -2 (acc - dl),
-                    //  and a member is admitted when its lower bound -2 (acc + dl) is within reach: acc >= thr2)
-                    const float thr = -2.0f * (ms - dl);
+                    // (base mode: the list holds accumulators already pushed DOWN by their tile's query-rounding term,
+                    //  i.e. upper bounds of t; a member is admitted when its accumulator pushed UP by that term
+                    //  reaches thr2: acc >= thr2 - d_tile)
+                    const float thr = -2.0f * ms;
                     tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
                     const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
-                    thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo) - dl;
+                    thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
                 }
                 // for the fused selection path: tau bounds the m-th distance among these members -- the update
                 // stage's threshold and (smallest over the bins) the label guess
@@ -880,6 +892,16 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 }
+                // base mode: the tile's largest member norm, a SCALAR load (an ordinary vector load here would make the
+                // compiler drain the tile DMA queue); it is complete behind the fragment reads' lgkmcnt(0) below
+                float tsn_t = 0.f;
+                if (!UPD) {
+                    const unsigned long long ta = reinterpret_cast<unsigned long long>(tsn_c + ct);
+                    const unsigned ta_lo = __builtin_amdgcn_readfirstlane((unsigned)ta);
+                    const unsigned ta_hi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
+                    const unsigned long long ta_s = ((unsigned long long)ta_hi << 32) | ta_lo;
+                    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(tsn_t) : "s"(ta_s) : "memory");
+                }
                 f16x8 af[KS == 9 ? 9 : 10];
                 {
                     const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
@@ -896,7 +918,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
-                               "+v"(af[6]), "+v"(af[7]), "+v"(af[8])
+                               "+v"(af[6]), "+v"(af[7]), "+v"(af[8]), "+s"(tsn_t)
                              :
                              : "memory");
                 if (KS == 10) asm volatile("" : "+v"(af[KS - 1]) : : "memory");
@@ -904,9 +926,11 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                 for (int sx = 0; sx < KS; ++sx)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[sx], qreg[sx], acc, 0, 0, 0);
 
+                // base mode: this tile's query-rounding term (a wave-uniform table read)
+                const float dlt = UPD ? 0.f : rgq * tsn_t;
                 if (!UPD && sweep == 0) {
-                    // acc = -t/2: UB is monotone in t, so the m LARGEST accumulators are kept; per
-                    // tile a 16-way maximum and one branch
+                    // acc = -t/2: UB is monotone in t, so the m LARGEST accumulators are kept (pushed down by the
+                    // tile's term: upper bounds of t); per tile a 16-way maximum and one branch
                     float mx = acc[0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
@@ -915,13 +939,13 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                         // of per-(tile, lane half) bests is the m-th best of m distinct members, i.e.
                         // still a valid tau; it is the exact m-th unless two of the top m share a tile
                         // half (probability ~ m^2 / (4 ntile)), and then one rank looser.
-                        if (mx > thr_s) {
-                            list_insert_desc<ML>(lb, mx);
+                        if (mx - dlt > thr_s) {
+                            list_insert_desc<ML>(lb, mx - dlt);
                             thr_s = lb[ML - 1];
                         }
                     } else
-                    while (mx > thr_s) {
-                        list_insert_desc<ML>(lb, mx);
+                    while (mx - dlt > thr_s) {
+                        list_insert_desc<ML>(lb, mx - dlt);
                         thr_s = lb[ML - 1];
                         float nx = -INFINITY;
 #pragma unroll
@@ -940,9 +964,10 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                         wcnt = 0;
                     }
                     const unsigned ebase = ent0 + (unsigned)((ct + seg_tb) * kPfP);
+                    const float thr_t = thr2 - dlt;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const bool hit = acc[r] >= thr2;
+                        const bool hit = acc[r] >= thr_t;
                         const unsigned long long bal = __ballot(hit);
                         if (bal) {
                             const int before = __builtin_amdgcn_mbcnt_hi(

@@ -497,15 +497,37 @@ def test_cli_perform_clustering_matches_oracle(ctx, O, tmp_path, golden_dir, mon
     from chbin_amd import cli_clustering
     feats = tmp_path / "features.csv"
     make_features_csv(feats, golden_dir)
+    # a contig FASTA for the parents of that table (plus one record nobody is assigned to), so that the GPU run goes
+    # through dump_bins (dump_bins.py:8-29, called at cli/clustering.py:96) as the reference's does
+    parents = sorted(set(pd.read_csv(feats)["PARENT_NAME"].astype(str)))
+    fasta = tmp_path / "contigs.fasta"
+    rng = np.random.default_rng(3)
+    with open(fasta, "w") as fh:
+        for name in parents + ["not_binned_contig"]:
+            fh.write(f">{name} len=130\n")
+            seq = "".join(rng.choice(list("ACGT"), 130))
+            fh.write(seq[:70] + "\n" + seq[70:] + "\n")
     np.random.seed(0)
-    out_gpu = cli_clustering.perform_clustering(None, feats, tmp_path / "gpu", num_neighbors=5,
+    out_gpu = cli_clustering.perform_clustering(fasta, feats, tmp_path / "gpu", num_neighbors=5,
                                                 max_iterations=6)
     monkeypatch.setattr(cli_clustering, "fit_cluster", oracle_fit)
     np.random.seed(0)
-    out_cpu = cli_clustering.perform_clustering(None, feats, tmp_path / "cpu", num_neighbors=5,
+    out_cpu = cli_clustering.perform_clustering(fasta, feats, tmp_path / "cpu", num_neighbors=5,
                                                 max_iterations=6)
     assert open(out_gpu).read() == open(out_cpu).read()
-    assert len(pd.read_csv(out_gpu)) == 120
+    table = pd.read_csv(out_gpu)
+    assert len(table) == 120
+    # bins/bin_<i>.fasta: every assigned parent exactly once, in its bin's file, header line kept; the unassigned
+    # record dropped; the two runs' files identical
+    seen = {}
+    for b in sorted(set(table["BIN"])):
+        text = open(tmp_path / "gpu" / "bins" / f"bin_{b}.fasta").read()
+        assert text == open(tmp_path / "cpu" / "bins" / f"bin_{b}.fasta").read()
+        for line in text.splitlines():
+            if line.startswith(">"):
+                assert line.endswith(" len=130")
+                seen[line[1:].split()[0]] = b
+    assert seen == dict(zip(table["CONTIG_NAME"].astype(str), table["BIN"]))
 
 
 def test_native_comm_exchange_path_world1(O):
