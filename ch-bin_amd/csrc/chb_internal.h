@@ -210,6 +210,7 @@ struct FusedArgs {
     int metric;
     int *slow;        // pair indices (pos - pos_begin) * B + bin
     int *n_slow;      // zeroed by the caller
+    int stripe = 0;   // m <= 5 kernel, set by its launcher: work striped over the XCDs by bin (see fused_pair_of)
 };
 // false: not supported by the fused kernels (caller uses the list-based path): m <= 16, padded rows of at most
 // kFusedMaxDp doubles (the 16-lane kernel stages the query row in LDS)

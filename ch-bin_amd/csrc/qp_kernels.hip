@@ -539,6 +539,29 @@ __device__ __forceinline__ double diag_rows8(const double *X, int Dp, int qid, i
     return reduce_scatter16(acc, l16);
 }
 
+// Work order of the m <= 5 fused kernel.  STRIPED (a.stripe != 0, B >= 16): consecutive workgroups go round-robin over the
+// 8 XCDs, each with its own L2; workgroup b (XCD b % 8) only takes pairs of the bins c = b % 8 (mod 8), walked position-major
+// over that bin subset (64 consecutive pairs per wavefront = 64 / nbx positions x the XCD's nbx bins).  The candidate rows an
+// XCD gathers then come from an eighth of the bins -- its 4 MiB L2 holds a far larger share of them -- while a query row is
+// still shared by the nbx pairs of a position.  Otherwise: position-major over all bins (one position x 64 bins per
+// wavefront at B = 64).
+__device__ __forceinline__ bool fused_pair_of(const FusedArgs &a, int g0, int lane, int nprob, int &pos, int &c)
+{
+    if (!a.stripe) {
+        const int g = g0 + lane;
+        pos = a.pos_begin + g / a.B;
+        c = g - (g / a.B) * a.B;
+        return g < nprob;
+    }
+    const int x = (int)(blockIdx.x & 7);
+    const int nbx = (a.B - x + 7) >> 3;                    // bins c = x (mod 8)
+    const int t = g0 + lane;                               // pair number inside the XCD's list
+    const int pq = t / nbx;
+    pos = a.pos_begin + pq;
+    c = x + 8 * (t - pq * nbx);
+    return pq < a.pos_end - a.pos_begin;
+}
+
 template <int M, int C, int WAVES, bool OFF32>
 __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kernel(FusedArgs a, int nprob, Gate gate)
 {
@@ -561,18 +584,19 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
     const int m = a.m;
     if (threadIdx.x == 0) sSlowN = 0;
     __syncthreads();
-    const int g0 = (blockIdx.x * WAVES + w) * 64;
+    // (striped: the wavefront's place in its XCD's own pair list; nprob is then the length of the longest of the 8 lists)
+    const int g0 = ((a.stripe ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * WAVES + w) * 64;
     unsigned long long slowmask = 0ull;        // problems of this wavefront left to the exact path
+    int pos = 0, c = 0;
+    bool valid = false;
 
     if (g0 < nprob) {
         // ---- classification, one problem per lane
-        const int g = g0 + lane;
-        const bool valid = g < nprob;
+        valid = fused_pair_of(a, g0, lane, nprob, pos, c);
         int nb = 0, nu = 0, qid = 0;
         size_t slot = 0;
         bool changed = valid;
         if (valid) {
-            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
             qid = a.bq[pos];
             slot = (size_t)c * a.Kcap + pos;
             nb = a.cand_cnt[slot];
@@ -625,8 +649,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             const int n_g = has ? n_s : 0;
             const int nb_g = __shfl(nb, pl, 64);
             const int qid_g = __shfl(qid, pl, 64);
-            const int gg = g0 + pl;
-            const size_t slot_g = (size_t)(gg - (gg / a.B) * a.B) * a.Kcap + (a.pos_begin + gg / a.B);
+            const size_t slot_g = (size_t)__shfl(c, pl, 64) * a.Kcap + (size_t)__shfl(pos, pl, 64);
             int idm = -1;
             if (l16 < n_g)
                 idm = l16 < nb_g ? a.cand[slot_g * kCandCap + l16] : a.candu[slot_g * kCandCapU + (l16 - nb_g)];
@@ -704,8 +727,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             const int n_g = has ? n_s : 0;
             const int nb_g = __shfl(nb, pl, 64);
             const int qid_g = __shfl(qid, pl, 64);
-            const int gg = g0 + pl;
-            const size_t slot_g = (size_t)(gg - (gg / a.B) * a.B) * a.Kcap + (a.pos_begin + gg / a.B);
+            const size_t slot_g = (size_t)__shfl(c, pl, 64) * a.Kcap + (size_t)__shfl(pos, pl, 64);
             int idm = -1;
             if (l16 < n_g)
                 idm = l16 < nb_g ? a.cand[slot_g * kCandCap + l16] : a.candu[slot_g * kCandCapU + (l16 - nb_g)];
@@ -762,9 +784,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
 
     // ---- phase 2: one problem per lane
     {
-        const int g = g0 + lane;
-        const int n = g < nprob ? sN[w][lane] : -1;
-        if (g < nprob && n != -1 && !((sm >> lane) & 1ull)) {   // else: distance kept, or written by the exact path
+        const int n = valid ? sN[w][lane] : -1;
+        if (valid && n != -1 && !((sm >> lane) & 1ull)) {   // else: distance kept, or written by the exact path
             double Q[NPM];
 #pragma unroll
             for (int e = 0; e < NPM; ++e) Q[e] = sQ[w][e][lane];
@@ -776,7 +797,6 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
                 const double val = a.metric == 0 ? min_norm_point<M>(Q, n, alpha) : affine_min_norm<M>(Q, n, alpha);
                 dist = sqrt(fmax(val, 0.0));
             }
-            const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
             a.dist[(size_t)pos * a.B + c] = dist;
         }
     }
@@ -792,7 +812,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
     wbase = __shfl(wbase, 0, 64) + sSlowBase;
     if (nsl > 0 && ((sm >> lane) & 1ull)) {
         const int before = __popcll(sm & ((1ull << lane) - 1ull));
-        a.slow[wbase + before] = g0 + lane;
+        a.slow[wbase + before] = (pos - a.pos_begin) * a.B + c;   // (position-major pair index, whatever the work order)
     }
 }
 
@@ -1941,14 +1961,22 @@ void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
                            nprob, g_gate);
         return;
     }
-    const int grid = (nprob + 64 * WV - 1) / (64 * WV);
+    int np5 = nprob, grid = (nprob + 64 * WV - 1) / (64 * WV);
+    FusedArgs as = a;
+    static const bool stripe_off = getenv("CHB_FUSED_STRIPE") != nullptr && atoi(getenv("CHB_FUSED_STRIPE")) == 0;
+    as.stripe = (!stripe_off && a.B >= 16) ? 1 : 0;
+    if (as.stripe) {
+        // the longest of the 8 XCD lists: XCD 0 has ceil(B / 8) bins
+        np5 = (a.pos_end - a.pos_begin) * ((a.B + 7) / 8);
+        grid = 8 * ((np5 + 64 * WV - 1) / (64 * WV));
+    }
     // (rows as 32-bit byte offsets while the sample matrix is smaller than 4 GiB: see gram_rows; CHB_FUSED_PTR64=1
     //  selects the 64-bit-pointer instantiation regardless, for the tests)
     static const bool ptr64 = getenv("CHB_FUSED_PTR64") != nullptr && atoi(getenv("CHB_FUSED_PTR64")) != 0;
     if (!ptr64 && (unsigned long long)a.n_samples * (unsigned long long)a.Dp * 8ull < (1ull << 32))
-        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, true>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
+        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, true>), dim3(grid), dim3(64 * WV), 0, s, as, np5, g_gate);
     else
-        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, false>), dim3(grid), dim3(64 * WV), 0, s, a, nprob, g_gate);
+        hipLaunchKernelGGL((hull_select_qp_kernel<5, CHB_FUSED_C, WV, false>), dim3(grid), dim3(64 * WV), 0, s, as, np5, g_gate);
 }
 
 bool hull_generic_supported()
