@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * WAVES, (M <= 5 ? 4 : 1)) void hull_qp_kernel(Q
     CHB_GATE(gate);
     constexpr int NP = Sym<M>::NP;
     static_assert(M <= 8, "m > 8 runs on hull_qp16_kernel");
-    __shared__ double sQ[WAVES][NP][64];
+    __shared__ double sQ[WAVES][NP][65];    // (65: the 16 lanes of a group store 16 entries of ONE problem column -- a stride of 64 doubles would put them all on one bank)
     __shared__ int sN[WAVES][64];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
     constexpr int NR = (NPC + 15) / 16;
     constexpr int NCLS = C - M + 1;            // classes of the one-sweep form: widths M, M + 1, ..., C
     static_assert(C <= 8 && M <= C && C - M <= 3, "candidate Gram in registers");
-    __shared__ double sQ[WAVES][NPM][64];
+    __shared__ double sQ[WAVES][NPM][65];   // (65: the 16 lanes of a group store 16 entries of ONE problem column -- a stride of 64 doubles would put them all on one bank)
     __shared__ double sT[WAVES][4][NR * 16];   // candidate Gram of the group's pair
     __shared__ double sTh[WAVES][4][2];        // squared distances of ranks m-1 and m
     __shared__ int sSel[WAVES][4][16];         // candidate slot of each rank
