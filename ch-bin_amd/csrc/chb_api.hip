@@ -158,13 +158,13 @@ struct PinBuf {
 // device storage behind a MemberPack
 struct PackBufs {
     DevBuf<unsigned short> Z;
-    DevBuf<float> bias, rho, nrm, amax, sn, cs, cb, bb, tsn;
+    DevBuf<float> bias, sn, cs, cb, bb, tsn;   // (bias / sn / cs / cb: the batch-entry pack's per-row columns)
     DevBuf<int> pad_ptr;
     hipError_t ensure(size_t rows, size_t B, size_t Dz)
     {
         hipError_t e;
         if ((e = Z.ensure((rows + 64) * Dz)) != hipSuccess) return e;   // + slack: whole 32-row tiles are read
-        DevBuf<float> *f[] = {&bias, &rho, &nrm, &amax, &sn, &cs, &cb};
+        DevBuf<float> *f[] = {&bias, &sn, &cs, &cb};
         for (auto *b : f)
             if ((e = b->ensure(rows + 64)) != hipSuccess) return e;
         if ((e = bb.ensure(4 * B)) != hipSuccess) return e;
@@ -173,13 +173,12 @@ struct PackBufs {
     }
     void release()
     {
-        Z.release(); bias.release(); rho.release(); nrm.release(); amax.release(); sn.release(); cs.release(); cb.release();
+        Z.release(); bias.release(); sn.release(); cs.release(); cb.release();
         bb.release(); tsn.release(); pad_ptr.release();
     }
     chb::MemberPack view()
     {
-        return chb::MemberPack{Z.p, bias.p, rho.p, nrm.p, amax.p, sn.p, cs.p, cb.p, tsn.p, pad_ptr.p,
-                               reinterpret_cast<float4 *>(bb.p)};
+        return chb::MemberPack{Z.p, bias.p, sn.p, cs.p, cb.p, tsn.p, pad_ptr.p, reinterpret_cast<float4 *>(bb.p)};
     }
 };
 

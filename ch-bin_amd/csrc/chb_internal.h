@@ -66,13 +66,13 @@ constexpr int kCandCapU = 32;   // same for the batch's own entries in the fused
 // fp16 shadow data of the shortlist stage (prefilter_kernels.hip explains the quantities).
 // Members of all bins, grouped by bin, every bin padded to a multiple of 32 rows:
 struct MemberPack {
-    unsigned short *Z;        // [rows][Dz] fp16 bits of (x_p - mu_c) S; zero rows in the padding
-    float *bias;              // [rows] batch-entry pack: ||zh||^2 + 2 <(mu_c - mu_g) S, zh>; base pack: residual of
-                              // the bias pieces the row carries in its columns D .. D + 2; +inf in the padding
-    float *rho, *nrm, *amax;  // [rows] rounding distance, ||zh||^2, ||zh||^2 + 2 |<..>|
+    unsigned short *Z;        // [rows][Dz] fp16 bits of (x_p - mu_c) S; base pack: columns D .. D + 2 carry the three
+                              // fp16 pieces of -bias / 2^15 (first piece -inf in the padding rows); padding: zero rows
+    // per-row columns of the BATCH-ENTRY pack only (update mode; the base pack's tile loop reads nothing but Z):
+    float *bias;              // [rows] ||zh||^2 + 2 <(mu_c - mu_g) S, zh>; +inf in the padding
     float *sn;                // [rows] ||zh|| (rounded up)
-    float *cs, *cb;           // [rows] update mode: entry eligible for position q <=> cs q + cb >= 0
-    float *tsn;               // [rows / 32] base pack: largest ||zh|| (rounded up) of each 32-row tile
+    float *cs, *cb;           // [rows] entry eligible for position q <=> cs q + cb >= 0
+    float *tsn;               // [rows / 32] base pack only: largest ||zh|| (rounded up) of each 32-row tile
     int *pad_ptr;             // [B+1] first row of each bin (multiples of 32)
     float4 *bb;               // [B] {largest rho, largest ||zh||, largest amax, largest residual of the bias pieces}
                               // (the batch-entry pack accumulates the largest ||zh||^2 in .y; its .w is unused)

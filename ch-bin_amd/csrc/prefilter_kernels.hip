@@ -275,7 +275,7 @@ __device__ __forceinline__ int bin_of_row(const int *pad_ptr, int B, int r)
 
 // Gathers the per-sample member rows of the CSR-ordered base members into the padded layout;
 // 16 lanes per row.  Padding rows: zero features, bias = +inf (never selectable).
-__device__ __forceinline__ void pack_rows_block(const unsigned short *Zs, const float4 *ms, int D, int Dz,
+__device__ __forceinline__ void pack_rows_block(const unsigned short *Zs, int D, int Dz,
                                                 const int *memb_id, const int *bin_ptr,
                                                 const int *pad_ptr, int B, const MemberPack &P, int block, int nblocks)
 {
@@ -307,12 +307,7 @@ __device__ __forceinline__ void pack_rows_block(const unsigned short *Zs, const 
             }
             *reinterpret_cast<uint4 *>(P.Z + (size_t)r * Dz + cc * 8) = v;
         }
-        if (l16 == 0) {
-            // (.bias of the base pack = residual of the row's bias pieces; +inf marks a padding row)
-            const float4 o = real ? ms[id] : make_float4(INFINITY, 0.f, 0.f, 0.f);
-            P.bias[r] = o.x; P.rho[r] = o.y; P.nrm[r] = o.z; P.amax[r] = o.w;
-            P.sn[r] = sqrtf(o.z) * (1.0f + 1e-6f);
-        }
+        // (the base pack has no per-row columns beside Z: -bias / 2 sits in the row, the bounds are per bin / per tile)
     }
 }
 
@@ -338,7 +333,7 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
                                                S, D, Dz, lane, P.Z + (size_t)r * Dz);
             m_rho = fmaxf(m_rho, o.y); m_nrm = fmaxf(m_nrm, o.z); m_amax = fmaxf(m_amax, o.w);
             if (lane == 0) {
-                P.bias[r] = o.x; P.rho[r] = o.y; P.nrm[r] = o.z; P.amax[r] = o.w;
+                P.bias[r] = o.x;
                 P.sn[r] = sqrtf(o.z) * (1.0f + 1e-6f);
                 const int code = memb_code[b0 + e];
                 float sv = 0.f, bv = 0.f;
@@ -351,7 +346,7 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
         } else {
             for (int k = lane; k < Dz; k += 64) P.Z[(size_t)r * Dz + k] = 0;
             if (lane == 0) {
-                P.bias[r] = INFINITY; P.rho[r] = 0.f; P.nrm[r] = 0.f; P.amax[r] = 0.f; P.sn[r] = 0.f;
+                P.bias[r] = INFINITY; P.sn[r] = 0.f;
                 P.cs[r] = 0.f; P.cb[r] = 0.f;
             }
         }
@@ -496,7 +491,7 @@ __global__ __launch_bounds__(256) void pack_build_kernel(const unsigned short *Z
 {
     CHB_GATE(gate);
     const int b = blockIdx.x;
-    if (b < npack) pack_rows_block(Zs, ms, q.D, Dz, memb_id, bin_ptr, pad_ptr, B, P, b, npack);
+    if (b < npack) pack_rows_block(Zs, q.D, Dz, memb_id, bin_ptr, pad_ptr, B, P, b, npack);
     else if (b < npack + B) bin_bounds_from_source(ms, memb_id, bin_ptr, b - npack, P.bb, P.tsn, pad_ptr[b - npack]);
     else query_norms_tile(q, (b - npack - B) % nqx, (b - npack - B) / nqx);
 }
