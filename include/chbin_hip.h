@@ -25,6 +25,8 @@
  *       CHB_FUSED_PTR64=1   64-bit row pointers in the m <= 5 fused kernel (what a matrix >= 4 GiB gets)
  *       CHB_SPECULATE=0     no look-ahead across batches in chb_fit_cluster
  *       CHB_FORCE_GATHER=1  exchange path of the sharded loop even with one rank
+ *       CHB_SEGMENTS=0      bins far larger than the rest are never cut into segments for the shortlist stage
+ *       CHB_FUSED_STRIPE=0  position-major work order in the m <= 5 fused kernel (default: striped over the XCDs by bin)
  */
 #ifndef CHBIN_HIP_H
 #define CHBIN_HIP_H
