@@ -28,57 +28,62 @@ __global__ void batch_close_kernel(int *labels, int *inb, const int *bq, const i
 
 // ---- base members: every labelled sample that is not in the current batch
 
+// CSR key of a base member.  Without shells (nsh == 1): its bin.  With shells: (bin, shell), the shell = the member's
+// distance from its bin's centre in the shadow space, ||zh|| (ms[p].z = ||zh||^2), in units of shell_inv[bin], outermost
+// shell first -- a bin's rows then come periphery first, and the members of a 32-row tile have similar norms, which is what
+// lets the shortlist kernel skip tiles by the bound | ||z_query|| - ||zh_member|| | (prefilter_kernels.hip).  Any monotone
+// bucketing is correct; shell_inv is a per-fit constant per bin.
+__device__ __forceinline__ int member_key(int l, int p, const float4 *ms, const float *shell_inv, int nsh)
+{
+    if (nsh <= 1) return l;
+    const float r = sqrtf(ms[p].z) * shell_inv[l];
+    int sh = r == r ? (int)fminf(r, (float)(nsh - 1)) : 0;
+    sh = sh < 0 ? 0 : sh;
+    return l * nsh + (nsh - 1 - sh);
+}
+
 // bq != nullptr: the batch is opened in the same launch (labels remembered, members marked) -- the count then takes every labelled sample and the batch's own entries are subtracted again, so
 // that neither part reads what the other writes.
+// (ckey, optional: the nearest-centre keys of the positions [ck_lo, ck_hi) are reset to ~0 for the coming query-norm launch)
 __global__ void count_base_kernel(const int *labels, int *inb, int N, int B, int *cnt, const int *bq, int K,
-                                  int *lab_old, Gate gate)
+                                  int *lab_old, const float4 *ms, const float *shell_inv, int nsh,
+                                  unsigned long long *ckey, int ck_lo, int ck_hi, Gate gate)
 {
     CHB_GATE(gate);
     extern __shared__ int hist[];
-    for (int b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
+    const int BK = B * nsh;
+    for (int b = threadIdx.x; b < BK; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     if (bq == nullptr) {
         for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
             const int l = labels[p];
-            if (l >= 0 && l < B && inb[p] < 0) atomicAdd(&hist[l], 1);
+            if (l >= 0 && l < B && inb[p] < 0) atomicAdd(&hist[member_key(l, p, ms, shell_inv, nsh)], 1);
         }
     } else {
         for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
             const int l = labels[p];
-            if (l >= 0 && l < B) atomicAdd(&hist[l], 1);
+            if (l >= 0 && l < B) atomicAdd(&hist[member_key(l, p, ms, shell_inv, nsh)], 1);
         }
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
             const int p = bq[i];
             const int l = labels[p];
             lab_old[i] = l;
             inb[p] = i;
-            if (l >= 0 && l < B) atomicSub(&hist[l], 1);
+            if (l >= 0 && l < B) atomicSub(&hist[member_key(l, p, ms, shell_inv, nsh)], 1);
+            if (ckey != nullptr && i >= ck_lo && i < ck_hi) ckey[i - ck_lo] = ~0ull;
         }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x)
+    for (int b = threadIdx.x; b < BK; b += blockDim.x)
         if (hist[b]) atomicAdd(&cnt[b], hist[b]);
 }
 
-// bin_ptr / cursor = exclusive scan of cnt; pad_ptr (optional) = the same with every count rounded
-// up to a multiple of 32 (the padded layout of the shortlist stage).  One block of 256 threads.
-__global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int *bin_ptr, int *cursor, int *pad_ptr,
-                                                    int *zero_me, SegPlan seg, int *stats, Gate gate)
+// exclusive scan of 256 per-thread partials (two of them at once) by the block's first wavefront, in place;
+// returns the totals through tot / ptot (valid on every thread after the trailing barrier)
+__device__ __forceinline__ void block_scan256(int *part, int *ppart, int *tot2)
 {
-    CHB_GATE(gate);
-    if (zero_me != nullptr && threadIdx.x == 0) *zero_me = 0;   // (the fallback list's counter: saves a launch)
-    __shared__ int part[256], ppart[256];
-    __shared__ int s_tot_pad, s_max_tiles, s_ng, s_ni;
-    if (threadIdx.x == 0) { s_max_tiles = 0; s_ng = 0; s_ni = 0; }
-    const int per = (B + 255) / 256;
-    const int b0 = min(B, (int)threadIdx.x * per), b1 = min(B, b0 + per);
-    int s = 0, sp = 0;
-    for (int b = b0; b < b1; ++b) { s += cnt[b]; sp += (cnt[b] + 31) / 32 * 32; }
-    part[threadIdx.x] = s; ppart[threadIdx.x] = sp;
     __syncthreads();
     if (threadIdx.x < 64) {
-        // exclusive scan of the 256 partials by one wavefront: lane l owns parts 4 l .. 4 l + 3
-        // (threads beyond ceil(B / per) own no bin and contribute zeros)
         const int l = threadIdx.x;
         int loc = 0, ploc = 0;
         for (int i = 0; i < 4; ++i) { loc += part[4 * l + i]; ploc += ppart[4 * l + i]; }
@@ -94,19 +99,59 @@ __global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int *bin_ptr
             part[4 * l + i] = run; ppart[4 * l + i] = prun;
             run += v; prun += pv;
         }
-        if (l == 63) {
-            bin_ptr[B] = run;   // (the totals)
-            if (pad_ptr) pad_ptr[B] = prun;
-            s_tot_pad = prun;
-        }
+        if (l == 63) { tot2[0] = run; tot2[1] = prun; }
     }
     __syncthreads();
-    int run = part[threadIdx.x], prun = ppart[threadIdx.x];
-    const long long tot_tiles = s_tot_pad / 32;
+}
+
+// cursor[key] = exclusive scan of cnt over the B * nsh keys (the fill's write cursors); bin_ptr = the same per bin;
+// pad_ptr (optional) = per bin with every bin's count rounded up to a multiple of 32 (the padded layout of the shortlist
+// stage).  One block of 256 threads.  Also: the batch's segment plan and bin-size statistics (see SegPlan).
+__global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int nsh, int *bin_ptr, int *cursor, int *pad_ptr,
+                                                    int *zero_me, SegPlan seg, int *stats, Gate gate)
+{
+    CHB_GATE(gate);
+    if (zero_me != nullptr && threadIdx.x == 0) *zero_me = 0;   // (the fallback list's counter: saves a launch)
+    __shared__ int part[256], ppart[256], tot2[2];
+    __shared__ int s_max_tiles, s_ng, s_ni;
+    if (threadIdx.x == 0) { s_max_tiles = 0; s_ng = 0; s_ni = 0; }
+    // ---- phase 1: the keys
+    const int BK = B * nsh;
+    {
+        const int per = (BK + 255) / 256;
+        const int k0 = min(BK, (int)threadIdx.x * per), k1 = min(BK, k0 + per);
+        int s = 0;
+        for (int k = k0; k < k1; ++k) s += cnt[k];
+        part[threadIdx.x] = s; ppart[threadIdx.x] = 0;
+        block_scan256(part, ppart, tot2);
+        int run = part[threadIdx.x];
+        for (int k = k0; k < k1; ++k) {
+            cursor[k] = run;
+            run += cnt[k];
+            cnt[k] = 0;   // left clean for the next count (launch_bucket_base needs no separate fill)
+        }
+    }
+    const int total = tot2[0];
+    __syncthreads();   // (cursor is read back below; tot2 is reused)
+    // ---- phase 2: the bins
+    const int per = (B + 255) / 256;
+    const int b0 = min(B, (int)threadIdx.x * per), b1 = min(B, b0 + per);
+    auto count_of = [&](int b) { return (b + 1 < B ? cursor[(b + 1) * nsh] : total) - cursor[b * nsh]; };
+    int sp = 0;
+    for (int b = b0; b < b1; ++b) sp += (count_of(b) + 31) / 32 * 32;
+    part[threadIdx.x] = 0; ppart[threadIdx.x] = sp;
+    block_scan256(part, ppart, tot2);
+    if (threadIdx.x == 0) {
+        bin_ptr[B] = total;
+        if (pad_ptr) pad_ptr[B] = tot2[1];
+    }
+    int prun = ppart[threadIdx.x];
+    const long long tot_tiles = tot2[1] / 32;
     for (int b = b0; b < b1; ++b) {
-        bin_ptr[b] = run; cursor[b] = run;
+        const int c = count_of(b);
+        bin_ptr[b] = cursor[b * nsh];
         if (pad_ptr) pad_ptr[b] = prun;
-        const int ntile = (cnt[b] + 31) / 32;
+        const int ntile = (c + 31) / 32;
         if (stats != nullptr) atomicMax(&s_max_tiles, ntile);
         if (seg.gflag != nullptr) {
             // the batch's segment plan: a bin far larger than the rest becomes up to 16 work items of its own
@@ -126,36 +171,39 @@ __global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int *bin_ptr
             }
             seg.gflag[b] = g;
         }
-        run += cnt[b]; prun += (cnt[b] + 31) / 32 * 32;
-        cnt[b] = 0;   // left clean for the next count (launch_bucket_base needs no separate fill)
+        prun += (c + 31) / 32 * 32;
     }
     if (seg.gflag != nullptr || stats != nullptr) {
         __syncthreads();
         if (threadIdx.x == 0) {
             if (seg.nseg != nullptr) *seg.nseg = s_ni;
-            if (stats != nullptr) { stats[0] = s_max_tiles; stats[1] = (int)tot_tiles; }
+            // (stats[2], stats[3]: wave-tiles skipped / seen, accumulated by the coming shortlist launch)
+            if (stats != nullptr) { stats[0] = s_max_tiles; stats[1] = (int)tot_tiles; stats[2] = 0; stats[3] = 0; stats[4] = 0; }
         }
     }
 }
 
-// Block-aggregated fill: one global atomic per (block, bin) instead of one per sample.
+// Block-aggregated fill: one global atomic per (block, key) instead of one per sample.
 __global__ __launch_bounds__(256) void fill_base_kernel(const int *labels, const int *inb, int N, int B,
-                                                        int *cursor, int *memb_id, Gate gate)
+                                                        int *cursor, int *memb_id, const float4 *ms,
+                                                        const float *shell_inv, int nsh, Gate gate)
 {
     CHB_GATE(gate);
-    extern __shared__ int sh[];      // [B] local counts, then [B] block base offsets
-    int *cnt = sh, *base = sh + B;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) cnt[b] = 0;
+    extern __shared__ int sh[];      // [B * nsh] local counts, then [B * nsh] block base offsets
+    const int BK = B * nsh;
+    int *cnt = sh, *base = sh + BK;
+    for (int b = threadIdx.x; b < BK; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     int l = -1, my = 0;
     if (p < N) {
         l = labels[p];
         if (!(l >= 0 && l < B && inb[p] < 0)) l = -1;
+        else l = member_key(l, p, ms, shell_inv, nsh);
     }
     if (l >= 0) my = atomicAdd(&cnt[l], 1);
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x)
+    for (int b = threadIdx.x; b < BK; b += blockDim.x)
         base[b] = cnt[b] ? atomicAdd(&cursor[b], cnt[b]) : 0;
     __syncthreads();
     if (l >= 0) memb_id[base[l] + my] = p;
@@ -545,6 +593,50 @@ void launch_select_row(const int *labels, const double *row, int N, int c, int m
     hipLaunchKernelGGL(select_row_kernel, dim3(1), dim3(256), 0, s, labels, row, N, c, m, out_idx, out_cnt);
 }
 
+#ifdef CHB_DEV_KNOBS
+// developer builds (CHB_SL_VALIDATE=1): the shortlist stage's output and the index arrays behind it, checked before the
+// hull kernels consume them: err = {code, bin, position, value}; 1 count out of range, 2 fewer candidates than min(m, bin
+// size), 3 candidate id out of range, 4 member id out of range, 5 seating order out of range, 6 a position seated twice
+// (err[4 ..]: one counter per position, zeroed by the caller)
+__global__ void validate_batch_kernel(const int *cand, const int *cand_cnt, int B, int Kcap, int pos_begin, int pos_end,
+                                      int cap, int N, const int *bin_ptr, const int *memb_id, const int *qord, int m,
+                                      int *err)
+{
+    const int nq = pos_end - pos_begin;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    auto report = [&](int code, int c, int pos, int val) {
+        if (atomicCAS(&err[0], 0, code) == 0) { err[1] = c; err[2] = pos; err[3] = val; }
+    };
+    if (idx < (long long)B * nq) {
+        const int c = (int)(idx / nq), pos = pos_begin + (int)(idx % nq);
+        const size_t slot = (size_t)c * Kcap + pos;
+        const int cnt = cand_cnt[slot], nb = bin_ptr[c + 1] - bin_ptr[c];
+        if (cnt < 0 || cnt > cap) report(1, c, pos, cnt);
+        else {
+            if (cnt < (m < nb ? m : nb)) report(2, c, pos, cnt);
+            for (int i = 0; i < cnt; ++i) {
+                const int id = cand[slot * cap + i];
+                if (id < 0 || id >= N) { report(3, c, pos, id); break; }
+            }
+        }
+    }
+    if (idx < bin_ptr[B]) { const int id = memb_id[idx]; if (id < 0 || id >= N) report(4, -1, (int)idx, id); }
+    if (qord != nullptr && idx < nq) {
+        const int q = qord[idx];
+        if (q < pos_begin || q >= pos_end) report(5, -1, (int)idx, q);
+        else if (atomicAdd(&err[4 + q - pos_begin], 1) != 0) report(6, -1, (int)idx, q);   // seated twice
+    }
+}
+
+void launch_validate_batch(const int *cand, const int *cand_cnt, int B, int Kcap, int pos_begin, int pos_end, int cap, int N,
+                           const int *bin_ptr, const int *memb_id, const int *qord, int m, int *err, hipStream_t s)
+{
+    const long long n = std::max<long long>((long long)B * (pos_end - pos_begin), N);
+    hipLaunchKernelGGL(validate_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cand, cand_cnt, B, Kcap,
+                       pos_begin, pos_end, cap, N, bin_ptr, memb_id, qord, m, err);
+}
+#endif
+
 void launch_fill_i32(int *p, int v, int n, hipStream_t s)
 {
     if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n, g_gate);
@@ -556,16 +648,20 @@ void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, in
 
 void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int *bin_ptr,
                         int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s, const int *open_bq,
-                        int open_K, int *open_lab_old, const SegPlan *seg, int *stats)
+                        int open_K, int *open_lab_old, const SegPlan *seg, int *stats, const void *ms,
+                        const float *shell_inv, int nsh, unsigned long long *ckey, int ck_lo, int ck_hi)
 {
-    // (cnt is all zero here: allocated zeroed, and scan_kernel clears what it has read)
+    // (cnt is all zero here: allocated zeroed, and scan_kernel clears what it has read; cnt / cursor hold B * nsh keys)
+    if (ms == nullptr || shell_inv == nullptr || nsh < 1) nsh = 1;
+    const float4 *ms4 = reinterpret_cast<const float4 *>(ms);
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * sizeof(int), s, labels, inb, N, B, cnt, open_bq,
-                       open_K, open_lab_old, g_gate);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, bin_ptr, cursor, pad_ptr, zero_me,
+    hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * nsh * sizeof(int), s, labels, inb, N, B, cnt, open_bq,
+                       open_K, open_lab_old, ms4, shell_inv, nsh, ckey, ck_lo, ck_hi, g_gate);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, nsh, bin_ptr, cursor, pad_ptr, zero_me,
                        seg ? *seg : SegPlan{}, stats, g_gate);
-    hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * sizeof(int), s, labels, inb, N, B, cursor, memb_id, g_gate);
+    hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * nsh * sizeof(int), s, labels, inb, N, B,
+                       cursor, memb_id, ms4, shell_inv, nsh, g_gate);
 }
 
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,

@@ -168,7 +168,7 @@ struct PackBufs {
         for (auto *b : f)
             if ((e = b->ensure(rows + 64)) != hipSuccess) return e;
         if ((e = bb.ensure(4 * B)) != hipSuccess) return e;
-        if ((e = tsn.ensure(rows / 32 + B + 4)) != hipSuccess) return e;
+        if ((e = tsn.ensure(rows / 32 + B + 68)) != hipSuccess) return e;   // (+ 64: the tile-skipping kernel reads 64 at a time)
         return pad_ptr.ensure(B + 1);
     }
     void release()
@@ -200,8 +200,10 @@ struct chb_ctx {
     DevBuf<int> bq, lab_old, lab_prev, lab_new, first_change;
     int *bq_cur = nullptr;      // the open batch's sample indices: bq.p, or a window of perm (no copy)
     int *fc_host = nullptr;     // pinned landing places of the two first_change slots (4 ints each, as on the device)
-    int *fc_cur = nullptr;      // slot of the open batch (first_change.p + 0 / 4): {first changed position, tiles of the
-                                // batch's largest bin, tiles of all bins, -}: the bin sizes ride home with the verdict
+    int *fc_cur = nullptr;      // slot of the open batch (first_change.p + 0 / 8): {first changed position, tiles of the
+                                // batch's largest bin, tiles of all bins, wave-tiles skipped / seen by the first
+                                // workgroups of its shortlist launch}: bin sizes and skip statistics ride home with the
+                                // verdict in one 20-byte copy
     hipEvent_t fc_event[2] = {nullptr, nullptr};
     bool speculate = true;      // CHB_SPECULATE=0: never enqueue the next batch ahead of the convergence test
     bool argmin_in_place = false;   // chb_fit_cluster without exchange: argmin also stores the label to lab_prev
@@ -242,6 +244,17 @@ struct chb_ctx {
     int seg_gcap = 0;
     int hint_max_tiles = 0, hint_total_tiles = 0;
     bool allow_segments = true;   // CHB_SEGMENTS=0: never (A/B tests)
+    // shells: the CSR of the base members is keyed (bin, shell of the member's distance from the bin's centre), outermost
+    // shell first, so that the rows of a 32-row tile have similar norms (tile skipping in the shortlist kernel)
+    DevBuf<float> shell_inv;
+    int nsh = 1;
+    // tile skipping in the base shortlist launch (needs the shells above and queries seated by nearest bin centre):
+    // nearest-centre keys, the seating order, and the fit's verdict on whether it pays (0 undecided = on, 1 on, -1 off)
+    DevBuf<unsigned long long> ckey;
+    DevBuf<int> qord;
+    bool allow_skip = true;       // CHB_TILE_SKIP=0: never (A/B tests)
+    int skip_state = 0, skip_batches = 0, skip_off_B = -1;
+    long long skip_skipped = 0, skip_seen = 0, skip_unloaded = 0;
     DevBuf<float> tau;
     // scratch for the indexed / explicit-point entry points
     DevBuf<int> xq, xhull, xcnt;
@@ -337,7 +350,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->lab_old.ensure(K));
     HIPCHK(h->lab_prev.ensure(Kpad));
     HIPCHK(h->lab_new.ensure(Kpad));
-    HIPCHK(h->first_change.ensure(8));
+    HIPCHK(h->first_change.ensure(16));
     h->fc_cur = h->first_change.p;
     HIPCHK(h->mind.ensure(Kpad));
     HIPCHK(h->mind2.ensure(Kpad));
@@ -351,9 +364,9 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->l1i.ensure(K * B * m));
     HIPCHK(h->l0c.ensure(K * B));
     HIPCHK(h->l1c.ensure(K * B));
-    { const size_t had = h->cnt.cap; HIPCHK(h->cnt.ensure(B)); if (h->cnt.cap != had) HIPCHK(hipMemsetAsync(h->cnt.p, 0, sizeof(int) * h->cnt.cap, h->stream)); }
+    { const size_t had = h->cnt.cap; HIPCHK(h->cnt.ensure(B * (size_t)kShells)); if (h->cnt.cap != had) HIPCHK(hipMemsetAsync(h->cnt.p, 0, sizeof(int) * h->cnt.cap, h->stream)); }
     HIPCHK(h->bin_ptr.ensure(B + 1));
-    HIPCHK(h->cursor.ensure(B));
+    HIPCHK(h->cursor.ensure(B * (size_t)kShells));
     HIPCHK(h->memb_id.ensure((size_t)h->N));
     HIPCHK(h->cnt2.ensure(B));
     HIPCHK(h->bin_ptr2.ensure(B + 1));
@@ -375,6 +388,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->pk.ensure((size_t)h->N + 32 * B, B, (size_t)h->Dz));
         HIPCHK(h->pk2.ensure(2 * K + 32 * B, B, (size_t)h->Dz));
         h->seg_gcap = (int)std::min<size_t>(64, B / 4 + 1);
+        HIPCHK(h->ckey.ensure(K));
+        HIPCHK(h->qord.ensure(K));
         HIPCHK(h->seg_nseg.ensure(1));
         HIPCHK(h->seg_gflag.ensure(B));
         HIPCHK(h->seg_items.ensure(16 * (size_t)h->seg_gcap));
@@ -406,6 +421,9 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     // the fp16 shortlist stage and the tuned kernels hold lists of up to 16 entries; beyond that the plain
     // one-wavefront-per-problem kernels run (brute-force selection, LDS-resident solver)
     h->pf_fit = h->use_prefilter && h->shadow_ok && m <= kMaxM;
+    // (a fit that found nothing to skip settles it for later fits over the same samples and bin count)
+    h->skip_state = (h->skip_off_B == (int)B) ? -1 : 0;
+    h->skip_batches = 0; h->skip_skipped = 0; h->skip_seen = 0; h->skip_unloaded = 0;
     h->fused = h->allow_fused && h->pf_fit && h->pf_base && h->pf_update && fused_supported(m, h->Dp);
     HIPCHK(h->pin_a.ensure((size_t)h->N));
     int *lab = h->pin_a.p;
@@ -425,10 +443,11 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     HIPCHK(h->inb.ensure((size_t)h->N));
     HIPCHK(hipMemcpyAsync(h->labels.p, lab, sizeof(int) * h->N, hipMemcpyHostToDevice, h->stream));
     launch_fill_i32(h->inb.p, -1, (int)h->N, h->stream);
-    HIPCHK(h->cnt.ensure((size_t)B));
+    HIPCHK(h->cnt.ensure((size_t)B * kShells));
     HIPCHK(hipMemsetAsync(h->cnt.p, 0, sizeof(int) * h->cnt.cap, h->stream));   // (kept zero by scan_kernel from here on)
     HIPCHK(h->bin_ptr.ensure((size_t)B + 1));
-    HIPCHK(h->cursor.ensure((size_t)B));
+    HIPCHK(h->cursor.ensure((size_t)B * kShells));
+    h->nsh = 1;
     HIPCHK(h->memb_id.ensure((size_t)h->N));
     if (h->pf_fit) {
         // Bin centres for the shortlist stage: the mean of each bin's initially labelled members
@@ -440,6 +459,12 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
         launch_bin_centers(h->X.p, h->D, h->Dp, h->memb_id.p, h->bin_ptr.p, h->B, h->centers.p, h->stream);
         launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
                              h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, nullptr, nullptr, h->stream);
+        // the unit of the CSR's shell key per bin (from the initially labelled members; fixed for the fit)
+        int nsh = kShells;
+        while (nsh > 1 && (int64_t)B * nsh > kMaxKeys) nsh >>= 1;
+        HIPCHK(h->shell_inv.ensure((size_t)B));
+        launch_shell_scale(h->ms.p, h->memb_id.p, h->bin_ptr.p, h->B, nsh, h->shell_inv.p, h->stream);
+        h->nsh = nsh;
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -462,6 +487,8 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
     // have more than kSegMinTiles tiles and four times the average
     SegPlan sp{};
     const bool pf_base_path = h->pf_fit && h->pf_base && h->cand.p;
+    // tile skipping: on until the fit's first batches have shown that it skips (next to) nothing
+    const bool skip_on = pf_base_path && h->allow_skip && h->nsh > 1 && h->skip_state >= 0 && h->ckey.p != nullptr;
     if (pf_base_path && h->seg_gflag.p) {
         sp.nseg = h->seg_nseg.p; sp.items = h->seg_items.p; sp.gflag = h->seg_gflag.p; sp.lists = h->seg_lists.p;
         sp.cap = 16 * h->seg_gcap; sp.gcap = h->seg_gcap;
@@ -473,7 +500,9 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         Timed t(h, "bucket", (double)h->N);
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
                            h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, h->nflag.p, s, h->bq_cur, K, h->lab_old.p,
-                           sp.gflag ? &sp : nullptr, h->fc_cur + 1);
+                           sp.gflag ? &sp : nullptr, h->fc_cur + 1, pf_base_path ? h->ms.p : nullptr,
+                           skip_on ? h->shell_inv.p : nullptr, skip_on ? h->nsh : 1,
+                           skip_on ? h->ckey.p : nullptr, q_lo, q_hi);
     }
     TopmArgs a{};
     a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = q_lo; a.pos_end = q_hi;
@@ -492,7 +521,9 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             // bounds, and the batch's query-to-centre norms: one launch
             Timed t(h, "bucket", 0.0);
             launch_pack_build(h->Zs.p, h->ms.p, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->pk.view(), h->X.p,
-                              h->D, h->Dp, h->bq_cur, q_lo, q_hi, h->Kcap, h->centers.p, h->shadow_scale, h->qn.p, s);
+                              h->D, h->Dp, h->bq_cur, q_lo, q_hi, h->Kcap, h->centers.p, h->shadow_scale, h->qn.p, s,
+                              skip_on ? h->ckey.p : nullptr);
+            if (skip_on) launch_query_order(h->ckey.p, q_lo, q_hi, h->B, h->qord.p, s);
         }
         ShortlistArgs pa{};
         pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
@@ -505,11 +536,37 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         if (fusedp) pa.tau_out = h->tau.p;
         pa.seg = sp;
         if (sp.launch) h->stats_seg_batches += 1;
+        if (skip_on) { pa.qord = h->qord.p; pa.skip = 1; pa.skip_stat = h->fc_cur + 3; }
+#ifdef CHB_DEV_KNOBS
+        if (skip_on) { if (const char *ev = getenv("CHB_SKIP_NEVER")) if (atoi(ev)) pa.skip = 1 | 2 * atoi(ev); }
+        if (const char *ev = getenv("CHB_SL_TRACE")) { int tc = -1, tp = 0; if (sscanf(ev, "%d,%d", &tc, &tp) == 2) { pa.trace_c1 = tc + 1; pa.trace_pos = tp; } }
+#endif
+#ifdef CHB_DEV_KNOBS
+        // CHB_SL_DBG=<file>: per-wavefront timeline of the 10th base shortlist launch of the process (tools/sl_timeline.py)
+        static int dbg_launch = 0;
+        static unsigned long long *dbg_dev = nullptr;
+        const char *dbg_path = getenv("CHB_SL_DBG");
+        const size_t dbg_words = (size_t)65536 * 16;
+        if (dbg_path != nullptr && ++dbg_launch == 10) {
+            HIPCHK(hipMalloc(&dbg_dev, dbg_words * 8));
+            HIPCHK(hipMemsetAsync(dbg_dev, 0, dbg_words * 8, s));
+            pa.dbg = dbg_dev;
+        }
+#endif
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
             pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;   // (counter reset by the CSR scan / the batch CSR kernel)
             launch_shortlist(pa, h->flags64.p, s);
         }
+#ifdef CHB_DEV_KNOBS
+        if (pa.dbg != nullptr) {
+            std::vector<unsigned long long> hostd(dbg_words);
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpy(hostd.data(), dbg_dev, dbg_words * 8, hipMemcpyDeviceToHost));
+            if (FILE *fp = fopen(dbg_path, "wb")) { fwrite(hostd.data(), 8, dbg_words, fp); fclose(fp); }
+            HIPCHK(hipFree(dbg_dev)); dbg_dev = nullptr;
+        }
+#endif
         if (!fusedp) {
             RescoreArgs ra{};
             ra.X = h->X.p; ra.Dp = h->Dp; ra.bq = h->bq_cur; ra.pos_begin = q_lo; ra.pos_end = q_hi;
@@ -527,6 +584,23 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             Timed t(h, "topm_fallback", 0.0);
             launch_topm_flagged(a, h->flags64.p, h->flaglist.p, h->nflag.p, s);
         }
+#ifdef CHB_DEV_KNOBS
+        if (fusedp && getenv("CHB_SL_VALIDATE") != nullptr) {
+            static int *verr = nullptr;
+            if (verr == nullptr) HIPCHK(hipMalloc(&verr, 16 + 4 * 65536));
+            HIPCHK(hipMemsetAsync(verr, 0, 16 + 4 * 65536, s));
+            launch_validate_batch(h->cand.p, h->cand_cnt.p, h->B, h->Kcap, q_lo, q_hi, kCandCap, (int)h->N, h->bin_ptr.p,
+                                  h->memb_id.p, skip_on ? h->qord.p : nullptr, h->m, verr, s);
+            int herr[4];
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpy(herr, verr, 16, hipMemcpyDeviceToHost));
+            if (herr[0] != 0) {
+                fprintf(stderr, "[chb validate] code %d bin %d position %d value %d (batch positions %d..%d, skip %d)\n", herr[0],
+                        herr[1], herr[2], herr[3], q_lo, q_hi, (int)skip_on);
+                return fail(CHB_ESTATE, "shortlist validation failed");
+            }
+        }
+#endif
     } else {
         Timed t(h, "topm_base", (double)(q_hi - q_lo) * h->hint_base_members);
         if (h->m > kMaxM) launch_topm_generic(a, s); else launch_topm(a, s);
@@ -751,6 +825,7 @@ int chb_create(int device_id, chb_ctx **out)
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->fc_event[i], hipEventDisableTiming);
     if (const char *ev = getenv("CHB_SPECULATE")) h->speculate = atoi(ev) != 0;
     if (const char *ev = getenv("CHB_SEGMENTS")) h->allow_segments = atoi(ev) != 0;
+    if (const char *ev = getenv("CHB_TILE_SKIP")) h->allow_skip = atoi(ev) != 0;
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
     return CHB_OK;
@@ -777,6 +852,7 @@ int chb_destroy(chb_ctx *h)
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
     h->slow.release(); h->n_slow.release(); h->tau.release();
     h->seg_nseg.release(); h->seg_gflag.release(); h->seg_items.release(); h->seg_lists.release();
+    h->shell_inv.release(); h->ckey.release(); h->qord.release();
     (void)hipStreamDestroy(h->stream);
     if (h->fc_host) (void)hipHostFree(h->fc_host);
     for (int i = 0; i < 2; ++i) if (h->fc_event[i]) (void)hipEventDestroy(h->fc_event[i]);
@@ -807,6 +883,7 @@ static int samples_upload(chb_ctx *h, const double *X, int64_t N, int64_t D, boo
 // everything that is a function of the resident X alone (global mean, scale, query-side shadow rows)
 static int samples_finish(chb_ctx *h)
 {
+    h->skip_off_B = -1;
     const int64_t N = h->N, D = h->D;
     const int Dp = h->Dp;
     // the shortlist stage (prefilter_kernels.hip) keeps its query fragments in registers: D <= 160
@@ -1140,15 +1217,26 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 launch_fill_i32(h->fc_cur, g.K, 1, s);
                 launch_first_change(h->lab_new.p, h->lab_prev.p, active, g.K, h->fc_cur, s);
             }
-            HIPCHK(hipMemcpyAsync(h->fc_host + 4 * slot, h->fc_cur, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(h->fc_host + 8 * slot, h->fc_cur, 6 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(h->fc_event[slot], s));
             return CHB_OK;
         };
         auto wait_round = [&](const Geom &g, int active, int slot, int *f) -> int {
             HIPCHK(hipEventSynchronize(h->fc_event[slot]));
-            *f = h->fc_host[4 * slot];
-            // (bin sizes of that batch, for the segment decision of the batches still to be enqueued)
-            h->hint_max_tiles = h->fc_host[4 * slot + 1]; h->hint_total_tiles = h->fc_host[4 * slot + 2];
+            *f = h->fc_host[8 * slot];
+            // (bin sizes of that batch, for the segment decision of the batches still to be enqueued; and what the tile
+            //  skipping of its shortlist launch achieved: a fit whose first batches skip next to nothing turns it off)
+            h->hint_max_tiles = h->fc_host[8 * slot + 1]; h->hint_total_tiles = h->fc_host[8 * slot + 2];
+            if (h->fc_host[8 * slot + 4] > 0) {
+                h->skip_skipped += h->fc_host[8 * slot + 3]; h->skip_seen += h->fc_host[8 * slot + 4];
+                h->skip_unloaded += h->fc_host[8 * slot + 5];
+                if (h->skip_state == 0 && ++h->skip_batches >= 3)
+                {
+                    // (it pays from a few per cent of the wave-tiles)
+                    h->skip_state = ((h->skip_skipped + h->skip_unloaded) * 50 >= h->skip_seen + h->skip_unloaded) ? 1 : -1;
+                    if (h->skip_state < 0) h->skip_off_B = h->B;
+                }
+            }
             // positions [active, K) now carry this round's labels (single rank: the argmin kernel has
             // already written them to lab_prev)
             if (xchg)
@@ -1159,7 +1247,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         // batch start + guess + round 0, nothing read back
         auto open_batch = [&](const Geom &g, int slot) -> int {
             h->bq_cur = h->perm.p + g.t0;   // the batch's sample indices: a window of the sweep's permutation
-            h->fc_cur = h->first_change.p + 4 * slot;
+            h->fc_cur = h->first_change.p + 8 * slot;
             h->hint_base_members = (double)((it == 0) ? assigned0 + g.t0 : labelled - g.K);
             h->hint_batch_entries = (double)((it == 0) ? g.K : 2 * g.K);
             h->argmin_in_place = !xchg;
@@ -1212,7 +1300,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             Snap snap{};
             if (spec) {
                 snap = save();
-                g_gate = Gate{h->first_change.p + 4 * slot, K};   // "this batch's round 0 changed nothing"
+                g_gate = Gate{h->first_change.p + 8 * slot, K};   // "this batch's round 0 changed nothing"
                 rc = batch_commit_dev(h, h->lab_prev.p);
                 if (rc) return rc;
                 rc = open_batch(geom_at(t1), slot ^ 1);
@@ -1677,6 +1765,11 @@ int chb_counter(chb_ctx *h, const char *name, int64_t *out)
     }
     if (!strcmp(name, "fused_enabled")) { *out = h->fused ? 1 : 0; return CHB_OK; }
     if (!strcmp(name, "segment_batches")) { *out = h->stats_seg_batches; return CHB_OK; }
+    // tile skipping of the last fit: its verdict (0 undecided, 1 kept on, -1 turned off) and the sampled wave-tile counters
+    if (!strcmp(name, "tile_skip_state")) { *out = h->skip_state; return CHB_OK; }
+    if (!strcmp(name, "tile_skipped")) { *out = h->skip_skipped; return CHB_OK; }
+    if (!strcmp(name, "tile_seen")) { *out = h->skip_seen; return CHB_OK; }
+    if (!strcmp(name, "tile_unloaded")) { *out = h->skip_unloaded; return CHB_OK; }
     if (!strcmp(name, "last_batch_k")) { *out = h->K; return CHB_OK; }
     if (!strcmp(name, "prefilter_enabled")) { *out = (h->use_prefilter && h->shadow_ok) ? 1 : 0; return CHB_OK; }
     return fail(CHB_EINVAL, "unknown counter");

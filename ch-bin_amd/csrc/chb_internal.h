@@ -87,6 +87,9 @@ void launch_global_shadow(const double *X, int N, int D, int Dp, const double *m
                           unsigned short *Gs, int Dz, void *gq, hipStream_t s);
 void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
                         double *centers, hipStream_t s);
+// shell_inv[c] = nsh / (1.25 x largest ||zh|| of the CSR's members of bin c) (0: empty bin): the unit of the shell key
+void launch_shell_scale(const void *ms, const int *memb_id, const int *bin_ptr, int B, int nsh, float *shell_inv,
+                        hipStream_t s);
 // member-side row of each listed sample relative to the centre of its current bin:
 // Zs[N][Dz], ms[N] = float4 {bias, rho, ||zh||^2, amax}
 // (commit form: ids = the batch, new_lab[i] = final label of ids[i]: the kernel also writes it to
@@ -103,7 +106,12 @@ void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, co
 // P.bb; qn[B][Kcap] = float2 {||(x_j - mu_c) S||^2 rounded up, rounded down} of the batch's queries
 void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
                        int B, int rows_hint, const MemberPack &P, const double *X, int D, int Dp, const int *bq,
-                       int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s);
+                       int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s,
+                       unsigned long long *ckey = nullptr);
+// (ckey, optional: [pos_end - pos_begin], pre-set to ~0 by the caller: the query-norm tiles leave {N_jc bits, bin} of every
+//  position's nearest bin centre there)
+// qord[0 .. pos_end - pos_begin) = the positions sorted by the bin of their key (positions without a key last)
+void launch_query_order(const unsigned long long *ckey, int pos_begin, int pos_end, int B, int *qord, hipStream_t s);
 
 // Plan of the bins that are cut into segments for the shortlist stage (see shortlist_kernel, SEG): made on the device
 // by the CSR scan of the batch start, consumed by the three shortlist launches of the batch.
@@ -128,6 +136,12 @@ struct ShortlistArgs {
     double S;
     const int *bq;
     int pos_begin, pos_end;
+    const int *qord;           // optional: the order in which the queries are seated ([pos_end - pos_begin] positions sorted
+                               // by nearest bin centre); nullptr: by position
+    int skip;                  // base mode: 1 = skip member tiles by the norm bound (needs shell-ordered members to pay)
+    int *skip_stat;            // optional: [3] wave-tiles skipped / seen / never loaded, reported by the first 64 workgroups
+    unsigned long long *dbg;   // developer builds: per workgroup {start, end (100 MHz clock), tiles computed, hardware id}
+    int trace_c1, trace_pos;   // developer builds: bin + 1 (0: off) and batch position whose tile decisions are printed
     const int *bin_ptr;        // (unpadded) CSR the pack was built from
     const int *memb_id;
     bool update;               // update mode: the batch's own entries, fixed tau from `seed`
@@ -233,6 +247,10 @@ void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const 
 
 // label / bucket helpers
 void launch_fill_i32(int *p, int v, int n, hipStream_t s);
+#ifdef CHB_DEV_KNOBS
+void launch_validate_batch(const int *cand, const int *cand_cnt, int B, int Kcap, int pos_begin, int pos_end, int cap, int N,
+                           const int *bin_ptr, const int *memb_id, const int *qord, int m, int *err, hipStream_t s);
+#endif
 // batch end: labels[bq[i]] = lab[i], inb[bq[i]] = -1  (batch start -- lab_old[i] = labels[bq[i]], inb[bq[i]] = i --
 // rides in launch_bucket_base)
 void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, int K, hipStream_t s);
@@ -245,7 +263,15 @@ void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, in
 void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int *bin_ptr,
                         int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s,
                         const int *open_bq = nullptr, int open_K = 0, int *open_lab_old = nullptr,
-                        const SegPlan *seg = nullptr, int *stats = nullptr);
+                        const SegPlan *seg = nullptr, int *stats = nullptr, const void *ms = nullptr,
+                        const float *shell_inv = nullptr, int nsh = 1, unsigned long long *ckey = nullptr, int ck_lo = 0,
+                        int ck_hi = 0);
+// (ckey, optional, with open_bq: nearest-centre keys of the batch positions [ck_lo, ck_hi) reset to ~0)
+// (stats: [4] ints -- tiles of the largest bin, tiles of all bins, and two counters zeroed here for the shortlist launch)
+// (ms + shell_inv + nsh > 1, optional: the members of a bin are grouped by SHELLS of their distance from the bin's centre,
+//  outermost first -- cnt / cursor then hold B * nsh entries; see member_key in aux_kernels.hip)
+constexpr int kShells = 16;       // shells per bin (fewer when B * kShells would exceed kMaxKeys)
+constexpr int kMaxKeys = 8192;    // CSR keys the count / fill kernels keep in LDS
 // CSR of the batch's own members: earlier positions under lab_prev, later positions under lab_old
 // (also starts the round's scalars: *first_change = K, *n_slow = 0, *nflag = 0 where the pointers are non-null)
 void launch_bucket_batch(const int *lab_prev, const int *lab_old, const int *bq, int K, int B,

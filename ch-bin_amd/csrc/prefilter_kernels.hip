@@ -363,14 +363,38 @@ __global__ __launch_bounds__(256) void pack_centered_kernel(const double *X, int
     }
 }
 
+// shell_inv[c] = nsh / (1.25 x the largest ||zh|| among the bin's members): the per-fit unit of the CSR's shell key
+// (member_key in aux_kernels.hip), from the initially labelled members; 0 for an empty bin.  One block per bin.
+__global__ __launch_bounds__(256) void shell_scale_kernel(const float4 *ms, const int *memb_id, const int *bin_ptr, int nsh,
+                                                          float *shell_inv)
+{
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    const int b0 = bin_ptr[c], cnt = bin_ptr[c + 1] - b0;
+    float u = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const float z = ms[memb_id[b0 + e]].z;
+        u = fmaxf(u, z == z ? z : 0.f);
+    }
+    red[threadIdx.x] = u;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) shell_inv[c] = red[0] > 0.f ? (float)nsh / (1.25f * sqrtf(red[0])) : 0.f;
+}
+
 // bb[c] = {largest rounding distance, largest ||zh|| (rounded up), largest ||zh||^2 + 2|<..>|, largest bias residual}
 // over the members of bin c, from the per-sample rows the pack is gathered FROM (ms[memb_id[..]]): independent of the
 // pack kernel's output, so that both can share one launch
 // tsn[tile] (tiles of the padded layout, first tile of the bin = pad0 / 32): the largest ||zh|| of each 32-row tile --
 // the query-rounding term of the shortlist kernel is taken per TILE, so that one stray member (a contig far from the
 // centre of the bin it sits in for the moment) loosens the bounds of its own tile only, not of the whole bin
+// suffix: tsn[t] = the largest ||zh|| of tile t AND of every later tile of the bin (tile skipping: the members come in
+// shells of decreasing norm, and a bound that never grows along the bin makes "nobody needs this tile" final for the rest)
 __device__ __forceinline__ void bin_bounds_from_source(const float4 *ms, const int *memb_id, const int *bin_ptr, int c,
-                                                       float4 *bb, float *tsn, int pad0)
+                                                       float4 *bb, float *tsn, int pad0, bool suffix)
 {
     __shared__ float red[4][256];
     const int b0 = bin_ptr[c], cnt = bin_ptr[c + 1] - b0;
@@ -387,6 +411,24 @@ __device__ __forceinline__ void bin_bounds_from_source(const float4 *ms, const i
     }
     red[0][threadIdx.x] = v; red[1][threadIdx.x] = u; red[2][threadIdx.x] = a; red[3][threadIdx.x] = rs;
     __syncthreads();
+    if (suffix && threadIdx.x < 64) {
+        // one wavefront, from the last tile backwards in chunks of 64 (the block's own writes: visible behind the barrier)
+        const int lane = (int)threadIdx.x, nt = (cnt + 31) / 32;
+        float *tb = tsn + pad0 / 32;
+        float carry = 0.f;
+        for (int hi = nt; hi > 0; hi -= 64) {
+            const int t = hi - 64 + lane;
+            float x = t >= 0 ? tb[t] : 0.f;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_down(x, off, 64);
+                if (lane + off < 64) x = fmaxf(x, o);
+            }
+            x = fmaxf(x, carry);
+            if (t >= 0) tb[t] = x;
+            carry = __shfl(x, 0, 64);
+        }
+    }
     for (int off = 128; off >= 1; off >>= 1) {
         if ((int)threadIdx.x < off)
             for (int q = 0; q < 4; ++q)
@@ -408,6 +450,8 @@ struct QnArgs {
     const double *centers;
     double S;
     float2 *qn;
+    unsigned long long *ckey;   // optional, [pos_end - pos_begin] (pre-set to ~0): 64-bit minimum of {N_jc bits, bin} over the
+                                // bins = the position's nearest bin centre (the shortlist launch's query order)
 };
 
 __device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, int tile_y)
@@ -480,6 +524,79 @@ __device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, in
                 qn[(size_t)c * Kcap + pos] = make_float2(round_up_f32(acc[i][j] * (1.0 + 1e-12)),
                                                         (float)(acc[i][j] * (1.0 - 1e-6)));
         }
+    if (q.ckey != nullptr) {
+        // nearest centre of my two positions among this tile's 64 bins: 4 bins here, 16 lanes (tx) per position
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned long long key = ~0ull;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + tx + 16 * j;
+                if (c < B && acc[i][j] == acc[i][j]) {
+                    const unsigned long long k = ((unsigned long long)__float_as_uint((float)acc[i][j]) << 32) | (unsigned)c;
+                    key = k < key ? k : key;
+                }
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                const unsigned long long o = __shfl_xor(key, off, 64);
+                key = o < key ? o : key;
+            }
+            const int pos = p0 + 2 * ty + i;
+            if (tx == 0 && pos < pos_end && key != ~0ull) atomicMin(&q.ckey[pos - pos_begin], key);
+        }
+    }
+}
+
+// qord[0 .. nq) = the positions [pos_begin, pos_end) sorted by their nearest bin centre (counting sort in one workgroup;
+// positions without a key last): the order in which the shortlist kernel seats its queries, so that the 32 queries of a
+// wavefront (and mostly the 128 of a workgroup) look at a bin from the same side and agree on the tiles they can skip.
+__global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long long *ckey, int pos_begin, int nq, int B,
+                                                           int *qord, Gate gate)
+{
+    CHB_GATE(gate);
+    extern __shared__ int sh[];   // [B + 1] counts -> cursors, [1024] scan partials
+    int *cnt = sh, *part = sh + B + 1;
+    const int tid = threadIdx.x;
+    for (int b = tid; b <= B; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    for (int i = tid; i < nq; i += 1024) {
+        const unsigned long long k = ckey[i];
+        const unsigned c = (unsigned)(k & 0xffffffffu);
+        atomicAdd(&cnt[(k != ~0ull && c < (unsigned)B) ? (int)c : B], 1);
+    }
+    __syncthreads();
+    const int per = (B + 1 + 1023) / 1024;
+    const int b0 = min(B + 1, tid * per), b1 = min(B + 1, b0 + per);
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += cnt[b];
+    part[tid] = s;
+    __syncthreads();
+    if (tid < 64) {
+        int loc = 0;
+        for (int i = 0; i < 16; ++i) loc += part[16 * tid + i];
+        int inc = loc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off, 64);
+            if (tid >= off) inc += o;
+        }
+        int run = inc - loc;
+        for (int i = 0; i < 16; ++i) {
+            const int v = part[16 * tid + i];
+            part[16 * tid + i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int b = b0; b < b1; ++b) { const int c = cnt[b]; cnt[b] = run; run += c; }
+    __syncthreads();
+    for (int i = tid; i < nq; i += 1024) {
+        const unsigned long long k = ckey[i];
+        const unsigned c = (unsigned)(k & 0xffffffffu);
+        qord[atomicAdd(&cnt[(k != ~0ull && c < (unsigned)B) ? (int)c : B], 1)] = pos_begin + i;
+    }
 }
 
 // One launch for three independent pieces of a batch start (each used to be a launch of its own, each too small to fill
@@ -492,7 +609,7 @@ __global__ __launch_bounds__(256) void pack_build_kernel(const unsigned short *Z
     CHB_GATE(gate);
     const int b = blockIdx.x;
     if (b < npack) pack_rows_block(Zs, q.D, Dz, memb_id, bin_ptr, pad_ptr, B, P, b, npack);
-    else if (b < npack + B) bin_bounds_from_source(ms, memb_id, bin_ptr, b - npack, P.bb, P.tsn, pad_ptr[b - npack]);
+    else if (b < npack + B) bin_bounds_from_source(ms, memb_id, bin_ptr, b - npack, P.bb, P.tsn, pad_ptr[b - npack], q.ckey != nullptr);
     else query_norms_tile(q, (b - npack - B) % nqx, (b - npack - B) / nqx);
 }
 
@@ -583,12 +700,30 @@ __device__ __forceinline__ void list_insert_desc(float (&l)[ML], float v)
 //            of the union is exactly what one workgroup streaming the whole bin would have found), derives tau and
 //            shortlists the segment's members; segments append to the same (query, bin) shortlist through its
 //            global counter.
-template <int ML, bool UPD, int KS, int SEG = 0>
+// The tile-skipping builds' flush in the MIDDLE of a bin, as a real function call: inlined, its code costs the 128-VGPR
+// builds registers inside the tile loop; as a call the live registers are saved around it on this rare path only.
+// pool / cnt / qpos: this wavefront's parked entries, per-query counters and positions (LDS, through generic pointers).
+__device__ __noinline__ void shortlist_flush_call(const unsigned *pool, int npark, int *cnt, const int *qpos, int *cand_bin,
+                                                  int cand_cap, const int *memb, int lane)
+{
+    for (int i = lane; i < npark; i += 64) {
+        const unsigned en = pool[i];
+        const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));
+        const int off = atomicAdd(&cnt[qc], 1);
+        if (off < cand_cap) cand_bin[(size_t)qpos[qc] * cand_cap + off] = memb[e];
+    }
+}
+
+template <int ML, bool UPD, int KS, int SEG = 0, bool SKIP = false>
 __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
                                                                          int bpw, int *flags64, int nqt64, Gate gate)
 {
     CHB_GATE(gate);
     static_assert(SEG == 0 || !UPD, "segments exist for base members only");
+#ifdef CHB_DEV_KNOBS
+    const unsigned long long dbg_t0 = wall_clock64();
+    int dbg_tiles = 0;
+#endif
     constexpr int CPR = 2 * KS;              // 16-byte chunks per shadow row
     constexpr int ROWB = 32 * KS;            // bytes per shadow row
     constexpr int TILEB = kPfP * ROWB;       // one member tile
@@ -630,8 +765,14 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
     const int m = a.m;
 
     // my query: lane (col, h) owns B[k = 16 s + 8 h + j][col] of its global-centred row
-    const int qpos = pos0 + 32 * w + col;
-    const bool qvalid = qpos < a.pos_end;
+    // (seated by position, or -- a.qord -- in the order of their nearest bin centre)
+    const int qseat = pos0 + 32 * w + col;
+    const bool qvalid = qseat < a.pos_end;
+    const int qpos = (a.qord != nullptr && qvalid) ? a.qord[qseat - a.pos_begin] : qseat;
+    int *sQpos = reinterpret_cast<int *>(sGb + kPfQ);   // [kPfQ] position of every seat of the workgroup (for the flush)
+    // [4] tile skipping: "somebody in the workgroup needs tile t" for t = 0 .. 3 (mod 4); accessed by LDS address only
+    const unsigned need_base = lds_addr(sQpos + kPfQ);
+    if (h == 0) sQpos[32 * w + col] = qpos;
     f16x8 qreg[KS];
     float nq, rg;
     {
@@ -666,7 +807,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
     const unsigned char *zall = reinterpret_cast<const unsigned char *>(a.P.Z);
 
     // ---- issue side of the tile stream: (bin ic, sweep isw, tile it), two tiles ahead of the consumer
-    int ic = c0, it = 0, isw = (UPD || SEG == 2) ? 1 : 0, ibuf = 0, n_issued = 0;
+    int ic = c0, it = 0, isw = (UPD || SEG == 2) ? 1 : 0, ibuf = 0;
     int irow0 = 0, int_ = 0;   // first padded row and tile count of bin ic
     bool ivalid = false;
     // move to the first / next non-empty bin
@@ -700,14 +841,18 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
             const float *p_ = (h ? a.P.sn : a.P.cb) + row_ + col;                                  \
             __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB + 256), 4, 0, 0); \
         }                                                                                          \
-        ++n_issued;                                                                                \
         if (++ibuf == NBUF) ibuf = 0;                                                              \
-        if (++it == int_) {                                                                        \
-            it = 0;                                                                                \
-            if (!UPD && SEG == 0 && isw == 0) isw = 1;                                             \
-            else { isw = (UPD || SEG == 2) ? 1 : 0; ++ic; CHB_SL_ISSUE_SEEK() }                    \
-        }                                                                                          \
+        ++n_issued;                                                                                \
+        if (++it == int_) CHB_SL_ISSUE_NEXTRUN()                                                   \
     }
+    // on to the next (bin, sweep) of the stream: at the end of a run of tiles, or -- tile skipping -- earlier
+#define CHB_SL_ISSUE_NEXTRUN()                                                                     \
+    {                                                                                              \
+        it = 0;                                                                                    \
+        if (!UPD && SEG == 0 && isw == 0) isw = 1;                                                 \
+        else { isw = (UPD || SEG == 2) ? 1 : 0; ++ic; CHB_SL_ISSUE_SEEK() }                        \
+    }
+    int n_issued = 0, n_consumed = 0;
     CHB_SL_ISSUE_SEEK()
     if (ivalid) CHB_SL_ISSUE()
     if (ivalid) CHB_SL_ISSUE()
@@ -753,14 +898,15 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
             int off = atomicAdd(&sCnt[32 * w + qc], 1);                                            \
             if (SEG == 2) off += sGb[32 * w + qc];                                                 \
             if (off < a.cand_cap)                                                                  \
-                a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * a.cand_cap + off] = a.memb_id[mb_ + e]; \
+                a.cand[((size_t)c * a.Kcap + sQpos[32 * w + qc]) * a.cand_cap + off] = a.memb_id[mb_ + e]; \
         }                                                                                          \
         if (SEG == 2) {                                                                            \
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                 \
             if (h == 0) sCnt[32 * w + col] = 0;                                                    \
         }                                                                                          \
     }
-    int cbuf = 0, n_consumed = 0;
+    int cbuf = 0;
+    int wt_seen = 0, wt_skipped = 0, wt_unloaded = 0;   // tiles this wavefront met / skipped / found not loaded (statistics)
     for (int c = c0; c < c1; ++c) {
         const int row0 = a.P.pad_ptr[c];
         int ntile = (a.P.pad_ptr[c + 1] - row0) / kPfP;
@@ -780,9 +926,23 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
         // (query, tile) that shifts the thresholds (update mode: per member, in the accumulator's start value)
         const float rgq = rg * (1.0f + 4.0f * kSlack);
         const float *tsn_c = UPD ? nullptr : a.P.tsn + (row0 >> 5) + seg_tb;
+
         const float nj_hi = (qn2.x + E) * (1.0f + kSlack);
         const float nj_lo = (qn2.y - E) * (qn2.y > E ? (1.0f - kSlack) : (1.0f + kSlack));
         const float rsum = bb.x * (1.0f + kSlack);
+        // tile skipping (base mode, a.skip): every member p of a tile has  S d(j, p) >= ||z_j|| - ||zh_p|| - rho_p
+        // >= zn_lo - sn_tile - rho_bin  (triangle inequality through the bin's centre; sn_tile = P.tsn); a tile whose bound
+        // exceeds an upper bound of the m-th nearest distance holds no member of the top m.  Sweep 1: the bound hi the
+        // admission test uses; sweep 0: the running bound tau_run of the list so far (+inf until it is full).
+        const float zn_lo = sqrtf(fmaxf(nj_lo, 0.f)) * (1.0f - 4.0f * kSlack) - rsum;
+        float tau_run = INFINITY, hi_s1 = INFINITY;
+#ifdef CHB_DEV_KNOBS
+        const bool kSkipNever = (a.skip & 2) != 0;   // (CHB_SKIP_NEVER: the skipping build with every tile needed, for A/B timing)
+        const bool kNoExit = (a.skip & 4) != 0, kNoWaveSkip = (a.skip & 8) != 0, kNoMidFlush = (a.skip & 16) != 0;
+#else
+        constexpr bool kSkipNever = false;
+#endif
+        constexpr bool can_skip = SKIP;   // (its own build: the flags and bounds cost registers the 128-VGPR builds lack)
         // sweep 0: the m largest accumulator values (= m smallest t) seen by this lane half,
         // descending; the first ML - m slots are pinned at +inf so that the m-th largest is lb[ML - 1]
         float lb[ML];
@@ -803,8 +963,13 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
             }
         }
         if (h == 0) sCnt[32 * w + col] = 0;
-        const bool tile_best = SEG != 0 || ntile >= a.tile_best_min;
+        // (per-tile bests assume that the m nearest members sit in different tiles, i.e. a random member order; with the
+        //  shell order of tile skipping they crowd into the same few tiles, so every value competes then)
+        const bool tile_best = !SKIP && (SEG != 0 || ntile >= a.tile_best_min) && !(!UPD && a.skip != 0);
         int wcnt = 0;   // entries parked by this wavefront and not yet written out (wave-uniform)
+#ifdef CHB_DEV_TRACE
+        int dbg_nhit = 0, dbg_s1tiles = 0, dbg_s0tiles = 0, dbg_flushes = 0;
+#endif
         if (SEG == 2) {
             // the m best accumulators of every segment of this bin (phase-1 launch): their union's m-th best
             float *sl = a.seg.lists + ((size_t)seg_g * 16 * a.Kcap + (qvalid ? qpos : a.pos_end - 1)) * ML;
@@ -816,6 +981,18 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 
         for (int sweep = (UPD || SEG == 2) ? 1 : 0; sweep < (SEG == 1 ? 1 : 2); ++sweep) {
             const float rgs = (sweep ? rg : -rg) * (1.0f + kSlack);
+            // tile skipping: the tiles' norm bounds of this run, 64 of them across the lanes of a VGPR (an ordinary load,
+            // once per sweep and then every 61 tiles: its wait drains the tile DMA queue, which at that rate costs nothing;
+            // the table has slack behind); a bound is then one v_readlane
+            float v_tsn = 0.f;
+            int tbase = 0;
+            if (SKIP && ntile > 0) {
+                v_tsn = tsn_c[lane];
+                asm volatile("" : "+v"(v_tsn));   // (waited for here, not at a use inside the tile loop)
+                // (the "somebody needs tile t" flags of this sweep; nobody reads the previous sweep's any more: its last
+                //  tiles' successors in the stream were this sweep's first tiles, which are always loaded)
+                if (tid < 4) lds_write_u32(need_base + 4u * (unsigned)tid, 0u);
+            }
             if (!UPD && sweep == 1) {
                 // end of sweep 0: m-th smallest t over BOTH lane halves -> tau -> thr2
                 // (SEG = 2: both halves hold the same merged list of all segments already)
@@ -840,19 +1017,92 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                     tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
                     const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
                     thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
+                    hi_s1 = hi * (1.0f + 4.0f * kSlack);
                 }
                 // for the fused selection path: tau bounds the m-th distance among these members -- the update
                 // stage's threshold and (smallest over the bins) the label guess
                 if (h == 0) sTau[32 * w + col] = tau;
             }
-            for (int ct = 0; ct < ntile; ++ct) {
+            // Tile skipping (SKIP builds).  The tiles' norm bounds never grow along a bin (P.tsn holds suffix maxima, and
+            // the thresholds only tighten), so the tiles a query can still need are a PREFIX of the run: every wavefront
+            // posts "one of my queries needs tile ct + 3" (LDS flags, made visible by the next barrier); when the flag of
+            // the tile about to be requested (two ahead) is down, nobody needs it or any later tile: the run ends two
+            // tiles from here, for the issue side (on to the next sweep / bin at once) and for the consumers alike.
+            int nt_run = ntile;
+            for (int ct = 0; ct < nt_run; ++ct) {
                 wait_vmcnt(n_issued - n_consumed > 1 ? n_w : 0);   // my pieces of this tile have landed
+                if (can_skip) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (and my flag writes)
                 __builtin_amdgcn_s_barrier();   // everybody's have; the buffer two tiles ahead is free again
+                if (can_skip && ct + 2 < nt_run && ct + 2 >= 3) {
+                    // (the issue side stands at tile ct + 2 of this very run)
+                    // (asm read: the compiler would order an ordinary LDS read behind the tile DMA -- vmcnt(0))
+                    int nd;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=v"(nd) : "v"(need_base + 4u * (unsigned)((ct + 2) & 3)) : "memory");
+#ifdef CHB_DEV_KNOBS
+                    if (kNoExit) nd = 1;
+#endif
+                    if (__builtin_amdgcn_readfirstlane(nd) == 0) {
+                        nt_run = ct + 2;
+                        CHB_SL_ISSUE_NEXTRUN()
+                    }
+                }
                 if (ivalid) CHB_SL_ISSUE()
+                if (can_skip && tid == 0) lds_write_u32(need_base + 4u * (unsigned)((ct + 1) & 3), 0u);   // (read one tile ago; next written in two)
 
                 const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
                 // rows held by this lane: (r & 3) + 8 (r >> 2) + 4 h
                 const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
+                float tsn_t = 0.f, tsn_3 = 0.f;   // largest member norm of this tile (and of the rest of the bin) / three tiles on
+                if (SKIP) {
+                    if (ct + 3 - tbase >= 64) { tbase = ct; v_tsn = tsn_c[ct + lane]; asm volatile("" : "+v"(v_tsn)); }   // (waited for here, not at a use)
+                    tsn_t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_tsn), ct - tbase));
+                    tsn_3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_tsn), ct + 3 - tbase));
+                }
+                bool do_tile = true;
+                if (can_skip) {
+                    const float thr_now = sweep == 0 ? tau_run : hi_s1;
+                    // does anybody of this wavefront need tile ct + 3?  (with the threshold as it stands: it only tightens)
+                    if (ct + 3 < nt_run) {
+                        const bool need3 = (qvalid && !(zn_lo - tsn_3 * (1.0f + kSlack) > thr_now)) || kSkipNever;
+                        if (__ballot(need3) != 0ull && lane == 0) lds_write_u32(need_base + 4u * (unsigned)((ct + 3) & 3), 1u);
+                    }
+                    // and this tile: no fragment reads, no matrix core, no selection code for a wavefront none of whose
+                    // queries can find a member of its top m here (the barriers stay: they are the workgroup's)
+                    const bool need0 = (qvalid && !(zn_lo - tsn_t * (1.0f + kSlack) > thr_now)) || kSkipNever;
+                    ++wt_seen;
+#ifdef CHB_DEV_KNOBS
+                    if (__ballot(need0) == 0ull && !kNoWaveSkip) { do_tile = false; ++wt_skipped; }
+#else
+                    if (__ballot(need0) == 0ull) { do_tile = false; ++wt_skipped; }
+#endif
+#ifdef CHB_DEV_TRACE
+                    if (a.trace_c1 == c + 1 && qvalid && qpos == a.trace_pos)
+                        printf("[trace] bin %d pos %d half %d sweep %d tile %d/%d: tsn %g zn_lo %g thr %g need0 %d do %d tau_run %g hi_s1 %g thr_s %g\n",
+                               c, qpos, h, sweep, ct, nt_run, (double)tsn_t, (double)zn_lo, (double)thr_now, (int)need0,
+                               (int)do_tile, (double)tau_run, (double)hi_s1, (double)thr_s);
+#endif
+                }
+#ifdef CHB_DEV_TRACE
+                // (a.skip & 32: shadow execution -- a tile the wavefront would skip is computed all the same, and every
+                //  member it would have admitted / listed is reported)
+                const bool shadow = !do_tile && (a.skip & 32) != 0;
+                if (shadow) do_tile = true;
+#endif
+                if (!do_tile) {
+#ifdef CHB_DEV_KNOBS
+                    if (a.skip & 128) asm volatile("s_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127" ::: "memory");   // (E1: as slow as a computed tile)
+#endif
+                    ++n_consumed;
+                    if (++cbuf == NBUF) cbuf = 0;
+                    continue;
+                }
+#ifdef CHB_DEV_KNOBS
+                ++dbg_tiles;
+#endif
+#ifdef CHB_DEV_TRACE
+                if (sweep == 0) ++dbg_s0tiles; else ++dbg_s1tiles;
+#endif
                 f32x16 acc;
                 if (UPD) {
                     f32x4 nv[4], nn[4], sv[4], bv[4];
@@ -887,10 +1137,10 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 }
-                // base mode: the tile's largest member norm, a SCALAR load (an ordinary vector load here would make the
-                // compiler drain the tile DMA queue); it is complete behind the fragment reads' lgkmcnt(0) below
-                float tsn_t = 0.f;
-                if (!UPD) {
+                // base mode (builds without tile skipping): the tile's largest member norm, a SCALAR load (an ordinary vector
+                // load here would make the compiler drain the tile DMA queue); it is complete behind the fragment reads'
+                // lgkmcnt(0) below
+                if (!UPD && !SKIP) {
                     const unsigned long long ta = reinterpret_cast<unsigned long long>(tsn_c + ct);
                     const unsigned ta_lo = __builtin_amdgcn_readfirstlane((unsigned)ta);
                     const unsigned ta_hi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
@@ -911,11 +1161,18 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                         af[9] = lds_read_frag<256>(fa1);
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
-                               "+v"(af[6]), "+v"(af[7]), "+v"(af[8]), "+s"(tsn_t)
-                             :
-                             : "memory");
+                if (SKIP)
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                                   "+v"(af[6]), "+v"(af[7]), "+v"(af[8])
+                                 :
+                                 : "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                                   "+v"(af[6]), "+v"(af[7]), "+v"(af[8]), "+s"(tsn_t)
+                                 :
+                                 : "memory");
                 if (KS == 10) asm volatile("" : "+v"(af[KS - 1]) : : "memory");
 #pragma unroll
                 for (int sx = 0; sx < KS; ++sx)
@@ -929,6 +1186,12 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                     float mx = acc[0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+#ifdef CHB_DEV_TRACE
+                    if (SKIP && shadow && qvalid && mx - dlt > thr_s)
+                        printf("[shadow] sweep 0 bin %d pos %d half %d tile %d: mx %.9g dlt %g thr_s %.9g tsn %g zn_lo %g tau_run %g nj_hi %g rsum %g\n",
+                               c, qpos, h, ct, (double)mx, (double)dlt, (double)thr_s, (double)tsn_t, (double)zn_lo, (double)tau_run,
+                               (double)nj_hi, (double)rsum);
+#endif
                     if (tile_best) {
                         // Large bins: only the BEST of the 16 values enters the list.  The m-th best
                         // of per-(tile, lane half) bests is the m-th best of m distinct members, i.e.
@@ -937,11 +1200,15 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                         if (mx - dlt > thr_s) {
                             list_insert_desc<ML>(lb, mx - dlt);
                             thr_s = lb[ML - 1];
+                            if (can_skip && thr_s > -INFINITY)
+                                tau_run = (sqrtf(fmaxf(-2.0f * thr_s + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum) * (1.0f + 4.0f * kSlack);
                         }
                     } else
                     while (mx - dlt > thr_s) {
                         list_insert_desc<ML>(lb, mx - dlt);
                         thr_s = lb[ML - 1];
+                        if (can_skip && thr_s > -INFINITY)
+                            tau_run = (sqrtf(fmaxf(-2.0f * thr_s + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum) * (1.0f + 4.0f * kSlack);
                         float nx = -INFINITY;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -952,9 +1219,24 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                     }
                 } else {
                     // make room (wave-uniform).  Only in the builds for m > 8 (update mode: ML = 2), whose
-                    // shortlists are long: in the 128-VGPR builds the extra code pushes query fragments into
-                    // scratch inside this loop
-                    if ((ML > 8 || (UPD && ML > 1)) && wcnt >= kPoolW / 2 && wcnt <= kPoolW) {
+                    // shortlists are long, and in the tile-skipping builds, whose workgroups hold queries of ONE
+                    // neighbourhood (in their own bin all of them park candidates); in the 128-VGPR builds the extra
+                    // code pushes query fragments into scratch inside this loop
+                    if (SKIP && ML <= 8) {
+#ifdef CHB_DEV_KNOBS
+                        if (wcnt >= kPoolW / 2 && wcnt <= kPoolW && !kNoMidFlush) {
+#else
+                        if (wcnt >= kPoolW / 2 && wcnt <= kPoolW) {
+#endif
+                            shortlist_flush_call(sPool + w * kPoolW, wcnt, sCnt + 32 * w, sQpos + 32 * w,
+                                                 a.cand + (size_t)c * a.Kcap * a.cand_cap, a.cand_cap,
+                                                 a.memb_id + a.bin_ptr[c], lane);
+                            wcnt = 0;
+#ifdef CHB_DEV_TRACE
+                            ++dbg_flushes;
+#endif
+                        }
+                    } else if ((ML > 8 || (UPD && ML > 1)) && wcnt >= kPoolW / 2 && wcnt <= kPoolW) {
                         CHB_SL_FLUSH()
                         wcnt = 0;
                     }
@@ -963,6 +1245,13 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const bool hit = acc[r] >= thr_t;
+#ifdef CHB_DEV_TRACE
+                        dbg_nhit += hit ? 1 : 0;
+                        if (SKIP && shadow && hit && qvalid)
+                            printf("[shadow] sweep 1 bin %d pos %d half %d tile %d row %d: acc %.9g thr_t %.9g thr2 %.9g dlt %g tsn %g zn_lo %g hi_s1 %g nj_lo %g nj_hi %g rsum %g\n",
+                                   c, qpos, h, ct, r, (double)acc[r], (double)thr_t, (double)thr2, (double)dlt, (double)tsn_t,
+                                   (double)zn_lo, (double)hi_s1, (double)nj_lo, (double)nj_hi, (double)rsum);
+#endif
                         const unsigned long long bal = __ballot(hit);
                         if (bal) {
                             const int before = __builtin_amdgcn_mbcnt_hi(
@@ -978,6 +1267,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                 ++n_consumed;
                 if (++cbuf == NBUF) cbuf = 0;
             }
+            if (can_skip) wt_unloaded += ntile - nt_run;
         }
 
         if (SEG == 1) {
@@ -1003,6 +1293,19 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
         CHB_SL_FLUSH()
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
+#ifdef CHB_DEV_TRACE
+        if (SKIP && (a.skip & 64) != 0) {
+            const int nh = dbg_nhit + __shfl_xor(dbg_nhit, 32, 64);
+            const int nb = a.bin_ptr[c + 1] - a.bin_ptr[c];
+            if (qvalid && h == 0 && ccount < (m < nb ? m : nb))
+                printf("[short] bin %d (%d members, %d tiles) pos %d sample %d wave %d col %d: count %d hits %d wcnt %d flushes %d tiles s0 %d s1 %d thr2 %.9g hi_s1 %g zn_lo %g tau %.9g S %.9g rsum %g\n",
+                       c, nb, ntile, qpos, a.bq[qpos], w, col, ccount, nh, wcnt, dbg_flushes, dbg_s0tiles, dbg_s1tiles, (double)thr2,
+                       (double)hi_s1, (double)zn_lo, (double)sTau[32 * w + col], (double)a.S, (double)rsum);
+        }
+        if (SKIP && a.trace_c1 == c + 1 && qvalid && qpos == a.trace_pos && h == 0)
+            printf("[trace] bin %d pos %d: ntile %d count %d wcnt %d nj_lo %g nj_hi %g rsum %g E %g\n", c, qpos, ntile, ccount, wcnt,
+                   (double)nj_lo, (double)nj_hi, (double)rsum, (double)E);
+#endif
         if (qvalid && h == 0) {
             // (SEG = 2: the bin's counter is the sum of its segments' reservations; the last one past the capacity
             //  flags the pair, and the brute-force fallback then rewrites list and count)
@@ -1015,14 +1318,28 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
             }
         }
     }
+#ifdef CHB_DEV_KNOBS
+    if (a.dbg != nullptr && lane == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + w) * 4;
+        d[0] = dbg_t0; d[1] = wall_clock64(); d[2] = (unsigned long long)dbg_tiles; d[3] = hw;
+    }
+#endif
+    if (SKIP && a.skip_stat != nullptr && blockIdx.x < 64 && lane == 0) {
+        atomicAdd(&a.skip_stat[0], wt_skipped);
+        atomicAdd(&a.skip_stat[1], wt_seen);
+        atomicAdd(&a.skip_stat[2], wt_unloaded);
+    }
 #undef CHB_SL_FLUSH
 #undef CHB_SL_ISSUE
+#undef CHB_SL_ISSUE_NEXTRUN
 #undef CHB_SL_ISSUE_SEEK
 }
 
 static size_t shortlist_lds_bytes(int ks, int ml)
 {
-    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 3 * kPfQ * 4;
+    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 4 * kPfQ * 4 + 16;
 }
 
 template <int ML, bool UPD>
@@ -1033,7 +1350,10 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
     const int nqt64 = (nq + kQTile - 1) / kQTile;
     // bins per workgroup: long tile streams per workgroup, but enough workgroups for the 256 CUs x 4
     const long long units = (long long)nqt * a.B;
-    int bpw = (int)std::max<long long>(1, units / ((UPD ? 1024 : 2048) * 4 / kPfW));
+    // (tile skipping: the workgroups' run lengths differ by what they could skip -- short ones, many, for an even finish)
+    bool skip_build = false;
+    if constexpr (!UPD) skip_build = a.skip != 0;
+    int bpw = (int)std::max<long long>(1, units / ((UPD ? 1024 : skip_build ? 8192 : 2048) * 4 / kPfW));
 #ifdef CHB_DEV_KNOBS
     static int env_bpw = -2;
     if (env_bpw == -2) { const char *e = getenv("CHB_SL_BPW"); env_bpw = e ? atoi(e) : 0; }
@@ -1043,7 +1363,16 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
     const int nchunk = (a.B + bpw - 1) / bpw;
     const int total = nqt * nchunk;
     const int grid = ((total + 7) / 8) * 8;
-    if (a.Dz == 144)
+    if (skip_build) {
+        if constexpr (!UPD) {
+            if (a.Dz == 144)
+                hipLaunchKernelGGL((shortlist_kernel<ML, false, 9, 0, true>), dim3(grid), dim3(64 * kPfW),
+                                   shortlist_lds_bytes(9, ML), s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+            else
+                hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 0, true>), dim3(grid), dim3(64 * kPfW),
+                                   shortlist_lds_bytes(10, ML), s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+        }
+    } else if (a.Dz == 144)
         hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(64 * kPfW), shortlist_lds_bytes(9, ML), s, a,
                            nqt, nchunk, bpw, flags64, nqt64, g_gate);
     else
@@ -1095,6 +1424,14 @@ void launch_global_shadow(const double *X, int N, int D, int Dp, const double *m
                            reinterpret_cast<float2 *>(gq));
 }
 
+void launch_shell_scale(const void *ms, const int *memb_id, const int *bin_ptr, int B, int nsh, float *shell_inv,
+                        hipStream_t s)
+{
+    if (B > 0)
+        hipLaunchKernelGGL(shell_scale_kernel, dim3(B), dim3(256), 0, s, reinterpret_cast<const float4 *>(ms), memb_id,
+                           bin_ptr, nsh, shell_inv);
+}
+
 void launch_bin_centers(const double *X, int D, int Dp, const int *memb_id, const int *bin_ptr, int B,
                         double *centers, hipStream_t s)
 {
@@ -1121,16 +1458,24 @@ void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, co
                        P.pad_ptr, centers, mu_g, S, Dz, P, g_gate);   // (bounds: into P.bb, zeroed by the batch-CSR kernel)
 }
 
+void launch_query_order(const unsigned long long *ckey, int pos_begin, int pos_end, int B, int *qord, hipStream_t s)
+{
+    if (pos_end > pos_begin)
+        hipLaunchKernelGGL(query_order_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 1 + 1024), s, ckey, pos_begin,
+                           pos_end - pos_begin, B, qord, g_gate);
+}
+
 void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
                        int B, int rows_hint, const MemberPack &P, const double *X, int D, int Dp, const int *bq,
-                       int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s)
+                       int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s,
+                       unsigned long long *ckey)
 {
     if (B <= 0) return;
     const long long rows = (long long)rows_hint + 32LL * B;
     const int npack = (int)std::max<long long>(1, std::min<long long>((rows + 15) / 16, 16384));
     const int nq = pos_end - pos_begin;
     const int nqx = nq > 0 ? (nq + 31) / 32 : 0, nqy = (B + 63) / 64;
-    const QnArgs q{X, D, Dp, bq, pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn)};
+    const QnArgs q{X, D, Dp, bq, pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn), ckey};
     hipLaunchKernelGGL(pack_build_kernel, dim3(npack + B + nqx * nqy), dim3(256), 0, s, Zs,
                        reinterpret_cast<const float4 *>(ms), Dz, memb_id, bin_ptr, P.pad_ptr, B, P, npack, q,
                        std::max(nqx, 1), g_gate);

@@ -977,3 +977,71 @@ def test_segmented_giant_bin(O, m):
         lab_now[tail[k:]] = first[tail[k:]] if its == 2 else initial[tail[k:]]
         lab_j, _ = O.sweep(X, B, lab_now, np.array([j]), m)
         assert lab_j[j] == got[j]
+
+
+@pytest.mark.parametrize("D,S,m", [(140, 5, 5), (146, 10, 5), (140, 5, 8), (141, 5, 15)])
+def test_tile_skipping_exact(O, D, S, m):
+    """Several coverage columns: the base shortlist launch orders a bin's members in norm shells, seats the queries by
+    their nearest bin centre and ends a (bin, sweep) run of tiles as soon as no query of the workgroup can find a member of
+    its top m in the rest.  Whole fits must equal a context that never skips (CHB_TILE_SKIP=0); the selection under the
+    final labels must equal the brute-force kernel's lists; the oracle replays contigs of the last sweep; and tiles must
+    really have been skipped."""
+    from chbin_amd import _lib
+    N, B = 48_000, 24
+    X, initial, true = _synth(N, D, B, S=S, seed=11, sigma=2e-3, mix=0.2)
+    perms = _perms(initial, 3)
+    a = _lib.Context(0)
+    try:
+        a.set_samples(X)
+        got, its, changed = a.fit_cluster(B, initial, perms, m, 3)
+        state, unloaded = a.counter("tile_skip_state"), a.counter("tile_unloaded")
+        skipped, seen = a.counter("tile_skipped"), a.counter("tile_seen")
+        overflow = a.counter("prefilter_overflow")
+        rng = np.random.default_rng(4)
+        q = rng.choice(np.flatnonzero(initial < 0), 300, replace=False)
+        lists = a.topm_per_bin(got, B, m, q)
+    finally:
+        a.close()
+    # (ten coverage columns leave this generator's bins too round to skip much, and the 15th neighbour is too far to
+    #  bound anything away: the fit may turn the skipping off)
+    if D < 146 and m <= 8:
+        assert state == 1 and unloaded > 0.1 * (seen + unloaded), (state, unloaded, skipped, seen)
+    else:
+        assert state in (1, -1) and seen > 0
+    b = _ctx_env({"CHB_TILE_SKIP": "0"})
+    try:
+        b.set_samples(X)
+        want, its_w, changed_w = b.fit_cluster(B, initial, perms, m, 3)
+        assert b.counter("tile_unloaded") == 0 and b.counter("tile_seen") == 0
+    finally:
+        b.close()
+    assert its == its_w and np.array_equal(changed, changed_w) and np.array_equal(got, want)
+    assert overflow <= (1e-3 if m <= 5 else 2e-2) * its * perms.shape[1] * B
+    c = _brute_ctx()
+    try:
+        c.set_samples(X)
+        want_lists = c.topm_per_bin(got, B, m, q)
+    finally:
+        c.close()
+    for g, w_ in zip(lists, want_lists):
+        assert np.array_equal(g, w_)
+    # the oracle on the converged labels: a fixed point of the reference sweep (frozen evaluation of a sample)
+    if changed[its - 1] == 0:
+        sample = rng.choice(np.flatnonzero(initial < 0), 96, replace=False)
+        bb, _ = O.eval_frozen_mt(X, B, got, sample, m, 8)
+        assert np.array_equal(bb, got[sample])
+    # and it replays the LAST contigs of the last sweep run
+    tail = perms[its - 1][-8:]
+    prev = initial
+    if its > 1:
+        d = _lib.Context(0)
+        try:
+            d.set_samples(X)
+            prev, _, _ = d.fit_cluster(B, initial, perms[:its - 1], m, its - 1)
+        finally:
+            d.close()
+    for k, j in enumerate(tail):
+        lab_now = got.copy()
+        lab_now[tail[k:]] = prev[tail[k:]]
+        lab_j, _ = O.sweep(X, B, lab_now, np.array([j]), m)
+        assert lab_j[j] == got[j]

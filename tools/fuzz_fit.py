@@ -17,6 +17,7 @@ m16 = len(sys.argv) > 3 and sys.argv[3] == "m16"
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ctx = _lib.default_context()
 bad = 0
+unloaded = seen = 0
 for t in range(n_cases):
     N = int(rng.integers(200, 1800))
     D = int(rng.choice([8, 24, 40, 100, 136, 137, 140, 143, 144, 145, 146, 160, 161, 200]))
@@ -56,8 +57,9 @@ for t in range(n_cases):
     got, its, ch = ctx.fit_cluster(B, initial, perms, m, iters, batch=batch)
     ok = its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
     bad += not ok
+    unloaded += ctx.counter("tile_unloaded"); seen += ctx.counter("tile_seen")
     print(f"[{t:3d}] N={N} D={D} B={B} m={m} iters={iters} batch={batch} sigma={sigma} mix={mix} seeds={n_seed} "
           f"{metric}: {'ok' if ok else 'MISMATCH'} (sweeps {its}/{its_o}, diff labels {int((got != want).sum())})", flush=True)
 ctx.set_metric("convex")
-print("mismatches:", bad)
+print("mismatches:", bad, " tiles never loaded / met (sampled):", unloaded, seen)
 sys.exit(1 if bad else 0)

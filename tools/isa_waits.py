@@ -23,5 +23,5 @@ for i, l in enumerate(src):
             j += 1
             if not src[j].strip().startswith(';'): break
         continue
-    if depth >= 3 and re.search(r'vmcnt\(0\)|scratch_', l):
+    if depth >= int(sys.argv[3] if len(sys.argv) > 3 else 3) and re.search(r'vmcnt\(0\)|scratch_', l):
         print(f'   line {i+1} depth {depth} {label}: {l.strip()[:70]}')

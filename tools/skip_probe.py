@@ -10,5 +10,5 @@ perms = synth.draw_permutations(initial, 2, seed=0)
 ctx = _lib.Context(0)
 ctx.set_samples(X)
 lab, its, ch = ctx.fit_cluster(B, initial, perms, 5, 2)
-print("skip state", ctx.counter("tile_skip_state"), "skipped", ctx.counter("tile_skipped"), "seen", ctx.counter("tile_seen"),
+print("skip state", ctx.counter("tile_skip_state"), "skipped", ctx.counter("tile_skipped"), "seen", ctx.counter("tile_seen"), "unloaded", ctx.counter("tile_unloaded"),
       "overflow", ctx.counter("prefilter_overflow"), "acc", float((lab == true).mean()))
