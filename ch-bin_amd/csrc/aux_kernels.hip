@@ -600,8 +600,9 @@ void launch_select_row(const int *labels, const double *row, int N, int c, int m
 // (err[4 ..]: one counter per position, zeroed by the caller)
 __global__ void validate_batch_kernel(const int *cand, const int *cand_cnt, int B, int Kcap, int pos_begin, int pos_end,
                                       int cap, int N, const int *bin_ptr, const int *memb_id, const int *qord, int m,
-                                      int *err)
+                                      int *err, Gate gate)
 {
+    CHB_GATE(gate);   // (a speculated batch whose launches all returned at once has nothing to check)
     const int nq = pos_end - pos_begin;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     auto report = [&](int code, int c, int pos, int val) {
@@ -633,7 +634,7 @@ void launch_validate_batch(const int *cand, const int *cand_cnt, int B, int Kcap
 {
     const long long n = std::max<long long>((long long)B * (pos_end - pos_begin), N);
     hipLaunchKernelGGL(validate_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cand, cand_cnt, B, Kcap,
-                       pos_begin, pos_end, cap, N, bin_ptr, memb_id, qord, m, err);
+                       pos_begin, pos_end, cap, N, bin_ptr, memb_id, qord, m, err, g_gate);
 }
 #endif
 

@@ -597,6 +597,14 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             if (herr[0] != 0) {
                 fprintf(stderr, "[chb validate] code %d bin %d position %d value %d (batch positions %d..%d, skip %d)\n", herr[0],
                         herr[1], herr[2], herr[3], q_lo, q_hi, (int)skip_on);
+                if (herr[0] >= 5 && skip_on && q_hi - q_lo <= 256) {
+                    const int nq = q_hi - q_lo;
+                    std::vector<unsigned long long> ck(nq); std::vector<int> qo(nq);
+                    HIPCHK(hipMemcpy(ck.data(), h->ckey.p, 8 * (size_t)nq, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(qo.data(), h->qord.p, 4 * (size_t)nq, hipMemcpyDeviceToHost));
+                    for (int i = 0; i < nq; ++i)
+                        fprintf(stderr, "  i %d key bin %d bits %08x  qord %d\n", i, (int)(ck[i] & 0xffffffffu), (unsigned)(ck[i] >> 32), qo[i]);
+                }
                 return fail(CHB_ESTATE, "shortlist validation failed");
             }
         }

@@ -27,6 +27,8 @@
  *       CHB_FORCE_GATHER=1  exchange path of the sharded loop even with one rank
  *       CHB_SEGMENTS=0      bins far larger than the rest are never cut into segments for the shortlist stage
  *       CHB_FUSED_STRIPE=0  position-major work order in the m <= 5 fused kernel (default: striped over the XCDs by bin)
+ *       CHB_TILE_SKIP=0     the shortlist stage never skips member tiles (default: on for fits whose first batches
+ *                           show that tiles can be skipped -- data with several coverage columns)
  */
 #ifndef CHBIN_HIP_H
 #define CHBIN_HIP_H
