@@ -539,7 +539,6 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         if (skip_on) { pa.qord = h->qord.p; pa.skip = 1; pa.skip_stat = h->fc_cur + 3; }
 #ifdef CHB_DEV_KNOBS
         if (skip_on) { if (const char *ev = getenv("CHB_SKIP_NEVER")) if (atoi(ev)) pa.skip = 1 | 2 * atoi(ev); }
-        if (const char *ev = getenv("CHB_SL_TRACE")) { int tc = -1, tp = 0; if (sscanf(ev, "%d,%d", &tc, &tp) == 2) { pa.trace_c1 = tc + 1; pa.trace_pos = tp; } }
 #endif
 #ifdef CHB_DEV_KNOBS
         // CHB_SL_DBG=<file>: per-wavefront timeline of the 10th base shortlist launch of the process (tools/sl_timeline.py)

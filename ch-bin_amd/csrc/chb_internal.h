@@ -141,7 +141,6 @@ struct ShortlistArgs {
     int skip;                  // base mode: 1 = skip member tiles by the norm bound (needs shell-ordered members to pay)
     int *skip_stat;            // optional: [3] wave-tiles skipped / seen / never loaded, reported by the first 64 workgroups
     unsigned long long *dbg;   // developer builds: per workgroup {start, end (100 MHz clock), tiles computed, hardware id}
-    int trace_c1, trace_pos;   // developer builds: bin + 1 (0: off) and batch position whose tile decisions are printed
     const int *bin_ptr;        // (unpadded) CSR the pack was built from
     const int *memb_id;
     bool update;               // update mode: the batch's own entries, fixed tau from `seed`

@@ -967,9 +967,6 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
         //  shell order of tile skipping they crowd into the same few tiles, so every value competes then)
         const bool tile_best = !SKIP && (SEG != 0 || ntile >= a.tile_best_min) && !(!UPD && a.skip != 0);
         int wcnt = 0;   // entries parked by this wavefront and not yet written out (wave-uniform)
-#ifdef CHB_DEV_TRACE
-        int dbg_nhit = 0, dbg_s1tiles = 0, dbg_s0tiles = 0, dbg_flushes = 0;
-#endif
         if (SEG == 2) {
             // the m best accumulators of every segment of this bin (phase-1 launch): their union's m-th best
             float *sl = a.seg.lists + ((size_t)seg_g * 16 * a.Kcap + (qvalid ? qpos : a.pos_end - 1)) * ML;
@@ -1076,32 +1073,14 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 #else
                     if (__ballot(need0) == 0ull) { do_tile = false; ++wt_skipped; }
 #endif
-#ifdef CHB_DEV_TRACE
-                    if (a.trace_c1 == c + 1 && qvalid && qpos == a.trace_pos)
-                        printf("[trace] bin %d pos %d half %d sweep %d tile %d/%d: tsn %g zn_lo %g thr %g need0 %d do %d tau_run %g hi_s1 %g thr_s %g\n",
-                               c, qpos, h, sweep, ct, nt_run, (double)tsn_t, (double)zn_lo, (double)thr_now, (int)need0,
-                               (int)do_tile, (double)tau_run, (double)hi_s1, (double)thr_s);
-#endif
                 }
-#ifdef CHB_DEV_TRACE
-                // (a.skip & 32: shadow execution -- a tile the wavefront would skip is computed all the same, and every
-                //  member it would have admitted / listed is reported)
-                const bool shadow = !do_tile && (a.skip & 32) != 0;
-                if (shadow) do_tile = true;
-#endif
                 if (!do_tile) {
-#ifdef CHB_DEV_KNOBS
-                    if (a.skip & 128) asm volatile("s_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127" ::: "memory");   // (E1: as slow as a computed tile)
-#endif
                     ++n_consumed;
                     if (++cbuf == NBUF) cbuf = 0;
                     continue;
                 }
 #ifdef CHB_DEV_KNOBS
                 ++dbg_tiles;
-#endif
-#ifdef CHB_DEV_TRACE
-                if (sweep == 0) ++dbg_s0tiles; else ++dbg_s1tiles;
 #endif
                 f32x16 acc;
                 if (UPD) {
@@ -1186,12 +1165,6 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                     float mx = acc[0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-#ifdef CHB_DEV_TRACE
-                    if (SKIP && shadow && qvalid && mx - dlt > thr_s)
-                        printf("[shadow] sweep 0 bin %d pos %d half %d tile %d: mx %.9g dlt %g thr_s %.9g tsn %g zn_lo %g tau_run %g nj_hi %g rsum %g\n",
-                               c, qpos, h, ct, (double)mx, (double)dlt, (double)thr_s, (double)tsn_t, (double)zn_lo, (double)tau_run,
-                               (double)nj_hi, (double)rsum);
-#endif
                     if (tile_best) {
                         // Large bins: only the BEST of the 16 values enters the list.  The m-th best
                         // of per-(tile, lane half) bests is the m-th best of m distinct members, i.e.
@@ -1232,9 +1205,6 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                                                  a.cand + (size_t)c * a.Kcap * a.cand_cap, a.cand_cap,
                                                  a.memb_id + a.bin_ptr[c], lane);
                             wcnt = 0;
-#ifdef CHB_DEV_TRACE
-                            ++dbg_flushes;
-#endif
                         }
                     } else if ((ML > 8 || (UPD && ML > 1)) && wcnt >= kPoolW / 2 && wcnt <= kPoolW) {
                         CHB_SL_FLUSH()
@@ -1245,13 +1215,6 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const bool hit = acc[r] >= thr_t;
-#ifdef CHB_DEV_TRACE
-                        dbg_nhit += hit ? 1 : 0;
-                        if (SKIP && shadow && hit && qvalid)
-                            printf("[shadow] sweep 1 bin %d pos %d half %d tile %d row %d: acc %.9g thr_t %.9g thr2 %.9g dlt %g tsn %g zn_lo %g hi_s1 %g nj_lo %g nj_hi %g rsum %g\n",
-                                   c, qpos, h, ct, r, (double)acc[r], (double)thr_t, (double)thr2, (double)dlt, (double)tsn_t,
-                                   (double)zn_lo, (double)hi_s1, (double)nj_lo, (double)nj_hi, (double)rsum);
-#endif
                         const unsigned long long bal = __ballot(hit);
                         if (bal) {
                             const int before = __builtin_amdgcn_mbcnt_hi(
@@ -1293,19 +1256,6 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
         CHB_SL_FLUSH()
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
-#ifdef CHB_DEV_TRACE
-        if (SKIP && (a.skip & 64) != 0) {
-            const int nh = dbg_nhit + __shfl_xor(dbg_nhit, 32, 64);
-            const int nb = a.bin_ptr[c + 1] - a.bin_ptr[c];
-            if (qvalid && h == 0 && ccount < (m < nb ? m : nb))
-                printf("[short] bin %d (%d members, %d tiles) pos %d sample %d wave %d col %d: count %d hits %d wcnt %d flushes %d tiles s0 %d s1 %d thr2 %.9g hi_s1 %g zn_lo %g tau %.9g S %.9g rsum %g\n",
-                       c, nb, ntile, qpos, a.bq[qpos], w, col, ccount, nh, wcnt, dbg_flushes, dbg_s0tiles, dbg_s1tiles, (double)thr2,
-                       (double)hi_s1, (double)zn_lo, (double)sTau[32 * w + col], (double)a.S, (double)rsum);
-        }
-        if (SKIP && a.trace_c1 == c + 1 && qvalid && qpos == a.trace_pos && h == 0)
-            printf("[trace] bin %d pos %d: ntile %d count %d wcnt %d nj_lo %g nj_hi %g rsum %g E %g\n", c, qpos, ntile, ccount, wcnt,
-                   (double)nj_lo, (double)nj_hi, (double)rsum, (double)E);
-#endif
         if (qvalid && h == 0) {
             // (SEG = 2: the bin's counter is the sum of its segments' reservations; the last one past the capacity
             //  flags the pair, and the brute-force fallback then rewrites list and count)
