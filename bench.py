@@ -466,7 +466,7 @@ def main():
                                    f"AlgoNumNeighbors={m}, one full fit_cluster sweep from the seed "
                                    "state per step (exact sequential label semantics)",
                        "n_contigs": N, "dim": D, "bins": B, "neighbors": m, "movable": int(n_move),
-                       "qp_per_step": int(qp_per_step), "batch": args.batch or 8192,
+                       "qp_per_step": int(qp_per_step), "batch": int(ctx.counter("batch_size")),
                        "generator": {"mix": args.mix, "sigma": args.sigma, "coverage_columns": S},
                        "parallelism_evidence": evidence,
                        "parallelism": (f"contig-sharded x{world}, " + ("RCCL all-gather in the C++ loop, X by the library's RCCL broadcast (chb_bcast_samples)"

@@ -768,11 +768,14 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
     // (seated by position, or -- a.qord -- in the order of their nearest bin centre)
     const int qseat = pos0 + 32 * w + col;
     const bool qvalid = qseat < a.pos_end;
-    const int qpos = (a.qord != nullptr && qvalid) ? a.qord[qseat - a.pos_begin] : qseat;
+    // (kSeated: only the tile-skipping launches -- and the segment launches that may accompany them -- seat their queries
+    //  out of position order; the other builds keep seat == position and need no table)
+    constexpr bool kSeated = SKIP || SEG != 0;
+    const int qpos = (kSeated && a.qord != nullptr && qvalid) ? a.qord[qseat - a.pos_begin] : qseat;
     int *sQpos = reinterpret_cast<int *>(sGb + kPfQ);   // [kPfQ] position of every seat of the workgroup (for the flush)
     // [4] tile skipping: "somebody in the workgroup needs tile t" for t = 0 .. 3 (mod 4); accessed by LDS address only
     const unsigned need_base = lds_addr(sQpos + kPfQ);
-    if (h == 0) sQpos[32 * w + col] = qpos;
+    if (kSeated && h == 0) sQpos[32 * w + col] = qpos;
     f16x8 qreg[KS];
     float nq, rg;
     {
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
             int off = atomicAdd(&sCnt[32 * w + qc], 1);                                            \
             if (SEG == 2) off += sGb[32 * w + qc];                                                 \
             if (off < a.cand_cap)                                                                  \
-                a.cand[((size_t)c * a.Kcap + sQpos[32 * w + qc]) * a.cand_cap + off] = a.memb_id[mb_ + e]; \
+                a.cand[((size_t)c * a.Kcap + (kSeated ? sQpos[32 * w + qc] : pos0 + 32 * w + qc)) * a.cand_cap + off] = a.memb_id[mb_ + e]; \
         }                                                                                          \
         if (SEG == 2) {                                                                            \
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                 \
