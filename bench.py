@@ -195,6 +195,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / max(args.steps, 1) * 1e3
+    try:
+        batch_used = int(ctx.counter("batch_size"))
+    except Exception:  # noqa: BLE001  (a library from before the counter: CHBIN_LIB A/B runs)
+        batch_used = args.batch or 8192
     value = qp_per_step * args.steps / dt
     dom = {k: ctx.profile_get(k) for k in ("prefilter", "hull_qp")}     # measured INSIDE the timed region
     stats = ctx.fit_stats()
@@ -466,7 +470,7 @@ def main():
                                    f"AlgoNumNeighbors={m}, one full fit_cluster sweep from the seed "
                                    "state per step (exact sequential label semantics)",
                        "n_contigs": N, "dim": D, "bins": B, "neighbors": m, "movable": int(n_move),
-                       "qp_per_step": int(qp_per_step), "batch": int(ctx.counter("batch_size")),
+                       "qp_per_step": int(qp_per_step), "batch": batch_used,
                        "generator": {"mix": args.mix, "sigma": args.sigma, "coverage_columns": S},
                        "parallelism_evidence": evidence,
                        "parallelism": (f"contig-sharded x{world}, " + ("RCCL all-gather in the C++ loop, X by the library's RCCL broadcast (chb_bcast_samples)"

@@ -901,7 +901,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
             int off = atomicAdd(&sCnt[32 * w + qc], 1);                                            \
             if (SEG == 2) off += sGb[32 * w + qc];                                                 \
             if (off < a.cand_cap)                                                                  \
-                a.cand[((size_t)c * a.Kcap + (kSeated ? sQpos[32 * w + qc] : pos0 + 32 * w + qc)) * a.cand_cap + off] = a.memb_id[mb_ + e]; \
+                a.cand[(kSeated ? (size_t)c * a.Kcap + sQpos[32 * w + qc] : (size_t)c * a.Kcap + pos0 + 32 * w + qc) * a.cand_cap + off] = a.memb_id[mb_ + e]; \
         }                                                                                          \
         if (SEG == 2) {                                                                            \
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                 \
