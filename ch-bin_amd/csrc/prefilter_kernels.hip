@@ -715,7 +715,7 @@ __device__ __noinline__ void shortlist_flush_call(const unsigned *pool, int npar
 }
 
 template <int ML, bool UPD, int KS, int SEG = 0, bool SKIP = false>
-__global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
+__global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 2))) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
                                                                          int bpw, int *flags64, int nqt64, Gate gate)
 {
     CHB_GATE(gate);
@@ -728,7 +728,11 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
     constexpr int ROWB = 32 * KS;            // bytes per shadow row
     constexpr int TILEB = kPfP * ROWB;       // one member tile
     constexpr int METAB = 512;               // floats [0,32) bias | [32,64) ||zh|| (base) or s | [64,96) b | [96,128) ||zh|| (update)
-    constexpr int BUFB = TILEB + METAB;
+    // (kFour: the 160-column base builds for m <= 5 drop what they do not use -- the bias / norm columns' slots, the
+    //  segment flush's bases -- and read their fragments in two halves through the same registers: 4 instead of 3
+    //  workgroups per CU)
+    constexpr bool kFour = KS == 10 && !UPD && ML <= 5 && SEG != 2;
+    constexpr int BUFB = kFour ? TILEB : TILEB + METAB;
     constexpr int NBUF = 3;
     constexpr int kPoolW = shortlist_pool_entries(ML);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
     //  out of position order; the other builds keep seat == position and need no table)
     constexpr bool kSeated = SKIP || SEG != 0;
     const int qpos = (kSeated && a.qord != nullptr && qvalid) ? a.qord[qseat - a.pos_begin] : qseat;
-    int *sQpos = reinterpret_cast<int *>(sGb + kPfQ);   // [kPfQ] position of every seat of the workgroup (for the flush)
+    int *sQpos = reinterpret_cast<int *>(kFour ? sGb : sGb + kPfQ);   // [kPfQ] position of every seat of the workgroup (for the flush)
     // [4] tile skipping: "somebody in the workgroup needs tile t" for t = 0 .. 3 (mod 4); accessed by LDS address only
     const unsigned need_base = lds_addr(sQpos + kPfQ);
     if (kSeated && h == 0) sQpos[32 * w + col] = qpos;
@@ -1129,6 +1133,27 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
                     const unsigned long long ta_s = ((unsigned long long)ta_hi << 32) | ta_lo;
                     asm volatile("s_load_dword %0, %1, 0x0" : "=s"(tsn_t) : "s"(ta_s) : "memory");
                 }
+                if constexpr (kFour) {
+                    // ten fragments through five registers: the second half is requested as the matrix core takes the first
+                    const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
+                    f16x8 h0 = lds_read_frag<0>(fa0), h1 = lds_read_frag<0>(fa1), h2 = lds_read_frag<64>(fa0),
+                          h3 = lds_read_frag<64>(fa1), h4 = lds_read_frag<128>(fa0);
+                    if (SKIP)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : : "memory");
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+s"(tsn_t) : : "memory");
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, qreg[0], acc, 0, 0, 0); h0 = lds_read_frag<128>(fa1);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, qreg[1], acc, 0, 0, 0); h1 = lds_read_frag<192>(fa0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, qreg[2], acc, 0, 0, 0); h2 = lds_read_frag<192>(fa1);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h3, qreg[3], acc, 0, 0, 0); h3 = lds_read_frag<256>(fa0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h4, qreg[4], acc, 0, 0, 0); h4 = lds_read_frag<256>(fa1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : : "memory");
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, qreg[5], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, qreg[6], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, qreg[7], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h3, qreg[8], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h4, qreg[9], acc, 0, 0, 0);
+                } else {
                 f16x8 af[KS == 9 ? 9 : 10];
                 {
                     const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
@@ -1159,6 +1184,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 #pragma unroll
                 for (int sx = 0; sx < KS; ++sx)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[sx], qreg[sx], acc, 0, 0, 0);
+                }
 
                 // base mode: this tile's query-rounding term (a wave-uniform table read)
                 const float dlt = UPD ? 0.f : rgq * tsn_t;
@@ -1290,8 +1316,10 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && KS == 9) ? 4 : 3) void short
 #undef CHB_SL_ISSUE_SEEK
 }
 
-static size_t shortlist_lds_bytes(int ks, int ml)
+// (four: the layout of the kFour builds -- no bias / norm column slots, the seat table in the segment bases' place)
+static size_t shortlist_lds_bytes(int ks, int ml, bool four = false)
 {
+    if (four) return (size_t)3 * (kPfP * 32 * ks) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 3 * kPfQ * 4 + 16;
     return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 4 * kPfQ * 4 + 16;
 }
 
@@ -1324,13 +1352,13 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
                                    shortlist_lds_bytes(9, ML), s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
             else
                 hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 0, true>), dim3(grid), dim3(64 * kPfW),
-                                   shortlist_lds_bytes(10, ML), s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+                                   shortlist_lds_bytes(10, ML, ML <= 5), s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
         }
     } else if (a.Dz == 144)
         hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 9>), dim3(grid), dim3(64 * kPfW), shortlist_lds_bytes(9, ML), s, a,
                            nqt, nchunk, bpw, flags64, nqt64, g_gate);
     else
-        hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(64 * kPfW), shortlist_lds_bytes(10, ML), s, a,
+        hipLaunchKernelGGL((shortlist_kernel<ML, UPD, 10>), dim3(grid), dim3(64 * kPfW), shortlist_lds_bytes(10, ML, !UPD && ML <= 5), s, a,
                            nqt, nchunk, bpw, flags64, nqt64, g_gate);
     if constexpr (!UPD) {
         // the segmented bins of this batch (usually none: the host only asks for these launches when the last batches'
@@ -1343,7 +1371,7 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
                 hipLaunchKernelGGL((shortlist_kernel<ML, false, 9, 2>), dim3(gseg), dim3(64 * kPfW), shortlist_lds_bytes(9, ML), s,
                                    a, nqt, 0, 1, flags64, nqt64, g_gate);
             } else {
-                hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 1>), dim3(gseg), dim3(64 * kPfW), shortlist_lds_bytes(10, ML), s,
+                hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 1>), dim3(gseg), dim3(64 * kPfW), shortlist_lds_bytes(10, ML, ML <= 5), s,
                                    a, nqt, 0, 1, flags64, nqt64, g_gate);
                 hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 2>), dim3(gseg), dim3(64 * kPfW), shortlist_lds_bytes(10, ML), s,
                                    a, nqt, 0, 1, flags64, nqt64, g_gate);
