@@ -700,6 +700,21 @@ __device__ __forceinline__ void list_insert_desc(float (&l)[ML], float v)
 //            of the union is exactly what one workgroup streaming the whole bin would have found), derives tau and
 //            shortlists the segment's members; segments append to the same (query, bin) shortlist through its
 //            global counter.
+//
+// SKIP (base mode, SEG = 0 only; launched when a.skip is set) -- exact tile skipping for data whose bins are not
+// isotropic (several coverage columns).  The host side has ordered every bin's members in shells of decreasing norm
+// (CSR key (bin, shell), aux_kernels.hip), made P.tsn a suffix maximum and seated the queries in the order of their nearest
+// bin centre (a.qord).  Every member p of tile t then satisfies  S d(j, p) >= ||z_jc|| - ||zh_p|| - rho_p >= zn_lo(j) - tsn[t];
+// a tile whose bound exceeds an upper bound of query j's m-th nearest distance (sweep 0: of the lane half's running list;
+// sweep 1: the admission bound) holds none of j's top m.  A wavefront none of whose queries needs tile t skips its
+// fragment reads, matrix-core and selection work; because the bounds only fall along a bin and the thresholds only
+// tighten, the tiles a workgroup can still need are a prefix of the run, and the run ends -- for the issue side of the
+// tile stream and, two tiles later, for the consumers -- when the "somebody needs it" flag of the tile about to be
+// requested is down (flags: four LDS words, posted three tiles ahead).  These builds take no per-tile-best shortcut (the m
+// nearest crowd into few tiles under the shell order) and flush their pools in the middle of a bin.  No asm value of
+// theirs lives across a loop iteration: the tile bounds sit in one VGPR (64 tiles, v_readlane) -- see DESIGN.md section 5
+// for what the first version's scalar-register window did.
+//
 // The tile-skipping builds' flush in the MIDDLE of a bin, as a real function call: inlined, its code costs the 128-VGPR
 // builds registers inside the tile loop; as a call the live registers are saved around it on this rare path only.
 // pool / cnt / qpos: this wavefront's parked entries, per-query counters and positions (LDS, through generic pointers).
