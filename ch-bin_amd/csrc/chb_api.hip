@@ -251,7 +251,7 @@ struct chb_ctx {
     // tile skipping in the base shortlist launch (needs the shells above and queries seated by nearest bin centre):
     // nearest-centre keys, the seating order, and the fit's verdict on whether it pays (0 undecided = on, 1 on, -1 off)
     DevBuf<unsigned long long> ckey;
-    DevBuf<int> qord;
+    DevBuf<int> qord, home;
     bool allow_skip = true;       // CHB_TILE_SKIP=0: never (A/B tests)
     int skip_state = 0, skip_batches = 0, skip_off_B = -1;
     long long last_batch = 0;
@@ -391,6 +391,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         h->seg_gcap = (int)std::min<size_t>(64, B / 4 + 1);
         HIPCHK(h->ckey.ensure(K));
         HIPCHK(h->qord.ensure(K));
+        HIPCHK(h->home.ensure(B));
         HIPCHK(h->seg_nseg.ensure(1));
         HIPCHK(h->seg_gflag.ensure(B));
         HIPCHK(h->seg_items.ensure(16 * (size_t)h->seg_gcap));
@@ -524,7 +525,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             launch_pack_build(h->Zs.p, h->ms.p, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->pk.view(), h->X.p,
                               h->D, h->Dp, h->bq_cur, q_lo, q_hi, h->Kcap, h->centers.p, h->shadow_scale, h->qn.p, s,
                               skip_on ? h->ckey.p : nullptr);
-            if (skip_on) launch_query_order(h->ckey.p, q_lo, q_hi, h->B, h->qord.p, s);
+            if (skip_on) launch_query_order(h->ckey.p, q_lo, q_hi, h->B, h->qord.p, h->home.p, s);
         }
         ShortlistArgs pa{};
         pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
@@ -537,7 +538,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         if (fusedp) pa.tau_out = h->tau.p;
         pa.seg = sp;
         if (sp.launch) h->stats_seg_batches += 1;
-        if (skip_on) { pa.qord = h->qord.p; pa.skip = 1; pa.skip_stat = h->fc_cur + 3; }
+        if (skip_on) { pa.qord = h->qord.p; pa.home = h->home.p; pa.skip = 1; pa.skip_stat = h->fc_cur + 3; }
 #ifdef CHB_DEV_KNOBS
         if (skip_on) { if (const char *ev = getenv("CHB_SKIP_NEVER")) if (atoi(ev)) pa.skip = 1 | 2 * atoi(ev); }
 #endif
@@ -860,7 +861,7 @@ int chb_destroy(chb_ctx *h)
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
     h->slow.release(); h->n_slow.release(); h->tau.release();
     h->seg_nseg.release(); h->seg_gflag.release(); h->seg_items.release(); h->seg_lists.release();
-    h->shell_inv.release(); h->ckey.release(); h->qord.release();
+    h->shell_inv.release(); h->ckey.release(); h->qord.release(); h->home.release();
     (void)hipStreamDestroy(h->stream);
     if (h->fc_host) (void)hipHostFree(h->fc_host);
     for (int i = 0; i < 2; ++i) if (h->fc_event[i]) (void)hipEventDestroy(h->fc_event[i]);

@@ -111,7 +111,7 @@ void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const i
 // (ckey, optional: [pos_end - pos_begin], pre-set to ~0 by the caller: the query-norm tiles leave {N_jc bits, bin} of every
 //  position's nearest bin centre there)
 // qord[0 .. pos_end - pos_begin) = the positions sorted by the bin of their key (positions without a key last)
-void launch_query_order(const unsigned long long *ckey, int pos_begin, int pos_end, int B, int *qord, hipStream_t s);
+void launch_query_order(const unsigned long long *ckey, int pos_begin, int pos_end, int B, int *qord, int *home, hipStream_t s);
 
 // Plan of the bins that are cut into segments for the shortlist stage (see shortlist_kernel, SEG): made on the device
 // by the CSR scan of the batch start, consumed by the three shortlist launches of the batch.
@@ -138,6 +138,7 @@ struct ShortlistArgs {
     int pos_begin, pos_end;
     const int *qord;           // optional: the order in which the queries are seated ([pos_end - pos_begin] positions sorted
                                // by nearest bin centre); nullptr: by position
+    const int *home;           // optional (with qord): [B] the query tile where the positions nearest to each bin start
     int skip;                  // base mode: 1 = skip member tiles by the norm bound (needs shell-ordered members to pay)
     int *skip_stat;            // optional: [3] wave-tiles skipped / seen / never loaded, reported by the first 64 workgroups
     unsigned long long *dbg;   // developer builds: per workgroup {start, end (100 MHz clock), tiles computed, hardware id}

@@ -551,8 +551,11 @@ __device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, in
 // qord[0 .. nq) = the positions [pos_begin, pos_end) sorted by their nearest bin centre (counting sort in one workgroup;
 // positions without a key last): the order in which the shortlist kernel seats its queries, so that the 32 queries of a
 // wavefront (and mostly the 128 of a workgroup) look at a bin from the same side and agree on the tiles they can skip.
+// home[b] = the query tile (of kPfQ seats) where the positions nearest to bin b start: the shortlist launch runs the
+// query tiles of a bin from there on, wrapping round -- the long work items of a bin (its own neighbourhood) first, the
+// short ones (far queries, most of their tiles skipped) last, so that the launch does not end on long ones.
 __global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long long *ckey, int pos_begin, int nq, int B,
-                                                           int *qord, Gate gate)
+                                                           int *qord, int *home, Gate gate)
 {
     CHB_GATE(gate);
     extern __shared__ int sh[];   // [B + 1] counts -> cursors, [1024] scan partials
@@ -590,7 +593,12 @@ __global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long l
     }
     __syncthreads();
     int run = part[tid];
-    for (int b = b0; b < b1; ++b) { const int c = cnt[b]; cnt[b] = run; run += c; }
+    for (int b = b0; b < b1; ++b) {
+        const int c = cnt[b];
+        cnt[b] = run;
+        if (b < B) home[b] = run / kPfQ;
+        run += c;
+    }
     __syncthreads();
     for (int i = tid; i < nq; i += 1024) {
         const unsigned long long k = ckey[i];
@@ -765,7 +773,10 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     if ((int)(blockIdx.x >> 3) >= per) return;
     const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (W >= total) return;
-    const int chunk = W / nqt, qt = W - chunk * nqt;
+    const int chunk = W / nqt;
+    int qt = W - chunk * nqt;
+    // (tile skipping, one bin per workgroup: the bin's query tiles start at its own neighbourhood's -- long items first)
+    if (SKIP && a.home != nullptr && bpw == 1) { qt += a.home[chunk]; qt = qt >= nqt ? qt - nqt : qt; }
     int c0 = chunk * bpw, c1 = min(a.B, c0 + bpw);
     int seg_tb = 0, seg_te = 0x3fffffff;   // tile window inside the bin (segments)
     int seg_g = 0, seg_i = 0, seg_n = 1;   // giant-bin slot, segment number, segments of the bin
@@ -1455,11 +1466,11 @@ void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, co
                        P.pad_ptr, centers, mu_g, S, Dz, P, g_gate);   // (bounds: into P.bb, zeroed by the batch-CSR kernel)
 }
 
-void launch_query_order(const unsigned long long *ckey, int pos_begin, int pos_end, int B, int *qord, hipStream_t s)
+void launch_query_order(const unsigned long long *ckey, int pos_begin, int pos_end, int B, int *qord, int *home, hipStream_t s)
 {
     if (pos_end > pos_begin)
         hipLaunchKernelGGL(query_order_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 1 + 1024), s, ckey, pos_begin,
-                           pos_end - pos_begin, B, qord, g_gate);
+                           pos_end - pos_begin, B, qord, home, g_gate);
 }
 
 void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
