@@ -37,11 +37,12 @@ CASES = [
     (3000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 0),   # SURVEY 8(d) generator
     (700, 40, 6, 15, 3, 9e-3, 0.5, 20, 150),       # m = 15: fused 16-lane kernel (hull_select_qp16_kernel)
     (10000, 136, 32, 5, 4, 1.5e-3, 0.0, None, 0),  # BASELINE configs[1] at its stated size (seed 0 as in test_gpu_configs)
+    (6000, 140, 12, 5, 3, 2e-3, 0.2, 60, 0),       # five coverage columns: the tile-skipping shortlist build on a rank's slice
 ]
 res = {}
 for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate(CASES):
     seed = 0 if N == 10000 else N + B
-    X, initial, _ = synth.make_synthetic(N, D, B, seed=seed, sigma=sigma, mix=mix, n_seed=n_seed)
+    X, initial, _ = synth.make_synthetic(N, D, B, S=5 if D == 140 else 1, seed=seed, sigma=sigma, mix=mix, n_seed=n_seed)
     perms = synth.draw_permutations(initial, iters, seed=0)
     ctx = _lib.Context(0)
     ctx.comm_init_hook(rank, world, allgather)
@@ -52,6 +53,7 @@ for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate(CASES):
     res[f"lab{case}"] = lab; res[f"its{case}"] = its; res[f"mind{case}"] = mind
     res[f"evaluated{case}"] = st["hull_evaluated"]; res[f"needed{case}"] = st["hull_needed"]
     res[f"rounds{case}"] = st["rounds"]
+    res[f"unloaded{case}"] = ctx.counter("tile_unloaded")
     ctx.comm_destroy()
     ctx.close()
 np.savez(out, **res)
@@ -78,7 +80,8 @@ def test_sharded_cpp_loop_more_than_one_rank_one_gpu(world):
     exec(WORKER[WORKER.index("CASES = ["):WORKER.index("res = {}")], ns)       # the worker's own case table
     for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate(ns["CASES"]):
         seed = 0 if N == 10000 else N + B
-        X, initial, _ = chbin_amd.synth.make_synthetic(N, D, B, seed=seed, sigma=sigma, mix=mix, n_seed=n_seed)
+        X, initial, _ = chbin_amd.synth.make_synthetic(N, D, B, S=5 if D == 140 else 1, seed=seed, sigma=sigma, mix=mix,
+                                                       n_seed=n_seed)
         perms = chbin_amd.synth.draw_permutations(initial, iters, seed=0)
         want, its_o, _ = O.fit_cluster(X, B, initial, perms, m, iters)
         labels = initial.copy()
@@ -94,3 +97,5 @@ def test_sharded_cpp_loop_more_than_one_rank_one_gpu(world):
         assert all(e > 0 for e in ev) and sum(ev) >= needed
         assert max(ev) <= (0.75 if world == 2 else 0.6) * sum(ev)                    # no rank did (nearly) all of it
         assert len({int(outs[r][f"rounds{case}"]) for r in range(world)}) == 1
+        if D == 140:   # tiles really were skipped on the ranks' slices (the first workgroups of a launch are sampled)
+            assert sum(int(outs[r][f"unloaded{case}"]) for r in range(world)) > 0
