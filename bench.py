@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=300)
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the m = 15 / overlapping-bins / label-margin legs")
+    ap.add_argument("--traffic-file", default=None,
+                    help="PMC traffic table to quote instead of profiles/%s (tools/collect_profiles.sh: the table it has "
+                         "just measured on this very build)" % TRAFFIC_FILE)
     ap.add_argument("--no-kernel-events", action="store_true", help="dev: no HIP events at all in the timed steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (dev: gloo)")
     ap.add_argument("--same-gpu", action="store_true", help="dev only: all ranks on cuda:0")
@@ -304,19 +307,21 @@ def main():
         traffic = {}
         traffic_note = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+            tj = json.load(open(args.traffic_file or os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+            tf_label = (f"{args.traffic_file} (this run's own rocprofv3 --pmc passes; committed as profiles/{TRAFFIC_FILE})"
+                        if args.traffic_file else f"profiles/{TRAFFIC_FILE}")
             tr = tj["kernels"]
             tmap = {"prefilter": "shortlist_kernel<5, false, 9>", "hull_qp": "hull_select_qp_kernel<5, 7, 4, true>",
                     "prefilter_update": "shortlist_kernel<1, true, 9>"}
             stamp = kernel_source_stamp()
             if tj.get("kernel_source_stamp") != stamp:
-                traffic_note = (f"profiles/{TRAFFIC_FILE} was measured on kernel sources {tj.get('kernel_source_stamp')}, "
+                traffic_note = (f"{tf_label} was measured on kernel sources {tj.get('kernel_source_stamp')}, "
                                 f"this build is {stamp}: not quoted")
             elif (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist and fused:
                 for name, src in tmap.items():
                     if src in tr:
                         traffic[name] = (tr[src]["traffic_bytes_per_launch"],
-                                         f"profiles/{TRAFFIC_FILE} ({src}; kernel sources {stamp})")
+                                         f"{tf_label} ({src}; kernel sources {stamp})")
         except Exception as e:  # noqa: BLE001
             traffic_note = f"no traffic file ({e})"
         for k in kern:

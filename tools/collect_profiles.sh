@@ -13,7 +13,9 @@ B="python3 $R/bench.py"
 echo "[1] kernel stats, config 2"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg2 -o t -- $B --steps 3 --warmup 1 --cpu-sample 0 --no-e2e --no-extra > $O/bench_under_rocprof.json 2> $O/err_stats_cfg2.txt || exit 1
 echo "[2] pmc fetch"; rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o t -- $B --steps 1 --warmup 0 --cpu-sample 0 --no-e2e --no-extra > $O/bench_pmc_fetch.json 2> $O/err_pmc_fetch.txt || exit 1
 echo "[3] pmc write"; rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o t -- $B --steps 1 --warmup 0 --cpu-sample 0 --no-e2e --no-extra > $O/bench_pmc_write.json 2> $O/err_pmc_write.txt || exit 1
-echo "[4] default bench"; $B > $O/bench_default.json 2> $O/err_default.txt || exit 1
+# (the default line quotes the traffic table of THIS build: bench.py only quotes a table whose source stamp matches)
+python3 $R/tools/traffic_from_pmc.py $O $O/this > $O/traffic_log.txt 2>&1 || exit 1
+echo "[4] default bench"; $B --traffic-file $O/this_traffic.json > $O/bench_default.json 2> $O/err_default.txt || exit 1
 [ -n "$quick" ] && exit 0
 echo "[5] m = 15"; $B --neighbors 15 --steps 3 --warmup 1 --no-extra > $O/m15_bench.json 2> $O/err_m15.txt || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_m15 -o t -- $B --neighbors 15 --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-extra > $O/m15_bench_under_rocprof.json 2> $O/err_stats_m15.txt || exit 1
