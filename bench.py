@@ -311,15 +311,20 @@ def main():
             tf_label = (f"{args.traffic_file} (this run's own rocprofv3 --pmc passes; committed as profiles/{TRAFFIC_FILE})"
                         if args.traffic_file else f"profiles/{TRAFFIC_FILE}")
             tr = tj["kernels"]
-            tmap = {"prefilter": "shortlist_kernel<5, false, 9>", "hull_qp": "hull_select_qp_kernel<5, 7, 4, true>",
-                    "prefilter_update": "shortlist_kernel<1, true, 9>"}
+            # (kernel names as rocprofv3 prints them: the shortlist kernel's template list has grown over the rounds)
+            tmap = {"prefilter": ["shortlist_kernel<5, false, 9, 0, false>", "shortlist_kernel<5, false, 9, 0>",
+                                  "shortlist_kernel<5, false, 9>"],
+                    "hull_qp": ["hull_select_qp_kernel<5, 7, 4, true>"],
+                    "prefilter_update": ["shortlist_kernel<1, true, 9, 0, false>", "shortlist_kernel<1, true, 9, 0>",
+                                         "shortlist_kernel<1, true, 9>"]}
             stamp = kernel_source_stamp()
             if tj.get("kernel_source_stamp") != stamp:
                 traffic_note = (f"{tf_label} was measured on kernel sources {tj.get('kernel_source_stamp')}, "
                                 f"this build is {stamp}: not quoted")
             elif (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist and fused:
-                for name, src in tmap.items():
-                    if src in tr:
+                for name, names in tmap.items():
+                    src = next((k for k in names if k in tr), None)
+                    if src is not None:
                         traffic[name] = (tr[src]["traffic_bytes_per_launch"],
                                          f"{tf_label} ({src}; kernel sources {stamp})")
         except Exception as e:  # noqa: BLE001
