@@ -270,7 +270,7 @@ void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int
 // (stats: [4] ints -- tiles of the largest bin, tiles of all bins, and two counters zeroed here for the shortlist launch)
 // (ms + shell_inv + nsh > 1, optional: the members of a bin are grouped by SHELLS of their distance from the bin's centre,
 //  outermost first -- cnt / cursor then hold B * nsh entries; see member_key in aux_kernels.hip)
-constexpr int kShells = 16;       // shells per bin (fewer when B * kShells would exceed kMaxKeys)
+constexpr int kShells = 32;       // shells per bin (fewer when B * kShells would exceed kMaxKeys)
 constexpr int kMaxKeys = 8192;    // CSR keys the count / fill kernels keep in LDS
 // CSR of the batch's own members: earlier positions under lab_prev, later positions under lab_old
 // (also starts the round's scalars: *first_change = K, *n_slow = 0, *nflag = 0 where the pointers are non-null)
