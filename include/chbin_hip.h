@@ -202,7 +202,11 @@ int chb_fit_stats(chb_ctx *h, int64_t *out4);
 /* diagnostic counters: "prefilter_enabled" (1 when the fp16 shortlist stage is active; the
  * environment variable CHB_PREFILTER=0 selects the brute-force selection kernel instead),
  * "prefilter_overflow" (shortlists that overflowed and were recomputed by brute force since the
- * last chb_fit_begin) */
+ * last chb_fit_begin), "fused_enabled" (1 when the fused selection + hull kernels serve the fit), "segment_batches"
+ * (batches of the last fit that cut a giant bin into segments), "batch_size" (speculative batch size of the last fit),
+ * "tile_skip_state" (tile skipping of the last fit: 0 undecided, 1 kept on, -1 turned off because next to nothing could be
+ * skipped), "tile_skipped" / "tile_seen" / "tile_unloaded" (wave-tiles whose compute was skipped / that were met / that
+ * were never loaded, as sampled by the first workgroups of each base shortlist launch) */
 int chb_counter(chb_ctx *h, const char *name, int64_t *out);
 
 #ifdef __cplusplus
