@@ -140,7 +140,7 @@ struct ShortlistArgs {
                                // by nearest bin centre); nullptr: by position
     const int *home;           // optional (with qord): [B] the query tile where the positions nearest to each bin start
     int skip;                  // base mode: 1 = skip member tiles by the norm bound (needs shell-ordered members to pay)
-    int *skip_stat;            // optional: [3] wave-tiles skipped / seen / never loaded, reported by the first 64 workgroups
+    int *skip_stat;            // optional: [3] wave-tiles skipped / seen / never loaded, reported by about 64 workgroups spread over the launch
     unsigned long long *dbg;   // developer builds: per workgroup {start, end (100 MHz clock), tiles computed, hardware id}
     const int *bin_ptr;        // (unpadded) CSR the pack was built from
     const int *memb_id;

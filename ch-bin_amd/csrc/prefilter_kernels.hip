@@ -1331,7 +1331,10 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
         d[0] = dbg_t0; d[1] = wall_clock64(); d[2] = (unsigned long long)dbg_tiles; d[3] = hw;
     }
 #endif
-    if (SKIP && a.skip_stat != nullptr && blockIdx.x < 64 && lane == 0) {
+    // (statistics: about 64 workgroups spread evenly over the work items -- the first ones of a launch are the bins' own
+    //  neighbourhoods since the query tiles are rotated, where least can be skipped)
+    //  (an ODD stride: the work items are (bin, query tile) with the tile running fastest, usually over a power of two)
+    if (SKIP && a.skip_stat != nullptr && W % (max(1, total >> 6) | 1) == 0 && lane == 0) {
         atomicAdd(&a.skip_stat[0], wt_skipped);
         atomicAdd(&a.skip_stat[1], wt_seen);
         atomicAdd(&a.skip_stat[2], wt_unloaded);

@@ -206,7 +206,7 @@ int chb_fit_stats(chb_ctx *h, int64_t *out4);
  * (batches of the last fit that cut a giant bin into segments), "batch_size" (speculative batch size of the last fit),
  * "tile_skip_state" (tile skipping of the last fit: 0 undecided, 1 kept on, -1 turned off because next to nothing could be
  * skipped), "tile_skipped" / "tile_seen" / "tile_unloaded" (wave-tiles whose compute was skipped / that were met / that
- * were never loaded, as sampled by the first workgroups of each base shortlist launch) */
+ * were never loaded, as sampled by about 64 workgroups of each base shortlist launch) */
 int chb_counter(chb_ctx *h, const char *name, int64_t *out);
 
 #ifdef __cplusplus
