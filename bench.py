@@ -75,6 +75,49 @@ def config_name(N, D, B):
     return "custom (not a BASELINE config)"
 
 
+def self_launch(n):
+    """One rank per GPU as child processes (the driver's own launch line, with a free rendezvous port); this process never
+    initialises a GPU and replaces nothing -- it waits, prints rank 0's JSON line and returns the launcher's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if p.returncode == 0 and len(lines) != 1:
+        print(f"self-launch: expected one result line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 4
+    if lines:
+        print(lines[-1], flush=True)
+    return p.returncode
+
+
+def launch_check(n):
+    """--launch-check: what a rank does up to the first collective, without a GPU (tests/test_distributed_cpu.py)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != n:
+        print(f"--gpus {n} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank + 1.0])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "rank_sum": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +141,16 @@ def main():
     ap.add_argument("--same-gpu", action="store_true", help="dev only: all ranks on cuda:0")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="dev only: with --gpus N > 1 keep going on the Python driver if the native RCCL loop is unavailable")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="dev / CPU test of the self-launch: the ranks rendezvous over gloo, rank 0 prints one line, no GPU touched")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run as a CHILD process,
+    # before this process has imported torch or touched a GPU), relay rank 0's single JSON line and the children's status
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    if args.launch_check:
+        raise SystemExit(launch_check(args.gpus))
 
     # stdout carries exactly ONE line, the result: libraries that chat on fd 1 (RCCL prints a version
     # banner when a communicator is created, gloo its peer counts) are sent to stderr instead
@@ -118,8 +170,7 @@ def main():
     if args.same_gpu:
         local_rank = 0
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     use_dist = world > 1
     if use_dist:
         import torch.distributed as dist

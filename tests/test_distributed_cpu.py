@@ -77,3 +77,24 @@ def test_gloo_world_size_2():
     for rank, labels, its, ch in res:
         assert its == its_o and np.array_equal(ch, ch_o)
         assert np.array_equal(labels, want)
+
+
+def test_bench_self_launch_prints_one_line():
+    """`python bench.py --gpus 2` with no launcher in the environment starts its two ranks itself (as children, before
+    anything touches a GPU), relays exactly one JSON line from rank 0 and returns the launcher's status.  --launch-check
+    stops the ranks after their first collective (gloo), so this runs without a GPU."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"launch_check": True, "world": 2, "rank_sum": 3.0}
+    # a launcher that started the wrong number of ranks is an error, not a silent single-GPU run
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       timeout=300)
+    assert p.returncode != 0 and p.stdout == ""
