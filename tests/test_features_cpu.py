@@ -119,3 +119,26 @@ def test_dump_bins(tmp_path):
     assert sorted(p.name for p in out.iterdir()) == ["bin_0.fasta", "bin_2.fasta"]
     assert list(fasta.read_fasta(out / "bin_2.fasta")) == [recs[0], recs[2]]
     assert list(fasta.read_fasta(out / "bin_0.fasta")) == [recs[1]]
+
+
+def test_preprocess_matches_reference_fixture(tmp_path):
+    """SURVEY 8f-3 pinned by the reference's own preprocess.py (tests/golden/make_golden_features.py ran it, unchanged,
+    between a recording Bio stand-in's reader and writer): the split rule's piece boundaries (preprocess.py:17-35), which
+    records are split, the `_S{i}` names with the description dropped (:55-63), the parent map, the `>= threshold` keep
+    rule (:84) and the length map (:91-101)."""
+    g = np.load(os.path.join(GOLD, "preprocess.npz"))
+    for length, split_len, want in zip(g["table_length"], g["table_split_len"], g["table_pieces"]):
+        got = [e - b for b, e in preprocess._piece_bounds(int(length), int(split_len))]
+        assert got == [int(v) for v in want if v >= 0], (length, split_len)
+        assert sum(got) == int(length)
+    recs = list(zip(g["in_ids"].tolist(), g["in_desc"].tolist(), g["in_seq"].tolist()))
+    src = tmp_path / "in.fa"
+    _write_fasta(src, recs)
+    assert list(preprocess.get_contig_lengths(src).items()) == list(zip(g["length_ids"].tolist(), g["length_vals"].tolist()))
+    removed = preprocess.filter_short_contigs(src, tmp_path / "f.fa", threshold=1000)
+    assert removed == g["removed"].tolist()
+    assert [(i, s) for i, _d, s in fasta.read_fasta(tmp_path / "f.fa")] == list(zip(g["kept_ids"].tolist(), g["kept_seq"].tolist()))
+    parents = preprocess.split_contigs(src, tmp_path / "s.fa", ["seedA", "seedB", "edge"], split_len=1000)
+    assert list(parents.items()) == list(zip(g["parent_keys"].tolist(), g["parent_vals"].tolist()))
+    out = list(fasta.read_fasta(tmp_path / "s.fa"))
+    assert [(i, d, s) for i, d, s in out] == list(zip(g["split_ids"].tolist(), g["split_desc"].tolist(), g["split_seq"].tolist()))

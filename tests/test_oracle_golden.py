@@ -69,6 +69,20 @@ def test_fit_cluster_control_flow(golden_dir):
     assert np.array_equal(labels2, labels)
 
 
+def test_fit_cluster_flow_does_not_depend_on_the_solver(golden_dir):
+    """fit_cluster_flow.npz came from the reference's loop with a stand-in quadprog that answers with the ORACLE's own
+    Goldfarb-Idnani -- circular for the solver stage.  fit_cluster_flow_slsqp.npz is the same reference loop on the same
+    inputs with scipy's SLSQP answering instead (tests/golden/make_golden_second_solver.py, 22,680 QP calls, all
+    converged): the labels are identical, so what the fixture pins is not an artefact of the oracle's solver."""
+    g = _load(golden_dir, "fit_cluster_flow.npz")
+    s = _load(golden_dir, "fit_cluster_flow_slsqp.npz")
+    assert int(s["not_converged"]) == 0 and int(s["qp_calls"]) > 20000
+    assert float(s["max_eq_violation"]) < 1e-12 and float(s["min_alpha"]) > -1e-12
+    assert np.array_equal(s["labels_slsqp"], g["labels"])
+    labels, _, _ = O.fit_cluster(g["X"], int(g["B"]), g["initial"], g["perms"], int(g["m"]), int(g["max_iter"]))
+    assert np.array_equal(labels, s["labels_slsqp"])
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_gi_vs_enumerator_random(seed):
     rng = np.random.default_rng(seed)
