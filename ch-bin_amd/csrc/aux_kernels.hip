@@ -629,6 +629,21 @@ __global__ void validate_batch_kernel(const int *cand, const int *cand_cnt, int 
     }
 }
 
+// fault injection for the test of the product build's shortlist check (FusedArgs::short_cnt): the first pair of the batch
+// whose bin has a member loses candidates until it holds one fewer than min(m, bin size)
+__global__ void inject_short_kernel(int *cand_cnt, int B, int Kcap, int pos, const int *bin_ptr, int m, Gate gate)
+{
+    CHB_GATE(gate);
+    for (int c = 0; c < B; ++c) {
+        const int sz = bin_ptr[c + 1] - bin_ptr[c];
+        if (sz > 0) { cand_cnt[(size_t)c * Kcap + pos] = min(m, sz) - 1; return; }
+    }
+}
+void launch_inject_short(int *cand_cnt, int B, int Kcap, int pos, const int *bin_ptr, int m, hipStream_t s)
+{
+    hipLaunchKernelGGL(inject_short_kernel, dim3(1), dim3(1), 0, s, cand_cnt, B, Kcap, pos, bin_ptr, m, g_gate);
+}
+
 void launch_validate_batch(const int *cand, const int *cand_cnt, int B, int Kcap, int pos_begin, int pos_end, int cap, int N,
                            const int *bin_ptr, const int *memb_id, const int *qord, int m, int *err, hipStream_t s)
 {

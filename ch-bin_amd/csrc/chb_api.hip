@@ -236,6 +236,10 @@ struct chb_ctx {
     bool pf_fit = false;        // this fit uses the shortlist stage (use_prefilter, D <= 160, m <= 16)
     bool lists_valid = false;   // the open batch was started with need_lists (chb_topm_per_bin)
     DevBuf<int> candu[2], candu_cnt[2], slow, n_slow;
+    // the shortlist stage's contract as checked by the fused kernels (FusedArgs::short_cnt): pairs of this fit whose base
+    // shortlist held fewer than min(m, bin size) candidates or a wild index -- any is an internal error of the fit
+    DevBuf<int> short_cnt;
+    int64_t short_seen = 0;
     // bins far larger than the rest are cut into segments for the shortlist stage (SegPlan, prefilter_kernels.hip): plan
     // buffers, and the bin sizes last seen by the host (they come home with the rounds' verdicts)
     DevBuf<int> seg_nseg, seg_gflag;
@@ -403,6 +407,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
             }
             HIPCHK(h->slow.ensure(K * B));
             HIPCHK(h->n_slow.ensure(1));
+            { const size_t had = h->short_cnt.cap; HIPCHK(h->short_cnt.ensure(1)); if (!had) HIPCHK(hipMemsetAsync(h->short_cnt.p, 0, sizeof(int), h->stream)); }
             HIPCHK(h->tau.ensure(K * B));
         }
     }
@@ -472,6 +477,8 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     HIPCHK(hipStreamSynchronize(h->stream));
     h->fit_open = true; h->batch_open = false; h->Kcap = 0;
     h->overflow_total_valid = false;
+    h->short_seen = 0;
+    if (h->short_cnt.p) HIPCHK(hipMemsetAsync(h->short_cnt.p, 0, sizeof(int), h->stream));
     return CHB_OK;
 }
 
@@ -586,6 +593,14 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             launch_topm_flagged(a, h->flags64.p, h->flaglist.p, h->nflag.p, s);
         }
 #ifdef CHB_DEV_KNOBS
+        // CHB_SL_INJECT_SHORT=<n>: the n-th batch start of the process hands the hull kernels one truncated shortlist
+        // (tests: the product build's check must turn it into an error)
+        if (fusedp) if (const char *ev = getenv("CHB_SL_INJECT_SHORT")) {
+            static int inj_batch = 0;
+            if (++inj_batch == atoi(ev)) launch_inject_short(h->cand_cnt.p, h->B, h->Kcap, q_lo, h->bin_ptr.p, h->m, s);
+        }
+#endif
+#ifdef CHB_DEV_KNOBS
         if (fusedp && getenv("CHB_SL_VALIDATE") != nullptr) {
             static int *verr = nullptr;
             if (verr == nullptr) HIPCHK(hipMalloc(&verr, 16 + 4 * 65536));
@@ -675,6 +690,7 @@ int batch_round_dev(chb_ctx *h, int active)
             f.candu = h->candu[cur].p; f.candu_cnt = h->candu_cnt[cur].p;
             if (h->round_in_batch > 0) { f.candp = h->candu[cur ^ 1].p; f.candp_cnt = h->candu_cnt[cur ^ 1].p; }
             f.dist = h->dist.p; f.metric = h->metric; f.slow = h->slow.p; f.n_slow = h->n_slow.p;
+            f.bin_ptr = h->bin_ptr.p; f.short_cnt = h->short_cnt.p;
             {
                 Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
                 launch_hull_select_qp(f, s);
@@ -859,7 +875,7 @@ int chb_destroy(chb_ctx *h)
     h->centers.release();
     h->active.release(); h->n_active.release(); h->act_blk.release();
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
-    h->slow.release(); h->n_slow.release(); h->tau.release();
+    h->slow.release(); h->n_slow.release(); h->tau.release(); h->short_cnt.release();
     h->seg_nseg.release(); h->seg_gflag.release(); h->seg_items.release(); h->seg_lists.release();
     h->shell_inv.release(); h->ckey.release(); h->qord.release(); h->home.release();
     (void)hipStreamDestroy(h->stream);
@@ -1365,7 +1381,14 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         h->stats[3] += n_move * (int64_t)h->B;
         HIPCHK(h->pin_b.ensure((size_t)N));
         HIPCHK(hipMemcpyAsync(h->pin_b.p, h->labels.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+        if (h->fused && h->short_cnt.p)   // (fc_host[7]: the spare word of the first verdict slot)
+            HIPCHK(hipMemcpyAsync(h->fc_host + 7, h->short_cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (h->fused && h->short_cnt.p && h->fc_host[7] != 0) {
+            h->short_seen = h->fc_host[7];
+            return fail(CHB_ESTATE, "internal error: " + std::to_string(h->fc_host[7]) + " (position, bin) shortlists of this sweep came "
+                        "out short of min(num_neighbors, bin size) candidates or held a wild index; labels not returned");
+        }
         int64_t diff = 0;  // algorithm.py:63
         labelled = 0;
         for (int64_t i = 0; i < N; ++i) {
@@ -1734,6 +1757,15 @@ int chb_counter(chb_ctx *h, const char *name, int64_t *out)
         if (h->overflow.p && h->overflow_total_valid) {
             int v = 0;
             HIPCHK(hipMemcpyAsync(&v, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            *out = v;
+        }
+        return CHB_OK;
+    }
+    if (!strcmp(name, "shortlist_short")) {   // pairs of the last fit that broke the shortlist stage's contract (0, or the fit failed)
+        if (h->short_cnt.p) {
+            int v = 0;
+            HIPCHK(hipMemcpyAsync(&v, h->short_cnt.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
             *out = v;
         }

@@ -224,7 +224,12 @@ struct FusedArgs {
     int metric;
     int *slow;        // pair indices (pos - pos_begin) * B + bin
     int *n_slow;      // zeroed by the caller
-    int stripe = 0;   // m <= 5 kernel, set by its launcher: work striped over the XCDs by bin (see fused_pair_of)
+    int stripe = 0;   // set by the launcher: work striped over the XCDs by bin (see fused_pair_of)
+    // the shortlist invariant, checked in the product build: every (position, bin) base shortlist holds at least
+    // min(m, members of the bin outside the batch) candidates, all of them sample indices.  bin_ptr = the base CSR;
+    // *short_cnt counts the pairs that violate it (the host turns a non-zero count into an error at the sweep's end)
+    const int *bin_ptr = nullptr;
+    int *short_cnt = nullptr;
 };
 // false: not supported by the fused kernels (caller uses the list-based path): m <= 16, padded rows of at most
 // kFusedMaxDp doubles (the 16-lane kernel stages the query row in LDS)
@@ -250,6 +255,7 @@ void launch_fill_i32(int *p, int v, int n, hipStream_t s);
 #ifdef CHB_DEV_KNOBS
 void launch_validate_batch(const int *cand, const int *cand_cnt, int B, int Kcap, int pos_begin, int pos_end, int cap, int N,
                            const int *bin_ptr, const int *memb_id, const int *qord, int m, int *err, hipStream_t s);
+void launch_inject_short(int *cand_cnt, int B, int Kcap, int pos, const int *bin_ptr, int m, hipStream_t s);
 #endif
 // batch end: labels[bq[i]] = lab[i], inb[bq[i]] = -1  (batch start -- lab_old[i] = labels[bq[i]], inb[bq[i]] = i --
 // rides in launch_bucket_base)

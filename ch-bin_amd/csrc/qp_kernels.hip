@@ -616,6 +616,13 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
                 }
             }
         }
+        if (a.short_cnt != nullptr) {
+            // the shortlist stage's contract (a short list would be a wrong hull with no error, a wild index a fault)
+            bool sh = false;
+            if (valid) sh = nb < min(m, a.bin_ptr[c + 1] - a.bin_ptr[c]);
+            const unsigned long long shm = __ballot(sh);
+            if (shm != 0ull && lane == 0) atomicAdd(a.short_cnt, __popcll(shm));
+        }
         const int n = nb + nu;
         // class 0: nothing to compute here.  Classes 1 .. NCLS: ONE sweep over max(n, M) = M + k - 1 candidate
         // rows (full candidate Gram).  Class NCLS + 1 (C < n <= 16): a distance sweep over all candidates,
@@ -653,6 +660,10 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             int idm = -1;
             if (l16 < n_g)
                 idm = l16 < nb_g ? a.cand[slot_g * kCandCap + l16] : a.candu[slot_g * kCandCapU + (l16 - nb_g)];
+            if ((unsigned)idm >= (unsigned)a.n_samples && idm != -1) {   // never a row address from a wild index
+                if (a.short_cnt != nullptr) atomicAdd(a.short_cnt, 1);
+                idm = -1;
+            }
             // the widest shortlist of the pass (the last problem: they are sorted)
             const int cw = __builtin_amdgcn_readfirstlane(__shfl(n, sOrd[w][min(p0 + 3, nnarrow - 1)], 64));
             double r[NR];
@@ -731,6 +742,10 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             int idm = -1;
             if (l16 < n_g)
                 idm = l16 < nb_g ? a.cand[slot_g * kCandCap + l16] : a.candu[slot_g * kCandCapU + (l16 - nb_g)];
+            if ((unsigned)idm >= (unsigned)a.n_samples && idm != -1) {   // never a row address from a wild index
+                if (a.short_cnt != nullptr) atomicAdd(a.short_cnt, 1);
+                idm = -1;
+            }
             int nmax = n_g;
             nmax = max(nmax, __shfl_xor(nmax, 16, 64));
             nmax = max(nmax, __shfl_xor(nmax, 32, 64));
@@ -1388,12 +1403,14 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
     int *sIdw = &sGI[w][0][0], *sNeww = &sGN[w][0][0];
     if (threadIdx.x == 0) sSlowN = 0;
     __syncthreads();
-    const int gw = (blockIdx.x * WAVES + w) * 4;
-    const int g = gw + grp;
-    const bool valid = g < nprob;
+    // (a.stripe: the work order of the m <= 5 kernel -- workgroup b only takes pairs of the bins c = b (mod 8), so that an
+    //  XCD gathers candidate rows of an eighth of the bins; the wavefront's four pairs are four of those bins at one
+    //  position while the XCD has that many.  nprob is then the length of the longest of the 8 lists)
+    const int gw = ((a.stripe ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * WAVES + w) * 4;
+    int pos = 0, c = 0;
+    const bool valid = fused_pair_of(a, gw, grp, nprob, pos, c);
     int nb = 0, nu = 0, qid = 0;
     bool changed = valid;
-    const int pos = a.pos_begin + g / a.B, c = g - (g / a.B) * a.B;
     const size_t slot = (size_t)c * a.Kcap + pos;
     if (valid) {
         qid = a.bq[pos];
@@ -1411,6 +1428,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
             changed = ((__ballot(!same) >> (lane & 48)) & 0xFFFFull) != 0ull;
         }
     }
+    if (a.short_cnt != nullptr && valid && l16 == 0 && nb < min(m, a.bin_ptr[c + 1] - a.bin_ptr[c]))
+        atomicAdd(a.short_cnt, 1);   // (the shortlist stage's contract, see FusedArgs)
     QP16_CLK(tc0);
 #ifdef CHB_DEV_CLK
     unsigned long long c_ids = 0, c_sweep = 0, c_one = 0;
@@ -1429,6 +1448,11 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
         if (l16 < n) idm = l16 < nb ? a.cand[slot * kCandCap + l16] : a.candu[slot * kCandCapU + (l16 - nb)];
         if (l16 < kExtraMax && 16 + l16 < n)
             idx = 16 + l16 < nb ? a.cand[slot * kCandCap + 16 + l16] : a.candu[slot * kCandCapU + (16 + l16 - nb)];
+        if (((unsigned)idm >= (unsigned)a.n_samples && idm != -1) || ((unsigned)idx >= (unsigned)a.n_samples && idx != -1)) {
+            if (a.short_cnt != nullptr) atomicAdd(a.short_cnt, 1);   // never a row address from a wild index
+            if ((unsigned)idm >= (unsigned)a.n_samples) idm = -1;
+            if ((unsigned)idx >= (unsigned)a.n_samples) idx = -1;
+        }
         double *xq = &sQ[w][grp][0][0];
         const int Dp16 = (a.Dp + 15) & ~15;
         for (int e = 2 * l16; e < Dp16; e += 32)
@@ -1451,8 +1475,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
         for (int b = 0; b < kExtraMax; ++b) ide[b] = __shfl(idx, 16 * p + b, 64);
         if (!go) continue;   // wave-uniform
         QP16_CLK(tp0);
-        const int gp = gw + p;
-        const size_t slot_p = (size_t)(gp - (gp / a.B) * a.B) * a.Kcap + (a.pos_begin + gp / a.B);
+        const size_t slot_p = (size_t)__shfl(c, 16 * p, 64) * a.Kcap + (size_t)__shfl(pos, 16 * p, 64);
         const bool two = np > 16 + kExtraMax;
         const int ne = (np > 16 && !two) ? np - 16 : 0;
         int idB = -1;
@@ -1488,6 +1511,10 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
         // ---- two tiles (up to 32 candidates): rank and scatter here, the accumulators are this pair's
         if (16 + row < np)
             idB = 16 + row < nbp ? a.cand[slot_p * kCandCap + 16 + row] : a.candu[slot_p * kCandCapU + (16 + row - nbp)];
+        if ((unsigned)idB >= (unsigned)a.n_samples && idB != -1) {   // never a row address from a wild index
+            if (a.short_cnt != nullptr) atomicAdd(a.short_cnt, 1);
+            idB = -1;
+        }
         f64x4 aa = {0.0, 0.0, 0.0, 0.0}, ab = aa, bb = aa;
         gram_tile16<true>(a.X, a.Dp, q, idA, idB, kq, aa, ab, bb);
         // squared distances = the diagonals (lane (row, kq = row & 3) holds D[row][row] in acc[row >> 2])
@@ -1641,7 +1668,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
         if (threadIdx.x == 0) sSlowBase = sSlowN > 0 ? atomicAdd(a.n_slow, sSlowN) : 0;
         __syncthreads();
         wbase = __shfl(wbase, 0, 64) + sSlowBase;
-        if (slow && l16 == 0) a.slow[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = g;
+        if (slow && l16 == 0)   // (position-major pair index, whatever the work order)
+            a.slow[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (pos - a.pos_begin) * a.B + c;
     }
 #ifdef CHB_DEV_CLK
     {
@@ -1956,15 +1984,19 @@ void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
     const int nprob = (a.pos_end - a.pos_begin) * a.B;
     if (nprob <= 0) return;
     constexpr int WV = 4;
-    if (a.m > 5) {   // 16 lanes per pair
-        hipLaunchKernelGGL((hull_select_qp16_kernel<WV>), dim3((nprob + 4 * WV - 1) / (4 * WV)), dim3(64 * WV), 0, s, a,
-                           nprob, g_gate);
-        return;
-    }
-    int np5 = nprob, grid = (nprob + 64 * WV - 1) / (64 * WV);
     FusedArgs as = a;
     static const bool stripe_off = getenv("CHB_FUSED_STRIPE") != nullptr && atoi(getenv("CHB_FUSED_STRIPE")) == 0;
     as.stripe = (!stripe_off && a.B >= 16) ? 1 : 0;
+    if (a.m > 5) {   // 16 lanes per pair, four pairs per wavefront
+        int np16 = nprob, grid16 = (nprob + 4 * WV - 1) / (4 * WV);
+        if (as.stripe) {
+            np16 = (a.pos_end - a.pos_begin) * ((a.B + 7) / 8);
+            grid16 = 8 * ((np16 + 4 * WV - 1) / (4 * WV));
+        }
+        hipLaunchKernelGGL((hull_select_qp16_kernel<WV>), dim3(grid16), dim3(64 * WV), 0, s, as, np16, g_gate);
+        return;
+    }
+    int np5 = nprob, grid = (nprob + 64 * WV - 1) / (64 * WV);
     if (as.stripe) {
         // the longest of the 8 XCD lists: XCD 0 has ceil(B / 8) bins
         np5 = (a.pos_end - a.pos_begin) * ((a.B + 7) / 8);

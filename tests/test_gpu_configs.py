@@ -137,6 +137,7 @@ def test_large_configs_full_size(O, idx, N, D, B, S):
         # the call bench.py times (no min_dist => look-ahead across batches): the whole fit once more
         got_t, its_t, changed_t = c.fit_cluster(B, initial, perms, m, 4)
         st_t = c.fit_stats()
+        assert c.counter("shortlist_short") == 0   # the product build's check of the shortlist stage's contract
         # (iii) two-stage selection == brute force on a sample of contigs under the final labels
         rng = np.random.default_rng(idx)
         q = rng.choice(np.flatnonzero(initial < 0), 256, replace=False)

@@ -938,6 +938,7 @@ def test_segmented_giant_bin(O, m):
         got, its, changed = a.fit_cluster(B, initial, perms, m, 2)
         seg_batches = a.counter("segment_batches")
         overflow = a.counter("prefilter_overflow")
+        assert a.counter("shortlist_short") == 0   # the product build's check of the shortlist stage's contract
         rng = np.random.default_rng(2)
         q = rng.choice(np.flatnonzero(initial < 0), 300, replace=False)
         lists = a.topm_per_bin(got, B, m, q)
@@ -997,6 +998,7 @@ def test_tile_skipping_exact(O, D, S, m):
         state, unloaded = a.counter("tile_skip_state"), a.counter("tile_unloaded")
         skipped, seen = a.counter("tile_skipped"), a.counter("tile_seen")
         overflow = a.counter("prefilter_overflow")
+        assert a.counter("shortlist_short") == 0   # the product build's check of the shortlist stage's contract
         rng = np.random.default_rng(4)
         q = rng.choice(np.flatnonzero(initial < 0), 300, replace=False)
         lists = a.topm_per_bin(got, B, m, q)
@@ -1045,3 +1047,49 @@ def test_tile_skipping_exact(O, D, S, m):
         lab_now[tail[k:]] = prev[tail[k:]]
         lab_j, _ = O.sweep(X, B, lab_now, np.array([j]), m)
         assert lab_j[j] == got[j]
+
+
+def test_short_shortlist_is_an_error_not_a_wrong_hull(tmp_path):
+    """Every fused hull launch of the PRODUCT build checks the shortlist stage's contract (each (position, bin) base
+    shortlist holds at least min(m, bin size) candidates, all of them sample indices) and the fit fails loudly at the
+    sweep's end if a pair broke it -- in round 3 a short shortlist was a GPU memory fault or a silently wrong hull.  The
+    developer library can hand the hull kernels one truncated shortlist (CHB_SL_INJECT_SHORT=<n-th batch>): the same
+    kernels must turn it into CHB_ESTATE.  Runs in a child process (its own library); skipped where the developer
+    library has not been built (make -C ch-bin_amd/csrc DEV=1)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = os.path.join(root, "ch-bin_amd", "libchbin_hip_dev.so")
+    if not os.path.exists(dev):
+        pytest.skip("developer library not built")
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import chbin_amd
+from chbin_amd import _lib, synth
+for m in (5, 15):
+    X, initial, _ = synth.make_synthetic(6000, 136, 12, seed=3)
+    perms = synth.draw_permutations(initial, 2, seed=0)
+    ctx = _lib.Context(0)
+    ctx.set_samples(X)
+    try:
+        ctx.fit_cluster(12, initial, perms, m, 2, batch=1024)
+    except _lib.ChbError as e:
+        assert "shortlists of this sweep came out short" in str(e), e
+        assert ctx.counter("shortlist_short") >= 1
+        print("caught", m)
+    else:
+        raise SystemExit("the truncated shortlist went unnoticed (m = %%d)" %% m)
+    # the next fit on the same context is clean again
+    lab, its, _ = ctx.fit_cluster(12, initial, perms, m, 2, batch=1024)
+    assert ctx.counter("shortlist_short") == 0
+    ctx.close()
+""" % root
+    script = tmp_path / "inject.py"
+    script.write_text(code)
+    env = dict(os.environ, CHBIN_LIB=dev, CHB_SL_INJECT_SHORT="2")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert p.stdout.count("caught") == 2
