@@ -31,7 +31,10 @@ sys.path.insert(0, ROOT)
 # MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F16_PEAK_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak
-TRAFFIC_FILE = "r03_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this round (tools/traffic_from_pmc.py)
+TRAFFIC_FILE = "r04_traffic.json"   # rocprofv3 --pmc passes of this round (tools/traffic_from_pmc.py); m > 5: r04_m15_traffic.json
+# MI355X_MICROARCH.md: indexed rows out of an L2-resident table gather at 16.8-18.8 TB/s chip-wide (mid-point); L2 aggregate 34.5
+L2_GATHER_PEAK_GBS = 17800.0
+L2_AGGREGATE_GBS = 34500.0
 
 
 def gather_ceiling_gbs(table_mb):
@@ -356,33 +359,78 @@ def main():
         # (quoted only while the kernel sources are byte-identical to the build the counters were collected on, and
         #  only for the configuration they were collected on; otherwise null)
         traffic = {}
+        onchip = {}
         traffic_note = None
         try:
-            tj = json.load(open(args.traffic_file or os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
-            tf_label = (f"{args.traffic_file} (this run's own rocprofv3 --pmc passes; committed as profiles/{TRAFFIC_FILE})"
-                        if args.traffic_file else f"profiles/{TRAFFIC_FILE}")
+            default_tf = TRAFFIC_FILE if m <= 5 else TRAFFIC_FILE.replace("_traffic", "_m15_traffic")
+            tj = json.load(open(args.traffic_file or os.path.join(ROOT, "profiles", default_tf)))
+            tf_label = (f"{args.traffic_file} (this run's own rocprofv3 --pmc passes; committed as profiles/{default_tf})"
+                        if args.traffic_file else f"profiles/{default_tf}")
             tr = tj["kernels"]
             # (kernel names as rocprofv3 prints them: the shortlist kernel's template list has grown over the rounds)
-            tmap = {"prefilter": ["shortlist_kernel<5, false, 9, 0, false>", "shortlist_kernel<5, false, 9, 0>",
-                                  "shortlist_kernel<5, false, 9>"],
-                    "hull_qp": ["hull_select_qp_kernel<5, 7, 4, true>"],
-                    "prefilter_update": ["shortlist_kernel<1, true, 9, 0, false>", "shortlist_kernel<1, true, 9, 0>",
-                                         "shortlist_kernel<1, true, 9>"]}
+            ml = 5 if m <= 5 else (8 if m <= 8 else 16)
+            tmap = {"prefilter": [f"shortlist_kernel<{ml}, false, 9, 0, false>", f"shortlist_kernel<{ml}, false, 9, 0>",
+                                  f"shortlist_kernel<{ml}, false, 9>"],
+                    "hull_qp": ["hull_select_qp_kernel<5, 7, 4, true>"] if m <= 5 else ["hull_select_qp16_kernel<4>"],
+                    "prefilter_update": [f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false>",
+                                         "shortlist_kernel<1, true, 9, 0>", "shortlist_kernel<1, true, 9>"]}
             stamp = kernel_source_stamp()
             if tj.get("kernel_source_stamp") != stamp:
                 traffic_note = (f"{tf_label} was measured on kernel sources {tj.get('kernel_source_stamp')}, "
                                 f"this build is {stamp}: not quoted")
-            elif (N, D, B, m) == (100_000, 136, 64, 5) and (args.batch or 8192) == 8192 and not use_dist and fused:
+            elif (N, D, B) == (100_000, 136, 64) and m in (5, 15) and (args.batch or 8192) == 8192 and not use_dist and fused:
                 for name, names in tmap.items():
                     src = next((k for k in names if k in tr), None)
                     if src is not None:
-                        traffic[name] = (tr[src]["traffic_bytes_per_launch"],
-                                         f"{tf_label} ({src}; kernel sources {stamp})")
+                        label = f"{tf_label} ({src}; kernel sources {stamp})"
+                        if tr[src].get("traffic_bytes_per_launch") is not None:
+                            traffic[name] = (tr[src]["traffic_bytes_per_launch"], label)
+                        onchip[name] = (tr[src], label)
         except Exception as e:  # noqa: BLE001
             traffic_note = f"no traffic file ({e})"
         for k in kern:
             if k["kernel"] in traffic:
                 k["traffic"], k["traffic_source"] = traffic[k["kernel"]]
+
+        def limiter_of(entry):
+            """What the kernel is really bound by, from counters of THIS build (the contract's `frac` prices SURVEY 8(d)'s
+            no-reuse byte model against the HBM peak and can exceed 1 when the rows come out of L2 / Infinity Cache): every
+            measured resource with its own peak; `resource` names the busiest one."""
+            oc = onchip.get(entry["kernel"])
+            if oc is None:
+                return None
+            t, label = oc
+            secs = entry["avg_launch_ms"] * 1e-3
+            cands = []
+            if t.get("l2_read_bytes_per_launch"):
+                ach = t["l2_read_bytes_per_launch"] / secs / 1e9
+                c = {"resource": "L2 -> L1 row gather (vector-L1 read requests x 128 B / launch time)", "achieved": ach,
+                     "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": ach / L2_GATHER_PEAK_GBS,
+                     "peak_source": "MI355X_MICROARCH.md: 16.8-18.8 TB/s for indexed rows of an L2-resident table",
+                     "frac_of_l2_aggregate_34.5TBs": ach / L2_AGGREGATE_GBS,
+                     "l2_read_bytes_per_launch": t["l2_read_bytes_per_launch"], "l2_hit_rate": t.get("l2_hit_rate")}
+                if entry.get("algorithmic_bytes_per_launch"):
+                    c["requested_over_algorithmic"] = t["l2_read_bytes_per_launch"] / entry["algorithmic_bytes_per_launch"]
+                cands.append(c)
+            if t.get("traffic_bytes_per_launch"):
+                ach = t["traffic_bytes_per_launch"] / secs / 1e9
+                cands.append({"resource": "HBM / Infinity Cache side (2 x FETCH_SIZE + WRITE_SIZE)", "achieved": ach,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
+            if t.get("valu_busy") is not None:
+                cands.append({"resource": "vector ALU issue (SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES)", "achieved": t["valu_busy"],
+                              "peak": 1.0, "unit": "share of SIMD time", "frac": t["valu_busy"]})
+            if t.get("mfma_busy"):
+                cands.append({"resource": "matrix pipe (SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_BUSY_CU_CYCLES)", "achieved": t["mfma_busy"],
+                              "peak": 1.0, "unit": "share of SIMD time", "frac": t["mfma_busy"],
+                              "coexec_share_of_mfma_busy": t.get("mfma_coexec")})
+            if not cands:
+                return None
+            top = dict(max(cands, key=lambda c: c["frac"]))
+            top["source"] = label + "; duration: HIP events of this run"
+            top["wave_time_shares"] = {k2: t.get(k2) for k2 in ("wait_any", "wait_inst", "active")}
+            top["candidates"] = [{k2: c[k2] for k2 in ("resource", "achieved", "peak", "unit", "frac")} for c in cands]
+            return top
+
         kern.sort(key=lambda k: -k["total_ms"])
 
         # the roofline object: the dominant kernel, with the durations measured inside the timed region
@@ -397,11 +445,12 @@ def main():
                 roofline["traffic"], roofline["traffic_source"] = traffic[roofline["kernel"]]
             elif traffic_note:
                 roofline["traffic_note"] = traffic_note
+            roofline["limiter"] = limiter_of(roofline)
             if len(timed) > 1:
                 o = timed[1]
                 roofline["runner_up"] = {"kernel": o["kernel"], "ms_per_step": o["total_ms"] / max(args.steps, 1),
                                          "frac": o["frac"], "bound": o["bound"], "unit": o["unit"],
-                                         "achieved": o["achieved"], "peak": o["peak"]}
+                                         "achieved": o["achieved"], "peak": o["peak"], "limiter": limiter_of(o)}
         # whole-path view in SURVEY 8(d)'s no-reuse gather model against the HBM spec: every hull distance the
         # sweep needs x bytes_QP over the sweep's wall time (the north star's 40 % target is on this figure)
         path_roofline = {"bound": "hbm", "achieved": value * bytes_qp / 1e9, "peak": HBM_PEAK_GBS,

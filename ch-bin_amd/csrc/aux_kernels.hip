@@ -370,10 +370,18 @@ __global__ __launch_bounds__(256) void argmin_kernel(const double *dist, const i
     if (in_place) lab_prev[pos] = bc;   // (each position is read and written by its own thread only)
 }
 
-__global__ void first_change_kernel(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change)
+__global__ void first_change_kernel(const int *lab_new, const int *lab_prev, int p0, int K, int *first_change, Gate gate)
 {
+    CHB_GATE(gate);
     const int pos = p0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (pos < K && lab_new[pos] != lab_prev[pos]) atomicMin(first_change, pos);
+}
+
+__global__ void copy_i32_kernel(int *dst, const int *src, int n, Gate gate)
+{
+    CHB_GATE(gate);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 // First-round label guess for batch members that carry no label yet (sweep 1): the bin of the
@@ -572,7 +580,13 @@ void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K,
                          hipStream_t s)
 {
     if (K > p0)
-        hipLaunchKernelGGL(first_change_kernel, dim3((K - p0 + 255) / 256), dim3(256), 0, s, lab_new, lab_prev, p0, K, first_change);
+        hipLaunchKernelGGL(first_change_kernel, dim3((K - p0 + 255) / 256), dim3(256), 0, s, lab_new, lab_prev, p0, K, first_change,
+                           g_gate);
+}
+
+void launch_copy_i32(int *dst, const int *src, int n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(copy_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n, g_gate);
 }
 
 void launch_compact_active(const int *cand_cnt, int pos_begin, int pos_end, int B, int Kcap, int *blk_cnt,

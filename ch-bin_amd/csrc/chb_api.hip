@@ -270,6 +270,7 @@ struct chb_ctx {
     std::vector<Pending> pending;
     int64_t stats[4] = {0, 0, 0, 0};
     int64_t stats_seg_batches = 0;   // batches of the last fit that ran the segment launches
+    int64_t stats_lookahead = 0;     // batches of the last fit whose successor was enqueued ahead of their verdict and kept
     // multi-GPU: one context per process per GPU, RCCL communicator over all ranks
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -1174,6 +1175,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     hipStream_t s = h->stream;
     memset(h->stats, 0, sizeof(h->stats));
     h->stats_seg_batches = 0;
+    h->stats_lookahead = 0;
 
     // (fit_begin_impl left the converted initial labels in pin_a and has synchronised the stream)
     std::vector<int> prev(h->pin_a.p, h->pin_a.p + N), cur;
@@ -1220,7 +1222,12 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         // a failed guess switches the look-ahead off until a batch converges in one round again.
         const int world = h->world;
         const bool xchg = (h->comm != nullptr || h->hook != nullptr) && (world > 1 || h->force_gather);
-        const bool can_spec = h->speculate && h->fused && !xchg && min_dist_out == nullptr;
+        // (look-ahead under an exchange: the RCCL all-gather sits on the context's stream, so the first-changed position of
+        //  a round is computed on the device right behind it and feeds the same gate as on one GPU; every rank sees the same
+        //  labels, hence the same verdict, and the all-gathers of a gated-off batch move identical bytes between the ranks'
+        //  identical buffers.  The hook transport needs the host between rounds anyway.)
+        const bool can_spec = h->speculate && h->fused && (!xchg || (h->hook == nullptr && h->comm != nullptr)) &&
+                              min_dist_out == nullptr;
         struct Geom { int64_t t0; int K, q_lo, q_hi, C; };
         auto geom_at = [&](int64_t t0) {
             // sweep 1 starts from few labelled members: do not let a batch outnumber them by much
@@ -1245,6 +1252,9 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 { const int r_ = exchange_all_gather(h, h->lab_new.p, (size_t)g.C, sizeof(int), ncclInt32); if (r_) return r_; }
                 launch_fill_i32(h->fc_cur, g.K, 1, s);
                 launch_first_change(h->lab_new.p, h->lab_prev.p, active, g.K, h->fc_cur, s);
+                // positions [active, K) now carry this round's labels (single rank: the argmin kernel has already
+                // written them to lab_prev); a gated kernel, not a memcpy: inside a look-ahead window it must not run
+                launch_copy_i32(h->lab_prev.p + active, h->lab_new.p + active, g.K - active, s);
             }
             HIPCHK(hipMemcpyAsync(h->fc_host + 8 * slot, h->fc_cur, 6 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(h->fc_event[slot], s));
@@ -1266,11 +1276,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                     if (h->skip_state < 0) h->skip_off_B = h->B;
                 }
             }
-            // positions [active, K) now carry this round's labels (single rank: the argmin kernel has
-            // already written them to lab_prev)
-            if (xchg)
-                HIPCHK(hipMemcpyAsync(h->lab_prev.p + active, h->lab_new.p + active,
-                                      sizeof(int) * (g.K - active), hipMemcpyDeviceToDevice, s));
+            (void)active; (void)g;
             return CHB_OK;
         };
         // batch start + guess + round 0, nothing read back
@@ -1356,6 +1362,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 inflight = false;
             } else {
                 inflight = spec;   // the next batch's first round is already running
+                if (spec) h->stats_lookahead += 1;
                 spec_ok = can_spec;
             }
             if (min_dist_out && xchg)
@@ -1762,6 +1769,7 @@ int chb_counter(chb_ctx *h, const char *name, int64_t *out)
         }
         return CHB_OK;
     }
+    if (!strcmp(name, "lookahead_batches")) { *out = h->stats_lookahead; return CHB_OK; }
     if (!strcmp(name, "shortlist_short")) {   // pairs of the last fit that broke the shortlist stage's contract (0, or the fit failed)
         if (h->short_cnt.p) {
             int v = 0;

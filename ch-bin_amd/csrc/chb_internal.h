@@ -252,6 +252,7 @@ void launch_hull_qp_indexed(const double *X, int D, int Dp, const int *q, const 
 
 // label / bucket helpers
 void launch_fill_i32(int *p, int v, int n, hipStream_t s);
+void launch_copy_i32(int *dst, const int *src, int n, hipStream_t s);   // (carries the look-ahead gate, like the fill)
 #ifdef CHB_DEV_KNOBS
 void launch_validate_batch(const int *cand, const int *cand_cnt, int B, int Kcap, int pos_begin, int pos_end, int cap, int N,
                            const int *bin_ptr, const int *memb_id, const int *qord, int m, int *err, hipStream_t s);

@@ -559,6 +559,19 @@ def test_native_comm_exchange_path_world1(O):
         for k in range(its):
             labels, md = O.sweep(X, 8, labels, perms[k], 5)
         assert np.allclose(mind[perms[its - 1]], md, rtol=0, atol=QP_TOL)
+        # look-ahead UNDER the exchange (no min_dist => the next batch is enqueued behind the all-gather and the device-side
+        # first-change reduction, gated on their verdict): well separated bins converge in one round per batch, so the
+        # look-ahead holds; the overlapping case above makes it fail and restore.  Both must equal the plain path.
+        X2, initial2, _ = _synth(5000, 136, 16, seed=33)
+        perms2 = _perms(initial2, 3)
+        want2, its2, ch2 = O.fit_cluster(X2, 16, initial2, perms2, 5, 3)
+        c.bcast_samples(X2, X2.shape[0], X2.shape[1], root=0)
+        got2, its_g, ch_g = c.fit_cluster(16, initial2, perms2, 5, 3, batch=256)
+        assert c.counter("lookahead_batches") > 0, "the look-ahead never engaged under the RCCL exchange"
+        assert its_g == its2 and np.array_equal(ch_g, ch2) and np.array_equal(got2, want2)
+        c.bcast_samples(X, X.shape[0], X.shape[1], root=0)
+        got3, its3, _ = c.fit_cluster(8, initial, perms, 5, 4, batch=200)      # failing look-aheads, restores
+        assert its3 == its_o and np.array_equal(got3, want)
         c.comm_destroy()
     finally:
         c.close()
