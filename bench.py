@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--same-gpu", action="store_true", help="dev only: all ranks on cuda:0")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="dev only: with --gpus N > 1 keep going on the Python driver if the native RCCL loop is unavailable")
+    ap.add_argument("--samples-by", choices=("bcast", "local"), default="bcast",
+                    help="--gpus N > 1: X reaches the ranks by the library's RCCL broadcast (default) or every rank uploads its own copy")
     ap.add_argument("--launch-check", action="store_true",
                     help="dev / CPU test of the self-launch: the ranks rendezvous over gloo, rank 0 prints one line, no GPU touched")
     args = ap.parse_args()
@@ -218,10 +220,18 @@ def main():
                 dist.barrier()
                 dist.destroy_process_group()
                 raise SystemExit(3)
-    if native:
+    samples_by = "local"
+    if native and args.samples_by == "bcast":
         # the feature matrix crosses the host boundary ONCE (rank 0) and reaches the other GPUs by the
-        # library's RCCL broadcast over xGMI (chb_bcast_samples); every rank then keeps its own resident copy
-        ctx.bcast_samples(X if rank == 0 else None, N, D, root=0)
+        # library's RCCL broadcast over xGMI (chb_bcast_samples); every rank then keeps its own resident copy.  The
+        # library makes the ranks agree on {status, N, D, root} before the collective, so a failure is an error on EVERY
+        # rank -- and then each rank uploads its own (identical, synthetic) copy instead, and the line says so
+        try:
+            ctx.bcast_samples(X if rank == 0 else None, N, D, root=0)
+            samples_by = "bcast"
+        except _lib.ChbError as e:
+            print(f"rank {rank}: chb_bcast_samples failed ({e}); every rank uploads its own copy", file=sys.stderr)
+            ctx.set_samples(X)
     else:
         ctx.set_samples(X)                                    # resident in HBM before timing
 
@@ -583,7 +593,7 @@ def main():
                        "qp_per_step": int(qp_per_step), "batch": batch_used,
                        "generator": {"mix": args.mix, "sigma": args.sigma, "coverage_columns": S},
                        "parallelism_evidence": evidence,
-                       "parallelism": (f"contig-sharded x{world}, " + ("RCCL all-gather in the C++ loop, X by the library's RCCL broadcast (chb_bcast_samples)"
+                       "parallelism": (f"contig-sharded x{world}, " + ("RCCL all-gather in the C++ loop, X " + ("by the library's RCCL broadcast (chb_bcast_samples)" if samples_by == "bcast" else "uploaded by every rank")
                                                                        if native else "torch.distributed all_reduce (Python driver)"))
                        if use_dist else "single GPU"},
             "roofline": roofline,

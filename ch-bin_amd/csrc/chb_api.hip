@@ -239,6 +239,7 @@ struct chb_ctx {
     // the shortlist stage's contract as checked by the fused kernels (FusedArgs::short_cnt): pairs of this fit whose base
     // shortlist held fewer than min(m, bin size) candidates or a wild index -- any is an internal error of the fit
     DevBuf<int> short_cnt;
+    DevBuf<int> agree;   // chb_bcast_samples: {status, N, D, root} of every rank
     int64_t short_seen = 0;
     // bins far larger than the rest are cut into segments for the shortlist stage (SegPlan, prefilter_kernels.hip): plan
     // buffers, and the bin sizes last seen by the host (they come home with the rounds' verdicts)
@@ -257,7 +258,8 @@ struct chb_ctx {
     DevBuf<unsigned long long> ckey;
     DevBuf<int> qord, home;
     bool allow_skip = true;       // CHB_TILE_SKIP=0: never (A/B tests)
-    int skip_state = 0, skip_batches = 0, skip_off_B = -1;
+    int skip_state = 0, skip_batches = 0;
+    long long skip_off_key = -1;   // (bins, neighbours, metric) of the fit that found nothing to skip on these samples
     long long last_batch = 0;
     long long skip_skipped = 0, skip_seen = 0, skip_unloaded = 0;
     DevBuf<float> tau;
@@ -348,6 +350,8 @@ void drain_profile(chb_ctx *h)
     h->pending.clear();
 }
 
+long long skip_key(const chb_ctx *h) { return (long long)h->B | ((long long)h->m << 32) | ((long long)h->metric << 40); }
+
 int ensure_batch_buffers(chb_ctx *h, int Kcap)
 {
     const size_t B = h->B, m = h->m, K = Kcap;
@@ -400,7 +404,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->seg_nseg.ensure(1));
         HIPCHK(h->seg_gflag.ensure(B));
         HIPCHK(h->seg_items.ensure(16 * (size_t)h->seg_gcap));
-        HIPCHK(h->seg_lists.ensure((size_t)h->seg_gcap * 16 * K * (size_t)shortlist_list_len((int)m)));
+        // (seg_lists -- giant slots x 16 segments x K x list length floats, 0.27 / 0.86 GB at 1M x 200 bins for m = 5 / 15 --
+        //  is allocated by the first batch that really runs the segment launches: batch_begin_dev)
         if (h->fused) {
             for (int i = 0; i < 2; ++i) {
                 HIPCHK(h->candu[i].ensure(K * B * (size_t)kCandCapU));
@@ -429,8 +434,9 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
     // the fp16 shortlist stage and the tuned kernels hold lists of up to 16 entries; beyond that the plain
     // one-wavefront-per-problem kernels run (brute-force selection, LDS-resident solver)
     h->pf_fit = h->use_prefilter && h->shadow_ok && m <= kMaxM;
-    // (a fit that found nothing to skip settles it for later fits over the same samples and bin count)
-    h->skip_state = (h->skip_off_B == (int)B) ? -1 : 0;
+    // (a fit that found nothing to skip settles it for later fits over the same samples with the same bin count,
+    //  neighbour count and metric -- the verdict depends on all three)
+    h->skip_state = (h->skip_off_key == skip_key(h)) ? -1 : 0;
     h->skip_batches = 0; h->skip_skipped = 0; h->skip_seen = 0; h->skip_unloaded = 0;
     h->fused = h->allow_fused && h->pf_fit && h->pf_base && h->pf_update && fused_supported(m, h->Dp);
     HIPCHK(h->pin_a.ensure((size_t)h->N));
@@ -504,6 +510,10 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         sp.cap = 16 * h->seg_gcap; sp.gcap = h->seg_gcap;
         const long long est = (long long)h->hint_max_tiles * 3 / 2 + 8;
         sp.launch = h->allow_segments && est > kSegMinTiles && est * h->B > 3LL * std::max(1, h->hint_total_tiles);
+        if (sp.launch) {
+            HIPCHK(h->seg_lists.ensure((size_t)h->seg_gcap * 16 * (size_t)h->Kcap * (size_t)shortlist_list_len(h->m)));
+            sp.lists = h->seg_lists.p;
+        }
     }
     {
         // (the batch is opened -- labels remembered, members marked -- inside the CSR count's launch)
@@ -876,7 +886,7 @@ int chb_destroy(chb_ctx *h)
     h->centers.release();
     h->active.release(); h->n_active.release(); h->act_blk.release();
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
-    h->slow.release(); h->n_slow.release(); h->tau.release(); h->short_cnt.release();
+    h->slow.release(); h->n_slow.release(); h->tau.release(); h->short_cnt.release(); h->agree.release();
     h->seg_nseg.release(); h->seg_gflag.release(); h->seg_items.release(); h->seg_lists.release();
     h->shell_inv.release(); h->ckey.release(); h->qord.release(); h->home.release();
     (void)hipStreamDestroy(h->stream);
@@ -909,7 +919,7 @@ static int samples_upload(chb_ctx *h, const double *X, int64_t N, int64_t D, boo
 // everything that is a function of the resident X alone (global mean, scale, query-side shadow rows)
 static int samples_finish(chb_ctx *h)
 {
-    h->skip_off_B = -1;
+    h->skip_off_key = -1;
     const int64_t N = h->N, D = h->D;
     const int Dp = h->Dp;
     // the shortlist stage (prefilter_kernels.hip) keeps its query fragments in registers: D <= 160
@@ -973,9 +983,32 @@ int chb_bcast_samples(chb_ctx *h, const double *X, int64_t N, int64_t D, int roo
     if (!h) return fail(CHB_EINVAL, "null context");
     if (!h->comm) return fail(CHB_ESTATE, "chb_bcast_samples needs chb_comm_init (RCCL)");
     if (root < 0 || root >= h->world) return fail(CHB_EINVAL, "bad root");
-    if (h->rank == root && !X) return fail(CHB_EINVAL, "the root rank must pass the matrix");
-    int rc = samples_upload(h, h->rank == root ? X : nullptr, N, D, false);
-    if (rc) return rc;
+    // Every rank reports {its own status, N, D, root} BEFORE the collective: a rank that returned early (no matrix on the
+    // root, an allocation that failed) or ranks that disagree about the shape would otherwise leave the others blocked in
+    // ncclBroadcast for good, or broadcast into buffers of the wrong size.
+    int rc = (h->rank == root && !X) ? fail(CHB_EINVAL, "the root rank must pass the matrix")
+                                     : samples_upload(h, h->rank == root ? X : nullptr, N, D, false);
+    {
+        const std::string my_err = g_err;
+        const int world = h->world;
+        HIPCHK(h->agree.ensure((size_t)4 * world));
+        std::vector<int> all((size_t)4 * world, 0);
+        int *mine = all.data() + 4 * h->rank;
+        mine[0] = rc; mine[1] = (int)(N & 0x7fffffff); mine[2] = (int)(D & 0x7fffffff); mine[3] = root;
+        HIPCHK(hipMemcpyAsync(h->agree.p + 4 * h->rank, mine, 4 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        NCCLCHK(rccl()->AllGather(h->agree.p + 4 * h->rank, h->agree.p, 4, ncclInt32, h->comm, h->stream));
+        HIPCHK(hipMemcpyAsync(all.data(), h->agree.p, sizeof(int) * all.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (rc) return fail(rc, my_err);
+        for (int r = 0; r < world; ++r) {
+            const int *o = all.data() + 4 * r;
+            if (o[0] != 0)
+                return fail(CHB_ESTATE, "chb_bcast_samples: rank " + std::to_string(r) + " failed before the broadcast (status " +
+                                        std::to_string(o[0]) + ")");
+            if (o[1] != mine[1] || o[2] != mine[2] || o[3] != mine[3])
+                return fail(CHB_EINVAL, "chb_bcast_samples: rank " + std::to_string(r) + " passed a different N, D or root");
+        }
+    }
     // the padded resident copy goes out as it lies on the root: one RCCL broadcast over xGMI
     NCCLCHK(rccl()->Broadcast(h->X.p, h->X.p, (size_t)N * (size_t)h->Dp, ncclDouble, root, h->comm, h->stream));
     return samples_finish(h);
@@ -1023,7 +1056,11 @@ int chb_fit_begin(chb_ctx *h, int64_t B, const int64_t *initial_bins, int m)
 {
     if (!h || !initial_bins) return fail(CHB_EINVAL, "null argument");
     HIPCHK(hipSetDevice(h->dev));
-    return fit_begin_impl(h, B, initial_bins, m);
+    const int rc = fit_begin_impl(h, B, initial_bins, m);
+    // (the stepwise batches have no loop that reads the skip statistics and could turn the tile-skipping builds off
+    //  where they do not pay: they run the ordinary builds)
+    if (rc == CHB_OK) h->skip_state = -1;
+    return rc;
 }
 
 int chb_batch_begin(chb_ctx *h, const int64_t *perm_slice, int64_t K, int64_t q_lo, int64_t q_hi)
@@ -1266,14 +1303,16 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             // (bin sizes of that batch, for the segment decision of the batches still to be enqueued; and what the tile
             //  skipping of its shortlist launch achieved: a fit whose first batches skip next to nothing turns it off)
             h->hint_max_tiles = h->fc_host[8 * slot + 1]; h->hint_total_tiles = h->fc_host[8 * slot + 2];
-            if (h->fc_host[8 * slot + 4] > 0) {
+            // (the slot's statistics are written by the batch's one base shortlist launch: counted with the batch's first
+            //  round only -- later rounds of the same batch bring the same three numbers home again)
+            if (active == 0 && h->fc_host[8 * slot + 4] > 0) {
                 h->skip_skipped += h->fc_host[8 * slot + 3]; h->skip_seen += h->fc_host[8 * slot + 4];
                 h->skip_unloaded += h->fc_host[8 * slot + 5];
                 if (h->skip_state == 0 && ++h->skip_batches >= 3)
                 {
                     // (it pays from a few per cent of the wave-tiles)
                     h->skip_state = ((h->skip_skipped + h->skip_unloaded) * 50 >= h->skip_seen + h->skip_unloaded) ? 1 : -1;
-                    if (h->skip_state < 0) h->skip_off_B = h->B;
+                    if (h->skip_state < 0) h->skip_off_key = skip_key(h);
                 }
             }
             (void)active; (void)g;
