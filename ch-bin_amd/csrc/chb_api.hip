@@ -240,6 +240,7 @@ struct chb_ctx {
     // shortlist held fewer than min(m, bin size) candidates or a wild index -- any is an internal error of the fit
     DevBuf<int> short_cnt;
     DevBuf<int> agree;   // chb_bcast_samples: {status, N, D, root} of every rank
+    int dev_inject_batches = 0;   // developer builds: batch starts of this context so far (CHB_SL_INJECT_SHORT)
     int64_t short_seen = 0;
     // bins far larger than the rest are cut into segments for the shortlist stage (SegPlan, prefilter_kernels.hip): plan
     // buffers, and the bin sizes last seen by the host (they come home with the rounds' verdicts)
@@ -604,11 +605,10 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             launch_topm_flagged(a, h->flags64.p, h->flaglist.p, h->nflag.p, s);
         }
 #ifdef CHB_DEV_KNOBS
-        // CHB_SL_INJECT_SHORT=<n>: the n-th batch start of the process hands the hull kernels one truncated shortlist
+        // CHB_SL_INJECT_SHORT=<n>: the n-th batch start of a context hands the hull kernels one truncated shortlist
         // (tests: the product build's check must turn it into an error)
         if (fusedp) if (const char *ev = getenv("CHB_SL_INJECT_SHORT")) {
-            static int inj_batch = 0;
-            if (++inj_batch == atoi(ev)) launch_inject_short(h->cand_cnt.p, h->B, h->Kcap, q_lo, h->bin_ptr.p, h->m, s);
+            if (++h->dev_inject_batches == atoi(ev)) launch_inject_short(h->cand_cnt.p, h->B, h->Kcap, q_lo, h->bin_ptr.p, h->m, s);
         }
 #endif
 #ifdef CHB_DEV_KNOBS
@@ -903,7 +903,13 @@ static int samples_upload(chb_ctx *h, const double *X, int64_t N, int64_t D, boo
     if (N <= 0 || D <= 0) return fail(CHB_EINVAL, "samples must be a non-empty N x D matrix");
     if (N >= (1LL << 31) - 64 || D > (1 << 20)) return fail(CHB_EUNSUPPORTED, "N or D too large");
     HIPCHK(hipSetDevice(h->dev));
-    const int Dp = (int)((D + kKChunk - 1) / kKChunk) * kKChunk;
+    // rows padded to whole 128-byte lines (16 doubles): a 16-lane group of the hull kernels reads a row in 256-byte pieces
+    // from its start, and a row that starts in the middle of a line makes every piece touch three lines instead of two
+#ifndef CHB_ROW_PAD
+#define CHB_ROW_PAD 16
+#endif
+    static_assert(CHB_ROW_PAD % kKChunk == 0, "the tile kernels stage kKChunk columns at a time");
+    const int Dp = (int)((D + CHB_ROW_PAD - 1) / CHB_ROW_PAD) * CHB_ROW_PAD;
     HIPCHK(h->X.ensure((size_t)N * Dp));
     if (X != nullptr) {
         if (Dp != D) HIPCHK(hipMemsetAsync(h->X.p, 0, sizeof(double) * (size_t)N * Dp, h->stream));

@@ -63,6 +63,10 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+#ifndef CHB_SL_DEFER
+#define CHB_SL_DEFER 0   // 1: a tile's selection code runs one tile late, under the next tile's LDS reads (round 4 experiment:
+                         // no gain at 100k x 136 x 64, +21 % / +45 % on the tile-skipping builds, whose registers it spills)
+#endif
 #ifndef CHB_SL_DMAREP
 #define CHB_SL_DMAREP 1   // developer experiment: issue every tile's DMA this many times
 #endif
@@ -755,6 +759,8 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     //  segment flush's bases -- and read their fragments in two halves through the same registers: 4 instead of 3
     //  workgroups per CU)
     constexpr bool kFour = KS == 10 && !UPD && ML <= 5 && SEG != 2;
+    constexpr bool kDefer = CHB_SL_DEFER != 0 && !UPD;   // base mode: a tile's selection code runs under the next tile's LDS reads
+    constexpr bool kHalf9 = kDefer && KS == 9 && ML <= 5;   // ... and the 144-column builds read their fragments in two halves too
     constexpr int BUFB = kFour ? TILEB : TILEB + METAB;
     constexpr int NBUF = 3;
     constexpr int kPoolW = shortlist_pool_entries(ML);
@@ -1059,161 +1065,23 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
             // the tile about to be requested (two ahead) is down, nobody needs it or any later tile: the run ends two
             // tiles from here, for the issue side (on to the next sweep / bin at once) and for the consumers alike.
             int nt_run = ntile;
-            for (int ct = 0; ct < nt_run; ++ct) {
-                wait_vmcnt(n_issued - n_consumed > 1 ? n_w : 0);   // my pieces of this tile have landed
-                if (can_skip) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (and my flag writes)
-                __builtin_amdgcn_s_barrier();   // everybody's have; the buffer two tiles ahead is free again
-                if (can_skip && ct + 2 < nt_run && ct + 2 >= 3) {
-                    // (the issue side stands at tile ct + 2 of this very run)
-                    // (asm read: the compiler would order an ordinary LDS read behind the tile DMA -- vmcnt(0))
-                    int nd;
-                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=v"(nd) : "v"(need_base + 4u * (unsigned)((ct + 2) & 3)) : "memory");
-#ifdef CHB_DEV_KNOBS
-                    if (kNoExit) nd = 1;
-#endif
-                    if (__builtin_amdgcn_readfirstlane(nd) == 0) {
-                        nt_run = ct + 2;
-                        CHB_SL_ISSUE_NEXTRUN()
-                    }
-                }
-                if (ivalid) CHB_SL_ISSUE()
-                if (can_skip && tid == 0) lds_write_u32(need_base + 4u * (unsigned)((ct + 1) & 3), 0u);   // (read one tile ago; next written in two)
-
-                const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
-                // rows held by this lane: (r & 3) + 8 (r >> 2) + 4 h
-                const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
-                float tsn_t = 0.f, tsn_3 = 0.f;   // largest member norm of this tile (and of the rest of the bin) / three tiles on
-                if (SKIP) {
-                    if (ct + 3 - tbase >= 64) { tbase = ct; v_tsn = tsn_c[ct + lane]; asm volatile("" : "+v"(v_tsn)); }   // (waited for here, not at a use)
-                    tsn_t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_tsn), ct - tbase));
-                    tsn_3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_tsn), ct + 3 - tbase));
-                }
-                bool do_tile = true;
-                if (can_skip) {
-                    const float thr_now = sweep == 0 ? tau_run : hi_s1;
-                    // does anybody of this wavefront need tile ct + 3?  (with the threshold as it stands: it only tightens)
-                    if (ct + 3 < nt_run) {
-                        const bool need3 = (qvalid && !(zn_lo - tsn_3 * (1.0f + kSlack) > thr_now)) || kSkipNever;
-                        if (__ballot(need3) != 0ull && lane == 0) lds_write_u32(need_base + 4u * (unsigned)((ct + 3) & 3), 1u);
-                    }
-                    // and this tile: no fragment reads, no matrix core, no selection code for a wavefront none of whose
-                    // queries can find a member of its top m here (the barriers stay: they are the workgroup's)
-                    const bool need0 = (qvalid && !(zn_lo - tsn_t * (1.0f + kSlack) > thr_now)) || kSkipNever;
-                    ++wt_seen;
-#ifdef CHB_DEV_KNOBS
-                    if (__ballot(need0) == 0ull && !kNoWaveSkip) { do_tile = false; ++wt_skipped; }
-#else
-                    if (__ballot(need0) == 0ull) { do_tile = false; ++wt_skipped; }
-#endif
-                }
-                if (!do_tile) {
-                    ++n_consumed;
-                    if (++cbuf == NBUF) cbuf = 0;
-                    continue;
-                }
-#ifdef CHB_DEV_KNOBS
-                ++dbg_tiles;
-#endif
-                f32x16 acc;
-                if (UPD) {
-                    f32x4 nv[4], nn[4], sv[4], bv[4];
-#define CHB_SL_META(G)                                                                             \
-                    nv[G] = lds_read_f4<32 * (G)>(ma);                                             \
-                    nn[G] = lds_read_f4<384 + 32 * (G)>(ma);                                       \
-                    sv[G] = lds_read_f4<128 + 32 * (G)>(ma); bv[G] = lds_read_f4<256 + 32 * (G)>(ma);
-                    CHB_SL_META(0) CHB_SL_META(1) CHB_SL_META(2) CHB_SL_META(3)
-#undef CHB_SL_META
-                    // (asm reads are complete once the tied s_waitcnt below returns: no use can be scheduled
-                    //  ahead of it.  Two phases -- bias column, then fragments -- keep the peak register count down.)
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "+v"(nn[0]), "+v"(nn[1]), "+v"(nn[2]),
-                                   "+v"(nn[3])
-                                 :
-                                 : "memory");
-                    asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(bv[0]), "+v"(bv[1]),
-                                      "+v"(bv[2]), "+v"(bv[3]) : : "memory");
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            // -bias / 2, pushed up (lower bounds) by the query's rounding error against THIS member's norm
-                            acc[4 * g + k] = fmaf(rgs, nn[g][k], -0.5f * nv[g][k]);
-                            // a batch member counts for this query only on the right side of the visiting order
-                            if (fmaf(sv[g][k], qposf, bv[g][k]) < 0.f) acc[4 * g + k] = -INFINITY;
-                        }
-                    }
-                } else {
-                    // base members: -bias / 2 is part of the dot product (three bias columns of the row against the
-                    // query's 2^kBiasExp) -- the tile loop touches nothing but the fragments
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                }
-                // base mode (builds without tile skipping): the tile's largest member norm, a SCALAR load (an ordinary vector
-                // load here would make the compiler drain the tile DMA queue); it is complete behind the fragment reads'
-                // lgkmcnt(0) below
-                if (!UPD && !SKIP) {
-                    const unsigned long long ta = reinterpret_cast<unsigned long long>(tsn_c + ct);
-                    const unsigned ta_lo = __builtin_amdgcn_readfirstlane((unsigned)ta);
-                    const unsigned ta_hi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
-                    const unsigned long long ta_s = ((unsigned long long)ta_hi << 32) | ta_lo;
-                    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(tsn_t) : "s"(ta_s) : "memory");
-                }
-                if constexpr (kFour) {
-                    // ten fragments through five registers: the second half is requested as the matrix core takes the first
-                    const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
-                    f16x8 h0 = lds_read_frag<0>(fa0), h1 = lds_read_frag<0>(fa1), h2 = lds_read_frag<64>(fa0),
-                          h3 = lds_read_frag<64>(fa1), h4 = lds_read_frag<128>(fa0);
-                    if (SKIP)
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : : "memory");
-                    else
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+s"(tsn_t) : : "memory");
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, qreg[0], acc, 0, 0, 0); h0 = lds_read_frag<128>(fa1);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, qreg[1], acc, 0, 0, 0); h1 = lds_read_frag<192>(fa0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, qreg[2], acc, 0, 0, 0); h2 = lds_read_frag<192>(fa1);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h3, qreg[3], acc, 0, 0, 0); h3 = lds_read_frag<256>(fa0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h4, qreg[4], acc, 0, 0, 0); h4 = lds_read_frag<256>(fa1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : : "memory");
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, qreg[5], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, qreg[6], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, qreg[7], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h3, qreg[8], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h4, qreg[9], acc, 0, 0, 0);
-                } else {
-                f16x8 af[KS == 9 ? 9 : 10];
-                {
-                    const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
-                    if (KS == 9) {
-                        af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<32>(fa0);  af[2] = lds_read_frag<64>(fa0);
-                        af[3] = lds_read_frag<96>(fa0);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<160>(fa0);
-                        af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<224>(fa0); af[8] = lds_read_frag<256>(fa0);
-                    } else {
-                        af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<0>(fa1);   af[2] = lds_read_frag<64>(fa0);
-                        af[3] = lds_read_frag<64>(fa1);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<128>(fa1);
-                        af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<192>(fa1); af[8] = lds_read_frag<256>(fa0);
-                        af[9] = lds_read_frag<256>(fa1);
-                    }
-                }
-                if (SKIP)
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
-                                   "+v"(af[6]), "+v"(af[7]), "+v"(af[8])
-                                 :
-                                 : "memory");
-                else
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
-                                   "+v"(af[6]), "+v"(af[7]), "+v"(af[8]), "+s"(tsn_t)
-                                 :
-                                 : "memory");
-                if (KS == 10) asm volatile("" : "+v"(af[KS - 1]) : : "memory");
-#pragma unroll
-                for (int sx = 0; sx < KS; ++sx)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[sx], qreg[sx], acc, 0, 0, 0);
-                }
-
-                // base mode: this tile's query-rounding term (a wave-uniform table read)
-                const float dlt = UPD ? 0.f : rgq * tsn_t;
+            // Everything this (bin, sweep) has loaded so far -- bounds, thresholds, spilled values -- is waited for HERE, by a
+            // wait the compiler knows (the builtin, not asm): otherwise its own waitcnt pass finds those loads still pending
+            // on the path into the loop and puts `s_waitcnt vmcnt(0)` in front of their first use INSIDE the tile loop, on
+            // every iteration (the loop header merges the pre-loop state) -- which drains the two member tiles kept in
+            // flight once per tile (round 3's builds did, in the selection code of sweep 1).  Once per run costs nothing.
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            // The selection code of a tile ("epilogue").  kDefer (base mode): it runs one tile LATE -- between the issue of the
+            // next tile's fragment reads and their wait -- so that a wavefront's matrix-core chain runs under its own trip
+            // round the barrier, the DMA issue and the next reads instead of being waited for right behind its last
+            // instruction, and the selection's vector work hides the LDS latency (MI355X_MICROARCH.md, "Two waves that run
+            // the SAME program ...": a deferred epilogue; here for every wavefront, the accumulators are simply left alone
+            // until the next tile's products are about to overwrite them -- no second set of registers).
+            f32x16 acc;
+            bool pend = false;
+            float dlt_p = 0.f;
+            int ct_p = 0;
+            auto epilogue = [&](const float dlt, const int ctp) __attribute__((always_inline)) {
                 if (!UPD && sweep == 0) {
                     // acc = -t/2: UB is monotone in t, so the m LARGEST accumulators are kept (pushed down by the
                     // tile's term: upper bounds of t); per tile a 16-way maximum and one branch
@@ -1265,7 +1133,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                         CHB_SL_FLUSH()
                         wcnt = 0;
                     }
-                    const unsigned ebase = ent0 + (unsigned)((ct + seg_tb) * kPfP);
+                    const unsigned ebase = ent0 + (unsigned)((ctp + seg_tb) * kPfP);
                     const float thr_t = thr2 - dlt;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -1282,9 +1150,197 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                         }
                     }
                 }
+            };
+            for (int ct = 0; ct < nt_run; ++ct) {
+                wait_vmcnt(n_issued - n_consumed > 1 ? n_w : 0);   // my pieces of this tile have landed
+                if (can_skip) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (and my flag writes)
+                __builtin_amdgcn_s_barrier();   // everybody's have; the buffer two tiles ahead is free again
+                if (can_skip && ct + 2 < nt_run && ct + 2 >= 3) {
+                    // (the issue side stands at tile ct + 2 of this very run)
+                    // (asm read: the compiler would order an ordinary LDS read behind the tile DMA -- vmcnt(0))
+                    int nd;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=v"(nd) : "v"(need_base + 4u * (unsigned)((ct + 2) & 3)) : "memory");
+#ifdef CHB_DEV_KNOBS
+                    if (kNoExit) nd = 1;
+#endif
+                    if (__builtin_amdgcn_readfirstlane(nd) == 0) {
+                        nt_run = ct + 2;
+                        CHB_SL_ISSUE_NEXTRUN()
+                    }
+                }
+                if (ivalid) CHB_SL_ISSUE()
+                if (can_skip && tid == 0) lds_write_u32(need_base + 4u * (unsigned)((ct + 1) & 3), 0u);   // (read one tile ago; next written in two)
+
+                const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
+                // rows held by this lane: (r & 3) + 8 (r >> 2) + 4 h
+                const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
+                float tsn_t = 0.f, tsn_3 = 0.f;   // largest member norm of this tile (and of the rest of the bin) / three tiles on
+                if (SKIP) {
+                    if (ct + 3 - tbase >= 64) { tbase = ct; v_tsn = tsn_c[ct + lane]; asm volatile("" : "+v"(v_tsn)); }   // (waited for here, not at a use)
+                    tsn_t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_tsn), ct - tbase));
+                    tsn_3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_tsn), ct + 3 - tbase));
+                }
+                bool do_tile = true;
+                if (can_skip) {
+                    const float thr_now = sweep == 0 ? tau_run : hi_s1;
+                    // does anybody of this wavefront need tile ct + 3?  (with the threshold as it stands: it only tightens)
+                    if (ct + 3 < nt_run) {
+                        const bool need3 = (qvalid && !(zn_lo - tsn_3 * (1.0f + kSlack) > thr_now)) || kSkipNever;
+                        if (__ballot(need3) != 0ull && lane == 0) lds_write_u32(need_base + 4u * (unsigned)((ct + 3) & 3), 1u);
+                    }
+                    // and this tile: no fragment reads, no matrix core, no selection code for a wavefront none of whose
+                    // queries can find a member of its top m here (the barriers stay: they are the workgroup's)
+                    const bool need0 = (qvalid && !(zn_lo - tsn_t * (1.0f + kSlack) > thr_now)) || kSkipNever;
+                    ++wt_seen;
+#ifdef CHB_DEV_KNOBS
+                    if (__ballot(need0) == 0ull && !kNoWaveSkip) { do_tile = false; ++wt_skipped; }
+#else
+                    if (__ballot(need0) == 0ull) { do_tile = false; ++wt_skipped; }
+#endif
+                }
+                if (!do_tile) {
+                    if (kDefer && pend) { epilogue(dlt_p, ct_p); pend = false; }
+                    ++n_consumed;
+                    if (++cbuf == NBUF) cbuf = 0;
+                    continue;
+                }
+#ifdef CHB_DEV_KNOBS
+                ++dbg_tiles;
+#endif
+                if (UPD) {
+                    f32x4 nv[4], nn[4], sv[4], bv[4];
+#define CHB_SL_META(G)                                                                             \
+                    nv[G] = lds_read_f4<32 * (G)>(ma);                                             \
+                    nn[G] = lds_read_f4<384 + 32 * (G)>(ma);                                       \
+                    sv[G] = lds_read_f4<128 + 32 * (G)>(ma); bv[G] = lds_read_f4<256 + 32 * (G)>(ma);
+                    CHB_SL_META(0) CHB_SL_META(1) CHB_SL_META(2) CHB_SL_META(3)
+#undef CHB_SL_META
+                    // (asm reads are complete once the tied s_waitcnt below returns: no use can be scheduled
+                    //  ahead of it.  Two phases -- bias column, then fragments -- keep the peak register count down.)
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "+v"(nn[0]), "+v"(nn[1]), "+v"(nn[2]),
+                                   "+v"(nn[3])
+                                 :
+                                 : "memory");
+                    asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(bv[0]), "+v"(bv[1]),
+                                      "+v"(bv[2]), "+v"(bv[3]) : : "memory");
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            // -bias / 2, pushed up (lower bounds) by the query's rounding error against THIS member's norm
+                            acc[4 * g + k] = fmaf(rgs, nn[g][k], -0.5f * nv[g][k]);
+                            // a batch member counts for this query only on the right side of the visiting order
+                            if (fmaf(sv[g][k], qposf, bv[g][k]) < 0.f) acc[4 * g + k] = -INFINITY;
+                        }
+                    }
+                }
+                // base mode (builds without tile skipping): the tile's largest member norm, a SCALAR load (an ordinary vector
+                // load here would make the compiler drain the tile DMA queue); it is complete behind the fragment reads'
+                // lgkmcnt(0) below
+                if (!UPD && !SKIP) {
+                    const unsigned long long ta = reinterpret_cast<unsigned long long>(tsn_c + ct);
+                    const unsigned ta_lo = __builtin_amdgcn_readfirstlane((unsigned)ta);
+                    const unsigned ta_hi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
+                    const unsigned long long ta_s = ((unsigned long long)ta_hi << 32) | ta_lo;
+                    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(tsn_t) : "s"(ta_s) : "memory");
+                }
+                if constexpr (kFour) {
+                    // ten fragments through five registers: the second half is requested as the matrix core takes the first
+                    const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
+                    f16x8 h0 = lds_read_frag<0>(fa0), h1 = lds_read_frag<0>(fa1), h2 = lds_read_frag<64>(fa0),
+                          h3 = lds_read_frag<64>(fa1), h4 = lds_read_frag<128>(fa0);
+                    if (kDefer && pend) epilogue(dlt_p, ct_p);   // (the previous tile's, under this tile's LDS reads)
+                    if (SKIP)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : : "memory");
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+s"(tsn_t) : : "memory");
+                    // base members: -bias / 2 is part of the dot product (three bias columns of the row against the query's 2^kBiasExp) -- the
+                    // tile loop touches nothing but the fragments
+                    if (!UPD) {
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, qreg[0], acc, 0, 0, 0); h0 = lds_read_frag<128>(fa1);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, qreg[1], acc, 0, 0, 0); h1 = lds_read_frag<192>(fa0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, qreg[2], acc, 0, 0, 0); h2 = lds_read_frag<192>(fa1);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h3, qreg[3], acc, 0, 0, 0); h3 = lds_read_frag<256>(fa0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h4, qreg[4], acc, 0, 0, 0); h4 = lds_read_frag<256>(fa1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : : "memory");
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, qreg[5], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, qreg[6], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, qreg[7], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h3, qreg[8], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h4, qreg[9], acc, 0, 0, 0);
+                } else if constexpr (kHalf9) {
+                    // nine fragments through five registers (as kFour): the deferred selection code of the previous tile runs
+                    // while the first five are on their way -- with all nine in flight it would not fit 128 registers
+                    const unsigned fa0 = tb + (unsigned)fbase0;
+                    f16x8 h0 = lds_read_frag<0>(fa0), h1 = lds_read_frag<32>(fa0), h2 = lds_read_frag<64>(fa0),
+                          h3 = lds_read_frag<96>(fa0), h4 = lds_read_frag<128>(fa0);
+                    if (pend) epilogue(dlt_p, ct_p);   // (the previous tile's, under this tile's LDS reads)
+                    if (SKIP)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : : "memory");
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+s"(tsn_t) : : "memory");
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, qreg[0], acc, 0, 0, 0); h0 = lds_read_frag<160>(fa0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, qreg[1], acc, 0, 0, 0); h1 = lds_read_frag<192>(fa0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, qreg[2], acc, 0, 0, 0); h2 = lds_read_frag<224>(fa0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h3, qreg[3], acc, 0, 0, 0); h3 = lds_read_frag<256>(fa0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h4, qreg[4], acc, 0, 0, 0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : : "memory");
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, qreg[5], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, qreg[6], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, qreg[7], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h3, qreg[8], acc, 0, 0, 0);
+                } else {
+                f16x8 af[KS == 9 ? 9 : 10];
+                {
+                    const unsigned fa0 = tb + (unsigned)fbase0, fa1 = tb + (unsigned)fbase1;
+                    if (KS == 9) {
+                        af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<32>(fa0);  af[2] = lds_read_frag<64>(fa0);
+                        af[3] = lds_read_frag<96>(fa0);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<160>(fa0);
+                        af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<224>(fa0); af[8] = lds_read_frag<256>(fa0);
+                    } else {
+                        af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<0>(fa1);   af[2] = lds_read_frag<64>(fa0);
+                        af[3] = lds_read_frag<64>(fa1);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<128>(fa1);
+                        af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<192>(fa1); af[8] = lds_read_frag<256>(fa0);
+                        af[9] = lds_read_frag<256>(fa1);
+                    }
+                }
+                if (kDefer && pend) epilogue(dlt_p, ct_p);   // (the previous tile's, under this tile's LDS reads)
+                if (SKIP)
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                                   "+v"(af[6]), "+v"(af[7]), "+v"(af[8])
+                                 :
+                                 : "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                                   "+v"(af[6]), "+v"(af[7]), "+v"(af[8]), "+s"(tsn_t)
+                                 :
+                                 : "memory");
+                if (KS == 10) asm volatile("" : "+v"(af[KS - 1]) : : "memory");
+                // base members: -bias / 2 is part of the dot product (three bias columns of the row against the query's 2^kBiasExp) -- the
+                // tile loop touches nothing but the fragments
+                if (!UPD) {
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                }
+#pragma unroll
+                for (int sx = 0; sx < KS; ++sx)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[sx], qreg[sx], acc, 0, 0, 0);
+                }
+
+                // base mode: this tile's query-rounding term (a wave-uniform table read)
+                const float dlt = UPD ? 0.f : rgq * tsn_t;
+                if (kDefer) { dlt_p = dlt; ct_p = ct; pend = true; }
+                else epilogue(dlt, ct);
                 ++n_consumed;
                 if (++cbuf == NBUF) cbuf = 0;
             }
+            if (kDefer && pend) { epilogue(dlt_p, ct_p); pend = false; }   // the run's last tile
             if (can_skip) wt_unloaded += ntile - nt_run;
         }
 

@@ -421,9 +421,9 @@ constexpr double kTieRel = 1e-11;
 // 64-bit row pointers, which is what keeps the kernel free of spills at 3 wavefronts per SIMD (the launcher picks
 // it when the sample matrix is smaller than 4 GiB).
 template <int CC, int NR, bool OFF32>
-__device__ __forceinline__ void gram_rows(const double *X, int Dp, int qid, int idm, int gbase, int l16,
+__device__ __forceinline__ void gram_rows(const double *X, int Dp, int Dk, int qid, int idm, int gbase, int l16,
                                           double (&r)[NR])
-{
+{   // (Dp: row stride -- whole 128-byte lines; Dk: the columns swept, D rounded up to 8: the padding beyond is never read)
     constexpr int NP = CC * (CC + 1) / 2;
     static_assert(NP <= 16 * NR, "result registers");
     const char *Xb = reinterpret_cast<const char *>(X);
@@ -445,7 +445,7 @@ __device__ __forceinline__ void gram_rows(const double *X, int Dp, int qid, int 
     double acc[NP];
 #pragma unroll
     for (int e = 0; e < NP; ++e) acc[e] = 0.0;
-    const int Dmain = Dp & ~31;
+    const int Dmain = Dk & ~31;
 #pragma unroll 1
     for (int k = 2 * l16; k < Dmain; k += 32) {
         const double2 xk = *reinterpret_cast<const double2 *>(xat(k));
@@ -464,7 +464,7 @@ __device__ __forceinline__ void gram_rows(const double *X, int Dp, int qid, int 
                 acc[i * (i + 1) / 2 + j] = fma(y[i].y, y[j].y, t);
             }
     }
-    for (int k = Dmain + l16; k < Dp; k += 16) {
+    for (int k = Dmain + l16; k < Dk; k += 16) {
         const double xk = *xat(k);
         double y[CC];
 #pragma unroll
@@ -497,7 +497,7 @@ constexpr int kFusedWide = CHB_FUSED_WIDE;   // widest shortlist the fused kerne
 // squared distances only: candidate v (v < 8) of every 16-lane group is the one held by lane gbase + v0 + v;
 // on return lane l16 < 8 holds the squared distance of candidate v0 + l16
 template <bool OFF32>
-__device__ __forceinline__ double diag_rows8(const double *X, int Dp, int qid, int idm, int gbase, int l16, int v0)
+__device__ __forceinline__ double diag_rows8(const double *X, int Dp, int Dk, int qid, int idm, int gbase, int l16, int v0)
 {
     const char *Xb = reinterpret_cast<const char *>(X);
     const double *xrow = X + (size_t)qid * Dp;
@@ -517,7 +517,7 @@ __device__ __forceinline__ double diag_rows8(const double *X, int Dp, int qid, i
     double acc[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0;
-    const int Dmain = Dp & ~31;
+    const int Dmain = Dk & ~31;
 #pragma unroll 1
     for (int k = 2 * l16; k < Dmain; k += 32) {
         const double2 xk = *reinterpret_cast<const double2 *>(xat(k));
@@ -528,7 +528,7 @@ __device__ __forceinline__ double diag_rows8(const double *X, int Dp, int qid, i
             acc[v] = fma(dy, dy, fma(dx, dx, acc[v]));
         }
     }
-    for (int k = Dmain + l16; k < Dp; k += 16) {
+    for (int k = Dmain + l16; k < Dk; k += 16) {
         const double xk = *xat(k);
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
@@ -582,6 +582,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15, gbase = lane & 48;
     const int m = a.m;
+    const int Dk = (a.D + 7) & ~7;   // columns swept (the rows are padded to whole 128-byte lines beyond)
     if (threadIdx.x == 0) sSlowN = 0;
     __syncthreads();
     // (striped: the wavefront's place in its XCD's own pair list; nprob is then the length of the longest of the 8 lists)
@@ -667,10 +668,10 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             // the widest shortlist of the pass (the last problem: they are sorted)
             const int cw = __builtin_amdgcn_readfirstlane(__shfl(n, sOrd[w][min(p0 + 3, nnarrow - 1)], 64));
             double r[NR];
-            if (cw <= M) gram_rows<M, NR, OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
-            else if (C >= M + 1 && cw == M + 1) gram_rows<(C >= M + 1 ? M + 1 : M), NR, OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
-            else if (C >= M + 2 && cw == M + 2) gram_rows<(C >= M + 2 ? M + 2 : M), NR, OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
-            else gram_rows<C, NR, OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, r);
+            if (cw <= M) gram_rows<M, NR, OFF32>(a.X, a.Dp, Dk, qid_g, idm, gbase, l16, r);
+            else if (C >= M + 1 && cw == M + 1) gram_rows<(C >= M + 1 ? M + 1 : M), NR, OFF32>(a.X, a.Dp, Dk, qid_g, idm, gbase, l16, r);
+            else if (C >= M + 2 && cw == M + 2) gram_rows<(C >= M + 2 ? M + 2 : M), NR, OFF32>(a.X, a.Dp, Dk, qid_g, idm, gbase, l16, r);
+            else gram_rows<C, NR, OFF32>(a.X, a.Dp, Dk, qid_g, idm, gbase, l16, r);
             bool tie = false;
             if (has && n_g <= m) {
                 // every candidate is a hull vertex: the candidate Gram is the hull's (any vertex order)
@@ -750,9 +751,9 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
             nmax = max(nmax, __shfl_xor(nmax, 16, 64));
             nmax = max(nmax, __shfl_xor(nmax, 32, 64));
             nmax = __builtin_amdgcn_readfirstlane(nmax);
-            double sv = diag_rows8<OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, 0);
+            double sv = diag_rows8<OFF32>(a.X, a.Dp, Dk, qid_g, idm, gbase, l16, 0);
             if (nmax > 8) {
-                const double s_hi = diag_rows8<OFF32>(a.X, a.Dp, qid_g, idm, gbase, l16, 8);
+                const double s_hi = diag_rows8<OFF32>(a.X, a.Dp, Dk, qid_g, idm, gbase, l16, 8);
                 const double moved = __shfl(s_hi, gbase + (l16 & 7), 64);
                 sv = l16 < 8 ? sv : moved;
             }
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
                 if (l16 < m) idm2 = sSel[w][grp][l16];
             }
             double r[NR];
-            gram_rows<M, NR, OFF32>(a.X, a.Dp, qid_g, idm2, gbase, l16, r);
+            gram_rows<M, NR, OFF32>(a.X, a.Dp, Dk, qid_g, idm2, gbase, l16, r);
             if (has && !tie) {
 #pragma unroll
                 for (int t = 0; t < NR; ++t)
@@ -1194,22 +1195,22 @@ __device__ __forceinline__ void mfma_chunk16(const RowChunk16<TWO> &cur, f64x4 &
     }
 }
 template <bool TWO>
-__device__ __forceinline__ void gram_tile16(const double *X, int Dp, int q, int idv, int idw, int kq, f64x4 &acc,
+__device__ __forceinline__ void gram_tile16(const double *X, int Dp, int Dk, int q, int idv, int idw, int kq, f64x4 &acc,
                                             f64x4 &acx, f64x4 &acw)
 {
     const double *vptr = X + (size_t)(idv >= 0 ? idv : q) * Dp + 4 * kq;   // a missing vertex reads the query row: y = 0
     const double *wptr = X + (size_t)(idw >= 0 ? idw : q) * Dp + 4 * kq;
     const double *qptr = X + (size_t)q * Dp + 4 * kq;
-    const int Dfull = Dp & ~31;
+    const int Dfull = Dk & ~31;
     int k0 = 0;
     for (; k0 < Dfull; k0 += 32) {
         RowChunk16<TWO> cur;
-        load_chunk16<TWO, true>(cur, vptr, wptr, qptr, k0, kq, Dp);
+        load_chunk16<TWO, true>(cur, vptr, wptr, qptr, k0, kq, Dk);
         mfma_chunk16<TWO>(cur, acc, acx, acw);
     }
-    if (k0 < Dp) {
+    if (k0 < Dk) {
         RowChunk16<TWO> cur;
-        load_chunk16<TWO, false>(cur, vptr, wptr, qptr, k0, kq, Dp);
+        load_chunk16<TWO, false>(cur, vptr, wptr, qptr, k0, kq, Dk);
         mfma_chunk16<TWO>(cur, acc, acx, acw);
     }
 }
@@ -1271,7 +1272,7 @@ __device__ __forceinline__ void gram_sweep16_chunk(const double *vptr, const dou
     }
 }
 template <int NE, int CH>
-__device__ __forceinline__ void gram_sweep16(const double *X, int Dp, int q, int idv, const int (&ide)[kExtraMax], int kq,
+__device__ __forceinline__ void gram_sweep16(const double *X, int Dp, int Dk, int q, int idv, const int (&ide)[kExtraMax], int kq,
                                              const double *xs, f64x4 &acc, double (&ae)[kExtraMax],
                                              double (&ee)[kExtraNP])
 {
@@ -1284,8 +1285,8 @@ __device__ __forceinline__ void gram_sweep16(const double *X, int Dp, int q, int
 #pragma unroll
     for (int e = 0; e < kExtraNP; ++e) ee[e] = 0.0;
     int k0 = 0;
-    for (; k0 + CH <= Dp; k0 += CH) gram_sweep16_chunk<NE, CH, true>(vptr, eptr, xs, k0, kq, Dp, acc, ae, ee);
-    if (k0 < Dp) gram_sweep16_chunk<NE, CH, false>(vptr, eptr, xs, k0, kq, Dp, acc, ae, ee);
+    for (; k0 + CH <= Dk; k0 += CH) gram_sweep16_chunk<NE, CH, true>(vptr, eptr, xs, k0, kq, Dk, acc, ae, ee);
+    if (k0 < Dk) gram_sweep16_chunk<NE, CH, false>(vptr, eptr, xs, k0, kq, Dk, acc, ae, ee);
     if (NE > 0) {
         // sum over the four feature slices
 #pragma unroll
@@ -1349,7 +1350,7 @@ __global__ __launch_bounds__(256, CHB_QP16_OCC) void hull_qp16_kernel(QpArgs a, 
             const int q = __shfl(qid, 16 * p, 64);
             if (!go) continue;   // wave-uniform
             f64x4 acc = {0.0, 0.0, 0.0, 0.0}, d0 = acc, d1 = acc;
-            gram_tile16<false>(a.X, a.Dp, q, id, -1, kq, acc, d0, d1);
+            gram_tile16<false>(a.X, a.Dp, (a.D + 7) & ~7, q, id, -1, kq, acc, d0, d1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sQ[w][p][kq + 4 * r][row] = acc[r];
         }
@@ -1397,6 +1398,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
     const int m = a.m;
+    const int Dk = (a.D + 7) & ~7;   // columns swept (the rows are padded to whole 128-byte lines beyond)
     // the two-tile form works on one pair at a time inside the sweep loop and borrows the wavefront's group arrays
     // (32 of the 80 entries each), which the groups only use after the loop
     double *sDw = &sGD[w][0][0];
@@ -1454,10 +1456,10 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
             if ((unsigned)idx >= (unsigned)a.n_samples) idx = -1;
         }
         double *xq = &sQ[w][grp][0][0];
-        const int Dp16 = (a.Dp + 15) & ~15;
+        const int Dp16 = (Dk + 15) & ~15;
         for (int e = 2 * l16; e < Dp16; e += 32)
             *reinterpret_cast<double2 *>(xq + e) =
-                e < a.Dp ? *reinterpret_cast<const double2 *>(a.X + (size_t)qid * a.Dp + e) : double2{0.0, 0.0};
+                e < Dk ? *reinterpret_cast<const double2 *>(a.X + (size_t)qid * a.Dp + e) : double2{0.0, 0.0};
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -1485,9 +1487,9 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
             double ae[kExtraMax], ee[kExtraNP];
             QP16_CLK(tp1);
             QP16_CLK_ACC(c_ids, tp1 - tp0);
-            if (ne == 0) gram_sweep16<0, CHB_SW0>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
-            else if (ne == 1) gram_sweep16<1, CHB_SW1>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
-            else gram_sweep16<2, CHB_SW2>(a.X, a.Dp, q, idA, ide, kq, Qp, aa, ae, ee);
+            if (ne == 0) gram_sweep16<0, CHB_SW0>(a.X, a.Dp, Dk, q, idA, ide, kq, Qp, aa, ae, ee);
+            else if (ne == 1) gram_sweep16<1, CHB_SW1>(a.X, a.Dp, Dk, q, idA, ide, kq, Qp, aa, ae, ee);
+            else gram_sweep16<2, CHB_SW2>(a.X, a.Dp, Dk, q, idA, ide, kq, Qp, aa, ae, ee);
             if (ne > 0) {
                 if (kq == 0) {
 #pragma unroll
@@ -1516,7 +1518,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
             idB = -1;
         }
         f64x4 aa = {0.0, 0.0, 0.0, 0.0}, ab = aa, bb = aa;
-        gram_tile16<true>(a.X, a.Dp, q, idA, idB, kq, aa, ab, bb);
+        gram_tile16<true>(a.X, a.Dp, Dk, q, idA, idB, kq, aa, ab, bb);
         // squared distances = the diagonals (lane (row, kq = row & 3) holds D[row][row] in acc[row >> 2])
         if ((row & 3) == kq) {
             const int rr = row >> 2;
