@@ -14,6 +14,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle_backend import oracle_fit_replay  # noqa: E402
 
 WORKER = r"""
 import os, sys
@@ -83,10 +85,8 @@ def test_sharded_cpp_loop_more_than_one_rank_one_gpu(world):
         X, initial, _ = chbin_amd.synth.make_synthetic(N, D, B, S=5 if D == 140 else 1, seed=seed, sigma=sigma, mix=mix,
                                                        n_seed=n_seed)
         perms = chbin_amd.synth.draw_permutations(initial, iters, seed=0)
-        want, its_o, _ = O.fit_cluster(X, B, initial, perms, m, iters)
-        labels = initial.copy()
-        for k in range(its_o):
-            labels, md = O.sweep(X, B, labels, perms[k], m)
+        # (one replay of the oracle's sweeps per case, shared by the world-2 and the world-3 run)
+        want, its_o, _, md = oracle_fit_replay(O, X, B, initial, perms, m, iters, key=("world", case))
         for r in range(world):
             assert int(outs[r][f"its{case}"]) == its_o
             assert np.array_equal(outs[r][f"lab{case}"], want)                       # every rank: the full result
