@@ -300,7 +300,7 @@ def main():
         Dz = 144 if D <= 144 else 160
         fused = ctx.counter("fused_enabled") == 1
         bytes_qp = 8.0 * (m * D + D / B + 1)      # no-reuse gather model per hull distance
-        x_mb = N * ((D + 7) // 8 * 8) * 8 / 1e6
+        x_mb = N * ((D + 15) // 16 * 16) * 8 / 1e6      # (rows of the resident matrix are padded to whole 128-byte lines)
         gather_peak = gather_ceiling_gbs(x_mb)
         gather_note = ("achieved = ALGORITHMIC bytes of SURVEY 8(d)'s no-reuse gather model (every candidate row counted as "
                        f"read from memory) / the measured launch time, peak = the 8 TB/s HBM spec.  The rows come out of a {x_mb:.0f} MB "

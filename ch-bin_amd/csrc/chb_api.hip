@@ -215,7 +215,7 @@ struct chb_ctx {
     DevBuf<int> cnt, bin_ptr, cursor, memb_id;
     DevBuf<int> cnt2, bin_ptr2, cursor2, memb2_id, memb2_code;
     DevBuf<int> perm;
-    PinBuf<int> pin_a, pin_b;   // host staging: labels in / permutation, labels out
+    PinBuf<int> pin_a, pin_b, pin_c;   // host staging: labels in, labels out, permutation
     // two-stage selection: fp16 shadow copies + shortlists (prefilter_kernels.hip)
     DevBuf<unsigned short> Gs, Zs;     // per sample: query-side row (global centre), member-side row (own bin)
     DevBuf<float> gq, ms;              // per sample: float2 {||qh||^2, rho}, float4 {bias, rho, ||zh||^2, amax}
@@ -422,7 +422,9 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     return CHB_OK;
 }
 
-int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
+// sync = false (chb_fit_cluster): the uploads and kernels of the fit's start are only enqueued -- the caller goes on with
+// its own host work (permutation check / conversion) while they run, and the stream orders everything behind them
+int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m, bool sync = true)
 {
     if (!h->X.p) return fail(CHB_ESTATE, "chb_set_samples has not been called");
     if (B <= 0) return fail(CHB_EINVAL, "num_clusters must be positive");
@@ -482,7 +484,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m)
         h->nsh = nsh;
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (sync) HIPCHK(hipStreamSynchronize(h->stream));
     h->fit_open = true; h->batch_open = false; h->Kcap = 0;
     h->overflow_total_valid = false;
     h->short_seen = 0;
@@ -1196,7 +1198,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         for (int64_t i = 0; i < tot; ++i) { lo = std::min(lo, perms[i]); hi = std::max(hi, perms[i]); }
         if (lo < 0 || hi >= h->N) return fail(CHB_EINVAL, "perm entry out of range");
     }
-    int rc = fit_begin_impl(h, B, initial_bins, m);
+    int rc = fit_begin_impl(h, B, initial_bins, m, /*sync=*/false);
     if (rc) return rc;
     struct FitCloser {   // an error return must not leave an open fit / batch behind
         chb_ctx *h; bool ok = false;
@@ -1220,9 +1222,9 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     h->stats_seg_batches = 0;
     h->stats_lookahead = 0;
 
-    // (fit_begin_impl left the converted initial labels in pin_a and has synchronised the stream)
-    std::vector<int> prev(h->pin_a.p, h->pin_a.p + N), cur;
-    cur.resize((size_t)N);
+    // (fit_begin_impl left the converted initial labels in pin_a; their upload and the kernels of the fit's start are
+    //  still running -- nothing below touches pin_a again before the sweep's final synchronisation)
+    std::vector<int> prev(h->pin_a.p, h->pin_a.p + N);
     std::vector<double> mind_host, mind2_host;
     if (min_dist_out) {
         for (int64_t i = 0; i < N; ++i) min_dist_out[i] = NAN;
@@ -1237,12 +1239,14 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     int64_t labelled = assigned0;
 
     int it = 0;
+    bool wrote_out = false;
     for (; it < max_iter; ++it) {
         const int64_t *perm = perms + (int64_t)it * n_move;
         HIPCHK(h->perm.ensure((size_t)std::max<int64_t>(n_move, 1)));
-        HIPCHK(h->pin_a.ensure((size_t)std::max<int64_t>(n_move, 1)));
+        HIPCHK(h->pin_c.ensure((size_t)std::max<int64_t>(n_move, 1)));
         if (n_move) {
-            HIPCHK(hipStreamSynchronize(s));   // (pin_a may still be the source of the previous upload)
+            // (pin_c, the permutations' own staging buffer: the previous sweep's upload from it completed before that
+            //  sweep's final synchronisation, and the first sweep's conversion overlaps the kernels of the fit's start)
             seen_bits.assign((size_t)(N + 63) / 64, 0);
             uint64_t dup = 0;
             for (int64_t i = 0; i < n_move; ++i) {
@@ -1251,10 +1255,10 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 const uint64_t bit = 1ull << (v & 63);
                 dup |= wd & bit;
                 wd |= bit;
-                h->pin_a.p[i] = (int)v;
+                h->pin_c.p[i] = (int)v;
             }
             if (dup) return fail(CHB_EINVAL, "a sweep's permutation lists a sample twice");
-            HIPCHK(hipMemcpyAsync(h->perm.p, h->pin_a.p, sizeof(int) * n_move, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(h->perm.p, h->pin_c.p, sizeof(int) * n_move, hipMemcpyHostToDevice, s));
         }
         // ---- the batches of this sweep.  A batch = start (selection against the members outside it), a
         // label guess, then rounds until the first changed position is past its end.  On one GPU the
@@ -1443,18 +1447,23 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         }
         int64_t diff = 0;  // algorithm.py:63
         labelled = 0;
-        for (int64_t i = 0; i < N; ++i) {
-            const int v = h->pin_b.p[i];
-            cur[(size_t)i] = v;
-            diff += prev[(size_t)i] != v;
-            labelled += v >= 0;
+        {   // (one pass: change count, label count and the caller's int64 copy -- the last sweep's is what stays)
+            const int *pb = h->pin_b.p;
+            const int *pv = prev.data();
+            for (int64_t i = 0; i < N; ++i) {
+                const int v = pb[i];
+                diff += pv[i] != v;
+                labelled += v >= 0;
+                labels_out[i] = v;
+            }
         }
+        wrote_out = true;
         if (changed_per_iter) changed_per_iter[it] = diff;
         if (diff == 0) { ++it; break; }  // algorithm.py:64-66
-        prev = cur;                       // algorithm.py:71-72
+        if (it + 1 < max_iter) prev.assign(h->pin_b.p, h->pin_b.p + N);   // algorithm.py:71-72
     }
-    if (it == 0) cur = prev;
-    for (int64_t i = 0; i < N; ++i) labels_out[i] = cur[(size_t)i];
+    if (!wrote_out)
+        for (int64_t i = 0; i < N; ++i) labels_out[i] = prev[(size_t)i];
     if (iters_run) *iters_run = it;
     fit_closer.ok = true;
     return CHB_OK;

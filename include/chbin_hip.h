@@ -161,8 +161,10 @@ int chb_comm_init_hook(chb_ctx *h, int rank, int world, chb_allgather_fn fn, voi
 /* chb_set_samples for every rank of the communicator with ONE crossing of the host boundary: rank `root` passes its host
  * matrix X[N][D] (cli/clustering.py:53), the other ranks pass NULL; the matrix is uploaded on `root`, broadcast to the
  * other GPUs by RCCL over xGMI (109 MB at N = 100k, 1.17 GB at N = 1M) and every rank builds its own resident copy and
- * shadow rows.  N and D must agree on all ranks.  Needs chb_comm_init (with the hook transport every rank simply calls
- * chb_set_samples). */
+ * shadow rows.  N, D and root must agree on all ranks: before the broadcast the ranks exchange {own status, N, D, root}
+ * (one small all-gather), and a rank that failed beforehand (no matrix on the root, an allocation) or disagrees makes the
+ * call fail on EVERY rank instead of leaving the others blocked in the collective.  Needs chb_comm_init (with the hook
+ * transport every rank simply calls chb_set_samples). */
 int chb_bcast_samples(chb_ctx *h, const double *X, int64_t N, int64_t D, int root);
 /* what the context's communicator really is: *rank / *world as given to chb_comm_init*, *comm_ranks = the rank count
  * RCCL itself reports for the communicator (ncclCommCount; 0 without an RCCL communicator), *transport = 0 none,
@@ -206,7 +208,12 @@ int chb_fit_stats(chb_ctx *h, int64_t *out4);
  * (batches of the last fit that cut a giant bin into segments), "batch_size" (speculative batch size of the last fit),
  * "tile_skip_state" (tile skipping of the last fit: 0 undecided, 1 kept on, -1 turned off because next to nothing could be
  * skipped), "tile_skipped" / "tile_seen" / "tile_unloaded" (wave-tiles whose compute was skipped / that were met / that
- * were never loaded, as sampled by about 64 workgroups of each base shortlist launch) */
+ * were never loaded, as sampled by about 64 workgroups of each base shortlist launch, a batch's launch counted once),
+ * "shortlist_short" ((position, bin) pairs of the last fit whose base shortlist reached the hull kernels with fewer than
+ * min(num_neighbors, members of the bin) candidates or with a wild index: always 0, or chb_fit_cluster has returned
+ * CHB_ESTATE at the end of that sweep -- the product build checks the shortlist stage's contract in every fused hull
+ * launch), "lookahead_batches" (batches of the last fit whose successor was enqueued ahead of their convergence verdict
+ * and kept: on one GPU and, since round 4, under the RCCL exchange) */
 int chb_counter(chb_ctx *h, const char *name, int64_t *out);
 
 #ifdef __cplusplus
