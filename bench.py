@@ -414,7 +414,7 @@ def main():
             cands = []
             if t.get("l2_read_bytes_per_launch"):
                 ach = t["l2_read_bytes_per_launch"] / secs / 1e9
-                c = {"resource": "L2 -> L1 row gather (vector-L1 read requests x 128 B / launch time)", "achieved": ach,
+                c = {"resource": "L2 -> CU reads (row gather / tile DMA: vector-L1 read requests x 128 B / launch time)", "achieved": ach,
                      "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": ach / L2_GATHER_PEAK_GBS,
                      "peak_source": "MI355X_MICROARCH.md: 16.8-18.8 TB/s for indexed rows of an L2-resident table",
                      "frac_of_l2_aggregate_34.5TBs": ach / L2_AGGREGATE_GBS,

@@ -241,6 +241,20 @@ struct chb_ctx {
     DevBuf<int> short_cnt;
     DevBuf<int> agree;   // chb_bcast_samples: {status, N, D, root} of every rank
     int dev_inject_batches = 0;   // developer builds: batch starts of this context so far (CHB_SL_INJECT_SHORT)
+    // the persistent base pack (prefilter_kernels.hip): the member pack kept across the batches of a fit
+    DevBuf<int> pp_start, pp_cap, pp_fill, pp_live, pp_nt, pp_memb, pp_row, pp_ctl, pp_ovf;
+    int pp_arena_rows = 0;
+    bool pp_allowed = true;    // CHB_PACK_INCR=0: every batch start rebuilds CSR and pack (the form up to round 3; A/B tests)
+    bool pp_fit = false;       // inside chb_fit_cluster (the stepwise entry points and chb_topm_per_bin always rebuild)
+    bool pp_valid = false;     // the pack on the device matches the labels
+    bool pp_batch = false;     // the open batch was started on it
+    bool pp_rebuild = false;   // much of the arena is used up: the next batch start outside a look-ahead window rebuilds
+    int64_t stats_pp_batches = 0, stats_pp_builds = 0;
+    chb::PackState pack_state()
+    {
+        return chb::PackState{pp_start.p, pp_cap.p, pp_fill.p, pp_live.p, pp_nt.p, pp_memb.p, pp_row.p, pp_ctl.p, pp_ovf.p,
+                              pp_arena_rows};
+    }
     int64_t short_seen = 0;
     // bins far larger than the rest are cut into segments for the shortlist stage (SegPlan, prefilter_kernels.hip): plan
     // buffers, and the bin sizes last seen by the host (they come home with the rounds' verdicts)
@@ -489,6 +503,35 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m, bool sy
     h->overflow_total_valid = false;
     h->short_seen = 0;
     if (h->short_cnt.p) HIPCHK(hipMemsetAsync(h->short_cnt.p, 0, sizeof(int), h->stream));
+    h->pp_valid = false; h->pp_batch = false; h->pp_rebuild = false;
+    if (h->pp_ctl.p) HIPCHK(hipMemsetAsync(h->pp_ctl.p, 0, 4 * sizeof(int), h->stream));
+    return CHB_OK;
+}
+
+// The persistent base pack from the labels as they stand (no batch open): compact CSR of all labelled samples, then
+// regions with room to grow.  Allocates on first use (8 N + 512 B rows: a commit's moves take at most 2 (N + K) rows, the
+// host rebuilds from 3 N on) -- hence only ever called outside a look-ahead window.
+int pack_state_build(chb_ctx *h)
+{
+    const size_t B = h->B;
+    const int arena = (int)std::min<int64_t>(8 * h->N + 512 * (int64_t)B, 0x7fffff00);
+    if (h->pp_arena_rows < arena || !h->pp_memb.p) {
+        HIPCHK(h->pk.ensure((size_t)arena, B, (size_t)h->Dz));
+        HIPCHK(h->pp_memb.ensure((size_t)arena + 64));
+        h->pp_arena_rows = arena;
+    }
+    HIPCHK(h->pp_row.ensure((size_t)h->N));
+    DevBuf<int> *pb[] = {&h->pp_start, &h->pp_cap, &h->pp_fill, &h->pp_live, &h->pp_nt};
+    for (auto *b : pb) HIPCHK(b->ensure(B + 1));
+    { const size_t had = h->pp_ctl.cap; HIPCHK(h->pp_ctl.ensure(4)); if (!had) HIPCHK(hipMemsetAsync(h->pp_ctl.p, 0, 4 * sizeof(int), h->stream)); }
+    HIPCHK(h->pp_ovf.ensure((size_t)std::max(h->Kcap, 1)));
+    launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p, h->memb_id.p, nullptr,
+                       nullptr, h->stream);
+    launch_pack_state_build(h->pack_state(), h->pk.view(), h->Zs.p, h->ms.p, h->D, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B,
+                            (int)h->N, h->stream);
+    HIPCHK(hipGetLastError());
+    h->pp_valid = true; h->pp_rebuild = false;
+    h->stats_pp_builds += 1;
     return CHB_OK;
 }
 
@@ -518,7 +561,24 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             sp.lists = h->seg_lists.p;
         }
     }
-    {
+    // the persistent base pack serves the fit loop's batches whenever the shortlist launch does not skip tiles (whose
+    // shell order needs the rebuild); built / rebuilt only outside a look-ahead window
+    bool pp_now = false;
+    if (h->pp_fit && h->pp_allowed && fusedp && pf_base_path && !skip_on) {
+        if ((!h->pp_valid || h->pp_rebuild) && g_gate.flag == nullptr) { const int r_ = pack_state_build(h); if (r_) return r_; }
+        pp_now = h->pp_valid;
+    }
+    if (!pp_now) h->pp_valid = false;   // (this batch's commit will not maintain the pack)
+    h->pp_batch = pp_now;
+    if (pp_now) {
+        // the batch is opened (its members' rows become holes), tiles per bin / statistics / segment plan written and the
+        // query norms computed: one launch instead of count + scan + fill + gather
+        Timed t(h, "bucket", (double)K);
+        launch_pack_state_start(h->pack_state(), h->pk.view(), h->D, h->Dz, h->labels.p, h->inb.p, h->bq_cur, K, h->lab_old.p,
+                                h->B, sp.gflag ? &sp : nullptr, h->fc_cur + 1, h->nflag.p, h->X.p, h->Dp, q_lo, q_hi, h->Kcap,
+                                h->centers.p, h->shadow_scale, h->qn.p, s);
+        h->stats_pp_batches += 1;
+    } else {
         // (the batch is opened -- labels remembered, members marked -- inside the CSR count's launch)
         Timed t(h, "bucket", (double)h->N);
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
@@ -530,6 +590,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
     TopmArgs a{};
     a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = q_lo; a.pos_end = q_hi;
     a.bin_ptr = h->bin_ptr.p; a.memb_id = h->memb_id.p; a.memb_code = nullptr;
+    if (pp_now) { a.bin_ptr = h->pp_start.p; a.bin_cnt = h->pp_fill.p; a.memb_id = h->pp_memb.p; }
     a.B = h->B; a.m = h->m; a.Kcap = h->Kcap;
     a.in = Lists{nullptr, nullptr, nullptr};
     a.out = h->L0();
@@ -539,7 +600,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         const int nq64 = (q_hi - q_lo + kQTile - 1) / kQTile;
         (void)nq64;   // (flags64 is all zero here: launch_topm_flagged clears what it serves)
         if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
-        {
+        if (!pp_now) {
             // the members' shadow rows (relative to their bin's centre) gathered into padded CSR order, the per-bin
             // bounds, and the batch's query-to-centre norms: one launch
             Timed t(h, "bucket", 0.0);
@@ -554,6 +615,10 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         pa.P = h->pk.view(); pa.Dz = h->Dz; pa.S = h->shadow_scale;
         pa.bq = h->bq_cur; pa.pos_begin = q_lo; pa.pos_end = q_hi;
         pa.bin_ptr = h->bin_ptr.p; pa.memb_id = h->memb_id.p; pa.update = false;
+        if (pp_now) {   // (a bin = its region: first row, tiles in use; a row's sample, -1 for a hole)
+            pa.P.pad_ptr = h->pp_start.p; pa.P.nt = h->pp_nt.p;
+            pa.bin_ptr = h->pp_start.p; pa.memb_id = h->pp_memb.p;
+        }
         pa.B = h->B; pa.m = h->m; pa.Kcap = h->Kcap;
         pa.cand = h->cand.p; pa.cand_cnt = h->cand_cnt.p; pa.cand_cap = kCandCap; pa.overflow = h->overflow.p;
         if (fusedp) pa.tau_out = h->tau.p;
@@ -609,12 +674,12 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
 #ifdef CHB_DEV_KNOBS
         // CHB_SL_INJECT_SHORT=<n>: the n-th batch start of a context hands the hull kernels one truncated shortlist
         // (tests: the product build's check must turn it into an error)
-        if (fusedp) if (const char *ev = getenv("CHB_SL_INJECT_SHORT")) {
+        if (fusedp && !pp_now) if (const char *ev = getenv("CHB_SL_INJECT_SHORT")) {
             if (++h->dev_inject_batches == atoi(ev)) launch_inject_short(h->cand_cnt.p, h->B, h->Kcap, q_lo, h->bin_ptr.p, h->m, s);
         }
 #endif
 #ifdef CHB_DEV_KNOBS
-        if (fusedp && getenv("CHB_SL_VALIDATE") != nullptr) {
+        if (fusedp && !pp_now && getenv("CHB_SL_VALIDATE") != nullptr) {   // (the validation kernel reads the rebuilt CSR)
             static int *verr = nullptr;
             if (verr == nullptr) HIPCHK(hipMalloc(&verr, 16 + 4 * 65536));
             HIPCHK(hipMemsetAsync(verr, 0, 16 + 4 * 65536, s));
@@ -704,6 +769,7 @@ int batch_round_dev(chb_ctx *h, int active)
             if (h->round_in_batch > 0) { f.candp = h->candu[cur ^ 1].p; f.candp_cnt = h->candu_cnt[cur ^ 1].p; }
             f.dist = h->dist.p; f.metric = h->metric; f.slow = h->slow.p; f.n_slow = h->n_slow.p;
             f.bin_ptr = h->bin_ptr.p; f.short_cnt = h->short_cnt.p;
+            if (h->pp_batch) f.bin_size = h->pp_live.p;
             {
                 Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
                 launch_hull_select_qp(f, s);
@@ -806,7 +872,12 @@ int batch_round_dev(chb_ctx *h, int active)
 int batch_commit_dev(chb_ctx *h, const int *final_dev)
 {
     hipStream_t s = h->stream;
-    if (h->pf_fit && h->centers.p)
+    if (h->pp_batch)
+        // ... and the rows put back into the persistent pack (in place, or appended to the new bin), then full regions moved
+        launch_pack_state_commit(h->pack_state(), h->pk.view(), h->X.p, h->D, h->Dp, h->bq_cur, h->K, h->labels.p, h->B,
+                                 h->centers.p, h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, final_dev, h->lab_old.p,
+                                 h->inb.p, s);
+    else if (h->pf_fit && h->centers.p)
         // final labels out, batch marks cleared, and the members' shadow rows recomputed against their
         // new bin's centre: one launch
         launch_sample_shadow(h->X.p, h->D, h->Dp, h->bq_cur, h->K, h->labels.p, h->B, h->centers.p, h->mu_g.p,
@@ -815,6 +886,7 @@ int batch_commit_dev(chb_ctx *h, const int *final_dev)
         launch_batch_close(h->labels.p, h->inb.p, h->bq_cur, final_dev, h->K, s);
     HIPCHK(hipGetLastError());
     h->batch_open = false;
+    h->pp_batch = false;
     return CHB_OK;
 }
 
@@ -864,6 +936,7 @@ int chb_create(int device_id, chb_ctx **out)
     if (const char *ev = getenv("CHB_SPECULATE")) h->speculate = atoi(ev) != 0;
     if (const char *ev = getenv("CHB_SEGMENTS")) h->allow_segments = atoi(ev) != 0;
     if (const char *ev = getenv("CHB_TILE_SKIP")) h->allow_skip = atoi(ev) != 0;
+    if (const char *ev = getenv("CHB_PACK_INCR")) h->pp_allowed = atoi(ev) != 0;
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
     return CHB_OK;
@@ -889,6 +962,8 @@ int chb_destroy(chb_ctx *h)
     h->active.release(); h->n_active.release(); h->act_blk.release();
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
     h->slow.release(); h->n_slow.release(); h->tau.release(); h->short_cnt.release(); h->agree.release();
+    h->pp_start.release(); h->pp_cap.release(); h->pp_fill.release(); h->pp_live.release(); h->pp_nt.release();
+    h->pp_memb.release(); h->pp_row.release(); h->pp_ctl.release(); h->pp_ovf.release();
     h->seg_nseg.release(); h->seg_gflag.release(); h->seg_items.release(); h->seg_lists.release();
     h->shell_inv.release(); h->ckey.release(); h->qord.release(); h->home.release();
     (void)hipStreamDestroy(h->stream);
@@ -1205,6 +1280,8 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         ~FitCloser() { if (!ok) { (void)hipStreamSynchronize(h->stream); h->fit_open = false; h->batch_open = false; } }
     } fit_closer{h};
     const int64_t N = h->N;
+    h->pp_fit = true; h->stats_pp_batches = 0; h->stats_pp_builds = 0;
+    struct PackOff { chb_ctx *h; ~PackOff() { h->pp_fit = false; h->pp_valid = false; } } pack_off{h};
     std::vector<uint64_t> seen_bits;
     // default batch: 8192 positions on one GPU, growing with sqrt(world): the batch-member
     // (update) work per rank is ~K^2/world, the per-rank grids ~K/world.  Twice that from 300k contigs to move: every
@@ -1303,7 +1380,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 // written them to lab_prev); a gated kernel, not a memcpy: inside a look-ahead window it must not run
                 launch_copy_i32(h->lab_prev.p + active, h->lab_new.p + active, g.K - active, s);
             }
-            HIPCHK(hipMemcpyAsync(h->fc_host + 8 * slot, h->fc_cur, 6 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(h->fc_host + 8 * slot, h->fc_cur, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(h->fc_event[slot], s));
             return CHB_OK;
         };
@@ -1313,6 +1390,8 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             // (bin sizes of that batch, for the segment decision of the batches still to be enqueued; and what the tile
             //  skipping of its shortlist launch achieved: a fit whose first batches skip next to nothing turns it off)
             h->hint_max_tiles = h->fc_host[8 * slot + 1]; h->hint_total_tiles = h->fc_host[8 * slot + 2];
+            // (the persistent pack's arena: rows handed out so far, as of that batch's start)
+            if (h->pp_valid && h->fc_host[8 * slot + 6] > 3 * h->N + 128 * (int64_t)h->B) h->pp_rebuild = true;
             // (the slot's statistics are written by the batch's one base shortlist launch: counted with the batch's first
             //  round only -- later rounds of the same batch bring the same three numbers home again)
             if (active == 0 && h->fc_host[8 * slot + 4] > 0) {
@@ -1348,11 +1427,11 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             return finish_round(g, 0, slot);
         };
         struct Snap {   // host-side batch state (the device side of a gated-off batch never changed)
-            int K, q_lo, q_hi, round_in_batch; bool lists_valid, batch_open; int *bq_cur, *fc_cur;
+            int K, q_lo, q_hi, round_in_batch; bool lists_valid, batch_open, pp_batch, pp_valid; int *bq_cur, *fc_cur;
             double hb, he; int64_t st[4]; size_t n_pending;
         };
         auto save = [&]() {
-            Snap v{h->K, h->q_lo, h->q_hi, h->round_in_batch, h->lists_valid, h->batch_open, h->bq_cur, h->fc_cur,
+            Snap v{h->K, h->q_lo, h->q_hi, h->round_in_batch, h->lists_valid, h->batch_open, h->pp_batch, h->pp_valid, h->bq_cur, h->fc_cur,
                    h->hint_base_members, h->hint_batch_entries, {0, 0, 0, 0}, h->pending.size()};
             memcpy(v.st, h->stats, sizeof(v.st));
             return v;
@@ -1360,6 +1439,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         auto restore = [&](const Snap &v) {
             h->K = v.K; h->q_lo = v.q_lo; h->q_hi = v.q_hi; h->round_in_batch = v.round_in_batch;
             h->lists_valid = v.lists_valid; h->batch_open = v.batch_open; h->bq_cur = v.bq_cur; h->fc_cur = v.fc_cur;
+            h->pp_batch = v.pp_batch; h->pp_valid = v.pp_valid;
             h->hint_base_members = v.hb; h->hint_batch_entries = v.he;
             memcpy(h->stats, v.st, sizeof(v.st));
             // the launches recorded inside the window were gated off (they returned at once): they are neither
@@ -1380,7 +1460,11 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             const int K = g.K;
             if (!inflight) { rc = open_batch(g, slot); if (rc) return rc; }
             const int64_t t1 = t0 + K;
-            const bool spec = spec_ok && t1 < n_move;
+            // (a batch start that has to build or rebuild the persistent pack stays outside the look-ahead window)
+            const bool skip_would = h->allow_skip && h->nsh > 1 && h->skip_state >= 0 && h->ckey.p != nullptr;
+            const bool pack_sync = h->pp_allowed && h->fused && h->pf_base && h->cand.p && !skip_would &&
+                                   (!h->pp_valid || h->pp_rebuild);
+            const bool spec = spec_ok && t1 < n_move && !pack_sync;
             Snap snap{};
             if (spec) {
                 snap = save();
@@ -1439,7 +1523,12 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         HIPCHK(hipMemcpyAsync(h->pin_b.p, h->labels.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));
         if (h->fused && h->short_cnt.p)   // (fc_host[7]: the spare word of the first verdict slot)
             HIPCHK(hipMemcpyAsync(h->fc_host + 7, h->short_cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        h->fc_host[15] = 0;
+        if (h->pp_ctl.p)   // (fc_host[15]: the spare word of the second slot -- the persistent pack's error flag)
+            HIPCHK(hipMemcpyAsync(h->fc_host + 15, h->pp_ctl.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (h->fc_host[15] != 0)
+            return fail(CHB_ESTATE, "internal error: the persistent member pack ran out of rows; labels not returned");
         if (h->fused && h->short_cnt.p && h->fc_host[7] != 0) {
             h->short_seen = h->fc_host[7];
             return fail(CHB_ESTATE, "internal error: " + std::to_string(h->fc_host[7]) + " (position, bin) shortlists of this sweep came "
@@ -1824,6 +1913,8 @@ int chb_counter(chb_ctx *h, const char *name, int64_t *out)
         return CHB_OK;
     }
     if (!strcmp(name, "lookahead_batches")) { *out = h->stats_lookahead; return CHB_OK; }
+    if (!strcmp(name, "pack_incremental_batches")) { *out = h->stats_pp_batches; return CHB_OK; }
+    if (!strcmp(name, "pack_builds")) { *out = h->stats_pp_builds; return CHB_OK; }
     if (!strcmp(name, "shortlist_short")) {   // pairs of the last fit that broke the shortlist stage's contract (0, or the fit failed)
         if (h->short_cnt.p) {
             int v = 0;

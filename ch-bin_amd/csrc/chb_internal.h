@@ -37,7 +37,8 @@ struct TopmArgs {
     const int *bq;       // [K] sample index of each batch position
     int pos_begin, pos_end;
     const int *bin_ptr;  // [B+1] CSR over member entries
-    const int *memb_id;  // sample index of each entry
+    const int *memb_id;  // sample index of each entry (negative: no member -- a hole of the persistent base pack)
+    const int *bin_cnt = nullptr;   // optional [B]: entries of each bin (nullptr: bin_ptr[c + 1] - bin_ptr[c])
     const int *memb_code;  // nullptr: always eligible. code>0: eligible iff query pos > code-1,
                            // -(1<<30) < code < 0: eligible iff query pos < -code-1,
                            // code <= -(1<<30): eligible iff query pos != -(1<<30)-code
@@ -76,6 +77,9 @@ struct MemberPack {
     int *pad_ptr;             // [B+1] first row of each bin (multiples of 32)
     float4 *bb;               // [B] {largest rho, largest ||zh||, largest amax, largest residual of the bias pieces}
                               // (the batch-entry pack accumulates the largest ||zh||^2 in .y; its .w is unused)
+    const int *nt = nullptr;  // optional [B]: tiles of each bin (nullptr: (pad_ptr[c + 1] - pad_ptr[c]) / 32).  The persistent
+                              // base pack keeps every bin in a region of its own with room to grow: pad_ptr[c] = the region's
+                              // first row, nt[c] = the tiles in use
 };
 int shortlist_list_len(int m);  // entries per (query, segment) list of SegPlan::lists for num_neighbors = m
 int shadow_row_elems(int D);   // Dz: 144 or 160, at least three spare columns (0: D too large for the shortlist stage)
@@ -161,6 +165,37 @@ struct ShortlistArgs {
     float gamma;         // accumulation error factor g (set by launch_shortlist)
     int tile_best_min;   // bins with at least this many tiles learn tau from per-tile bests (ditto)
 };
+// ---- the persistent base pack (prefilter_kernels.hip, "persistent base pack"): the member pack of the shortlist stage
+// kept across the batches of a fit instead of being rebuilt from the labels at every batch start
+struct PackState {
+    int *start;    // [B] first row of each bin's region (multiple of 32)
+    int *cap;      // [B] rows of the region (multiple of 32)
+    int *fill;     // [B] rows in use (members and holes); the rest of the region is padding
+    int *live;     // [B] members (rows in use minus holes)
+    int *nt;       // [B] tiles in use, ceil(fill / 32): written at every batch start
+    int *memb;     // [arena rows] sample of each row, -1: hole / padding
+    int *row;      // [N] row of each sample, -1: not in the pack
+    int *ctl;      // [4] {rows of the arena handed out, overflowed appends of the commit in flight, error flag, -}
+    int *ovf;      // [K] batch positions whose append found its bin's region full (served by the fix kernel)
+    int arena_rows;
+};
+// from the compact CSR of all labelled samples (launch_bucket_base without shells): regions with room to grow, rows,
+// bounds; every sample's row; the arena's fill mark
+void launch_pack_state_build(const PackState &ps, const MemberPack &P, const unsigned short *Zs, const void *ms, int D, int Dz,
+                             const int *memb_id, const int *bin_ptr, int B, int N, hipStream_t s);
+// batch start: the batch is opened (labels remembered, members marked, their rows turned into holes), the tiles per bin,
+// bin-size statistics and segment plan are written, and the batch's query norms computed: one launch
+void launch_pack_state_start(const PackState &ps, const MemberPack &P, int D, int Dz, const int *labels, int *inb,
+                             const int *open_bq, int open_K, int *open_lab_old, int B, const SegPlan *seg, int *stats,
+                             int *zero_me, const double *X, int Dp, int pos_begin, int pos_end, int Kcap,
+                             const double *centers, double S, void *qn, hipStream_t s);
+// batch commit: launch_sample_shadow's commit form, which also puts every committed sample's row back into the pack (in
+// place when its label is the one it was removed under, else appended to its new bin), then the regions that ran full are
+// moved to larger ones
+void launch_pack_state_commit(const PackState &ps, const MemberPack &P, const double *X, int D, int Dp, const int *ids, int n,
+                              int *labels, int B, const double *centers, const double *mu_g, double S, unsigned short *Zs,
+                              int Dz, void *ms, const int *new_lab, const int *lab_old, int *inb, hipStream_t s);
+
 // flags64[bin][ceil(nq/64)] (pre-zeroed): set for (query tile of 64, bin) pairs whose shortlist overflowed
 // (and listed once in a.flaglist)
 void launch_shortlist(const ShortlistArgs &a, int *flags64, hipStream_t s);
@@ -229,6 +264,7 @@ struct FusedArgs {
     // min(m, members of the bin outside the batch) candidates, all of them sample indices.  bin_ptr = the base CSR;
     // *short_cnt counts the pairs that violate it (the host turns a non-zero count into an error at the sweep's end)
     const int *bin_ptr = nullptr;
+    const int *bin_size = nullptr;   // (instead of bin_ptr: the members of each bin, [B] -- the persistent base pack's live counts)
     int *short_cnt = nullptr;
 };
 // false: not supported by the fused kernels (caller uses the list-based path): m <= 16, padded rows of at most

@@ -198,8 +198,9 @@ __global__ __launch_bounds__(256) void bin_center_kernel(const double *X, int D,
 // receives | -bias / 2 - (h1 + h2 + h3) 2^kBiasExp |, rounded up.  Without: those columns stay zero.
 __device__ __forceinline__ float4 member_shadow_row(const double *x, const double *mu, const double *mu_g,
                                                     double S, int D, int Dz, int lane, unsigned short *zrow,
-                                                    bool bias_cols = false, float *resid = nullptr)
-{
+                                                    bool bias_cols = false, float *resid = nullptr,
+                                                    unsigned short *zrow2 = nullptr)
+{   // (zrow2: a second copy of the row -- the persistent base pack's)
     double n2 = 0.0, e2 = 0.0, sp = 0.0;
     for (int k = lane; k < Dz; k += 64) {
         unsigned short hb = 0;
@@ -212,6 +213,7 @@ __device__ __forceinline__ float4 member_shadow_row(const double *x, const doubl
             sp += ((mu[k] - mu_g[k]) * S) * zh;
         }
         zrow[k] = hb;
+        if (zrow2 != nullptr) zrow2[k] = hb;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -225,7 +227,10 @@ __device__ __forceinline__ float4 member_shadow_row(const double *x, const doubl
         const unsigned short h1 = f16_shadow(v, b1);
         const unsigned short h2 = f16_shadow(v - b1, b2);
         const unsigned short h3 = f16_shadow(v - b1 - b2, b3);
-        if (lane == 0) { zrow[D] = h1; zrow[D + 1] = h2; zrow[D + 2] = h3; }
+        if (lane == 0) {
+            zrow[D] = h1; zrow[D + 1] = h2; zrow[D + 2] = h3;
+            if (zrow2 != nullptr) { zrow2[D] = h1; zrow2[D + 1] = h2; zrow2[D + 2] = h3; }
+        }
         if (resid != nullptr)
             *resid = round_up_f32(fabs(v - b1 - b2 - b3) * (double)(1 << kBiasExp) * (1.0 + 1e-12) + 1e-300);
     }
@@ -625,6 +630,321 @@ __global__ __launch_bounds__(256) void pack_build_kernel(const unsigned short *Z
     else query_norms_tile(q, (b - npack - B) % nqx, (b - npack - B) / nqx);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// the persistent base pack
+//
+// algorithm.py:50,60 removes ONE contig from its bin and puts it back.  Up to round 3 every batch start rebuilt the CSR
+// and the padded member pack of ALL labelled contigs (count / scan / fill over N labels, then a gather of every shadow
+// row: 29 MB at 100k x 136, four launches).  Here the pack lives across the batches of a fit (when the shortlist launch
+// does not skip tiles: the shell order of the tile-skipping builds needs the rebuild):
+//   * every bin owns a REGION of the row arena with room to grow (capacity a multiple of 32 rows; rows past `fill` are
+//     padding rows, i.e. never selectable);
+//   * a batch start turns the rows of the batch's own members into HOLES (first bias piece = fp16 -inf, the padding rows'
+//     encoding; sample -1) -- they are not base members while the batch is open;
+//   * a commit writes every member's row back: in place when its label is the one it was removed under (the usual case
+//     from sweep 2 on), else appended to its new bin's region; a region that runs full is moved to one twice as large
+//     (holes squeezed out) by the fix kernel that follows every commit;
+//   * per-tile and per-bin bounds only grow between two builds (valid, at worst looser);
+//   * the arena's fill mark rides home with the batch's verdict; the host rebuilds the pack from the labels (compaction)
+//     when half of the arena is gone, and at every fit start.
+// The order of a bin's rows depends on the order of the appends (atomics) -- as the rebuild's fill already did; the
+// selection is exact whatever the order.
+constexpr unsigned short kF16NegInf = 0xFC00u;
+
+__device__ __forceinline__ void atomic_max_nonneg(float *p, float v)   // (non-negative floats: their bits order like ints)
+{
+    if (v > *p) atomicMax(reinterpret_cast<int *>(p), __float_as_int(v));
+}
+__device__ __forceinline__ void pack_padding_row(unsigned short *zrow, int D, int Dz, int l16)
+{
+    const int cpr = Dz >> 3;
+    for (int cc = l16; cc < cpr; cc += 16) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (cc == (D >> 3)) {
+            const unsigned hw = (unsigned)kF16NegInf << (16 * (D & 1));
+            const int wd = (D & 7) >> 1;
+            if (wd == 0) v.x = hw; else if (wd == 1) v.y = hw; else if (wd == 2) v.z = hw; else v.w = hw;
+        }
+        *reinterpret_cast<uint4 *>(zrow + cc * 8) = v;
+    }
+}
+
+// regions from the compact CSR: capacity = twice the bin's members (at least 64 rows); one block
+__global__ __launch_bounds__(256) void pack_state_layout_kernel(PackState ps, const int *bin_ptr, int B)
+{
+    __shared__ int part[257];
+    const int per = (B + 255) / 256;
+    const int b0 = min(B, (int)threadIdx.x * per), b1 = min(B, b0 + per);
+    auto cap_of = [&](int b) { const int c = bin_ptr[b + 1] - bin_ptr[b]; return (max(2 * c, 64) + 31) / 32 * 32; };
+    int sp = 0;
+    for (int b = b0; b < b1; ++b) sp += cap_of(b);
+    part[threadIdx.x] = sp;
+    __syncthreads();
+    if (threadIdx.x == 0) {   // (256 partial sums, once per build)
+        int run = 0;
+        for (int t = 0; t < 256; ++t) { const int v = part[t]; part[t] = run; run += v; }
+        part[256] = run;
+        ps.ctl[0] = run; ps.ctl[1] = 0;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int b = b0; b < b1; ++b) {
+        const int c = bin_ptr[b + 1] - bin_ptr[b];
+        ps.start[b] = run; ps.cap[b] = cap_of(b); ps.fill[b] = c; ps.live[b] = c; ps.nt[b] = (c + 31) / 32;
+        run += cap_of(b);
+    }
+}
+
+// blocks [0, ngather): rows of the regions (members from the CSR, then padding); blocks [ngather, ngather + B): bounds
+__global__ __launch_bounds__(256) void pack_state_build_kernel(PackState ps, MemberPack P, const unsigned short *Zs,
+                                                               const float4 *ms, int D, int Dz, const int *memb_id,
+                                                               const int *bin_ptr, int B, int ngather)
+{
+    const int b = blockIdx.x;
+    if (b >= ngather) {
+        const int c = b - ngather;
+        bin_bounds_from_source(ms, memb_id, bin_ptr, c, P.bb, P.tsn, ps.start[c], false);
+        // the tiles of the region past the members: no norm yet
+        const int t0 = ps.start[c] / 32 + (bin_ptr[c + 1] - bin_ptr[c] + 31) / 32, t1 = (ps.start[c] + ps.cap[c]) / 32;
+        for (int t = t0 + (int)threadIdx.x; t < t1; t += 256) P.tsn[t] = 0.f;
+        return;
+    }
+    const int total = ps.ctl[0];
+    const int cpr = Dz >> 3, l16 = threadIdx.x & 15;
+    for (int r = b * 16 + (int)(threadIdx.x >> 4); r < total; r += ngather * 16) {
+        const int c = bin_of_row(ps.start, B, r);   // (start ascending; the last region ends at `total`)
+        const int e = r - ps.start[c];
+        const bool real = e < bin_ptr[c + 1] - bin_ptr[c];
+        if (real) {
+            const int id = memb_id[bin_ptr[c] + e];
+            for (int cc = l16; cc < cpr; cc += 16)
+                *reinterpret_cast<uint4 *>(P.Z + (size_t)r * Dz + cc * 8) =
+                    *reinterpret_cast<const uint4 *>(Zs + (size_t)id * Dz + cc * 8);
+            if (l16 == 0) { ps.memb[r] = id; ps.row[id] = r; }
+        } else {
+            pack_padding_row(P.Z + (size_t)r * Dz, D, Dz, l16);
+            if (l16 == 0) ps.memb[r] = -1;
+        }
+    }
+}
+
+// batch start in one launch: block 0 = the plan (tiles per bin, statistics, segment plan: what scan_kernel does for the
+// rebuilt pack), blocks [1, 1 + nopen) open the batch, the rest are the query-norm tiles
+__global__ __launch_bounds__(256) void pack_state_start_kernel(PackState ps, MemberPack P, int D, int Dz, const int *labels,
+                                                               int *inb, const int *bq, int K, int *lab_old, int B,
+                                                               SegPlan seg, int *stats, int *zero_me, int nopen, QnArgs q,
+                                                               int nqx, Gate gate)
+{
+    CHB_GATE(gate);
+    const int b = blockIdx.x;
+    if (b == 0) {
+        __shared__ int s_max, s_tot, s_ng, s_ni;
+        if (threadIdx.x == 0) { s_max = 0; s_tot = 0; s_ng = 0; s_ni = 0; ps.ctl[1] = 0; if (zero_me != nullptr) *zero_me = 0; }
+        __syncthreads();
+        int loc_tot = 0, loc_max = 0;
+        for (int c = threadIdx.x; c < B; c += 256) {
+            const int nt = (ps.fill[c] + 31) / 32;
+            ps.nt[c] = nt;
+            loc_tot += nt; loc_max = max(loc_max, nt);
+        }
+        atomicAdd(&s_tot, loc_tot); atomicMax(&s_max, loc_max);
+        __syncthreads();
+        const long long tot_tiles = s_tot;
+        if (seg.gflag != nullptr)
+            for (int c = threadIdx.x; c < B; c += 256) {
+                const int ntile = (ps.fill[c] + 31) / 32;
+                int g = -1;
+                if (seg.launch && ntile > kSegMinTiles && (long long)ntile * B > 4 * tot_tiles) {
+                    const int len = max(kSegLenTiles, (ntile + 15) / 16);
+                    const int ns = (ntile + len - 1) / len;
+                    g = atomicAdd(&s_ng, 1);
+                    if (g < seg.gcap) {
+                        const int i0 = atomicAdd(&s_ni, ns);
+                        for (int sgi = 0; sgi < ns; ++sgi)
+                            seg.items[i0 + sgi] = make_int4(c, sgi * len, min(ntile, (sgi + 1) * len),
+                                                            (g << 8) | (sgi << 4) | (ns - 1));
+                    } else {
+                        g = -1;
+                    }
+                }
+                seg.gflag[c] = g;
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (seg.gflag != nullptr && seg.nseg != nullptr) *seg.nseg = s_ni;
+            if (stats != nullptr) { stats[0] = s_max; stats[1] = s_tot; stats[2] = 0; stats[3] = 0; stats[4] = 0; stats[5] = ps.ctl[0]; }
+        }
+        return;
+    }
+    if (b < 1 + nopen) {
+        const int i = (b - 1) * 256 + (int)threadIdx.x;
+        if (i >= K) return;
+        const int p = bq[i];
+        const int l = labels[p];
+        lab_old[i] = l;
+        inb[p] = i;
+        if (l >= 0 && l < B) {
+            const int r = ps.row[p];
+            if (r >= 0) {
+                P.Z[(size_t)r * Dz + D] = kF16NegInf;   // a hole: never selectable while the batch is open
+                ps.memb[r] = -1;
+                atomicSub(&ps.live[l], 1);
+            }
+        }
+        return;
+    }
+    query_norms_tile(q, (b - 1 - nopen) % nqx, (b - 1 - nopen) / nqx);
+}
+
+// batch commit: sample_shadow_kernel's commit form + the member's row back into the pack
+__global__ __launch_bounds__(256) void pack_state_commit_kernel(PackState ps, MemberPack P, const double *X, int D, int Dp,
+                                                                const int *ids, int n, int *labels, int B,
+                                                                const double *centers, const double *mu_g, double S,
+                                                                unsigned short *Zs, int Dz, float4 *ms, const int *new_lab,
+                                                                const int *lab_old, int *inb, Gate gate)
+{
+    CHB_GATE(gate);
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int p = ids[i];
+    const int c = new_lab[i];
+    if (lane == 0) { labels[p] = c; inb[p] = -1; }
+    if (c < 0 || c >= B) {
+        if (lane == 0) ps.row[p] = -1;   // (its old row, if any, stays a hole)
+        return;
+    }
+    // where the row goes (lane 0 decides; -1: the bin's region is full -- the fix kernel appends it to the new one)
+    int dest = -1, fresh = 0;
+    if (lane == 0) {
+        const int r0 = ps.row[p];
+        if (lab_old[i] == c && r0 >= 0) {
+            dest = r0;
+        } else {
+            const int slot = atomicAdd(&ps.fill[c], 1);
+            if (slot < ps.cap[c]) { dest = ps.start[c] + slot; fresh = 1; }
+            else ps.ovf[atomicAdd(&ps.ctl[1], 1)] = i;
+        }
+    }
+    dest = __shfl(dest, 0, 64); fresh = __shfl(fresh, 0, 64);
+    float resid = 0.f;
+    float4 o = member_shadow_row(X + (size_t)p * Dp, centers + (size_t)c * Dp, mu_g, S, D, Dz, lane,
+                                 Zs + (size_t)p * Dz, true, &resid, dest >= 0 ? P.Z + (size_t)dest * Dz : nullptr);
+    o.x = resid;
+    if (lane == 0) {
+        ms[p] = o;
+        if (dest >= 0) {
+            ps.memb[dest] = p; ps.row[p] = dest;
+            atomicAdd(&ps.live[c], 1);
+            if (fresh) {
+                // a new row of the bin: its tile's and its bin's bounds (bin_bounds_from_source's quantities) can only grow
+                atomic_max_nonneg(&P.tsn[dest >> 5], sqrtf(o.z) * (1.0f + 2e-6f));
+                float *bb = reinterpret_cast<float *>(&P.bb[c]);
+                atomic_max_nonneg(bb + 0, o.y);
+                atomic_max_nonneg(bb + 1, sqrtf(o.z) * (1.0f + 2e-6f));
+                atomic_max_nonneg(bb + 2, o.w);
+                atomic_max_nonneg(bb + 3, o.x);
+            }
+        }
+    }
+}
+
+// behind every commit, one block per bin: a bin whose region ran full (fill > cap: the commit's appends past the
+// capacity are on the overflow list) moves to a region of twice its size -- members squeezed together, the overflowed
+// samples appended, the rest padding.  Exits at once for every other bin.
+__global__ __launch_bounds__(256) void pack_state_fix_kernel(PackState ps, MemberPack P, const unsigned short *Zs,
+                                                             const float4 *ms, int D, int Dz, const int *ids,
+                                                             const int *new_lab, Gate gate)
+{
+    CHB_GATE(gate);
+    const int c = blockIdx.x;
+    const int cap = ps.cap[c];
+    if (ps.fill[c] <= cap) return;
+    __shared__ int s_new, s_cnt, s_src[256];
+    const int nov = ps.ctl[1];
+    const int old = ps.start[c];
+    const int tid = threadIdx.x, l16 = tid & 15, cpr = Dz >> 3;
+    if (tid == 0) {
+        const int want = ps.live[c] + (ps.fill[c] - cap);
+        const int ncap = (2 * want + 64 + 31) / 32 * 32;
+        int st = atomicAdd(&ps.ctl[0], ncap);
+        if (st + ncap > ps.arena_rows) { ps.ctl[2] = 1; st = -1; }   // (the host sizes the arena so that this cannot happen)
+        s_new = st; s_cnt = 0;
+        if (st >= 0) ps.cap[c] = ncap;
+    }
+    __syncthreads();
+    const int nst = s_new;
+    if (nst < 0) { if (tid == 0) ps.fill[c] = cap; return; }
+    const int ncap = ps.cap[c];
+    // members of the old region, in row order, 256 rows at a time
+    for (int r0 = 0; r0 < cap; r0 += 256) {
+        const int r = r0 + tid;
+        const int id = r < cap ? ps.memb[old + r] : -1;
+        const unsigned long long bal = __ballot(id >= 0);
+        __shared__ int s_wave[4];
+        if ((tid & 63) == 0) s_wave[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        int before = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        for (int w = 0; w < (tid >> 6); ++w) before += s_wave[w];
+        const int chunk = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        const int base = s_cnt;
+        if (id >= 0) s_src[before] = old + r;
+        __syncthreads();
+        for (int j = tid >> 4; j < chunk; j += 16) {
+            const int src = s_src[j], dst = nst + base + j;
+            for (int cc = l16; cc < cpr; cc += 16)
+                *reinterpret_cast<uint4 *>(P.Z + (size_t)dst * Dz + cc * 8) =
+                    *reinterpret_cast<const uint4 *>(P.Z + (size_t)src * Dz + cc * 8);
+            if (l16 == 0) { const int sid = ps.memb[src]; ps.memb[dst] = sid; ps.row[sid] = dst; }
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt = base + chunk;
+        __syncthreads();
+    }
+    // the commit's overflowed appends of this bin
+    for (int k0 = 0; k0 < nov; k0 += 256) {
+        const int k = k0 + tid;
+        int i = -1;
+        if (k < nov) { i = ps.ovf[k]; if (new_lab[i] != c) i = -1; }
+        const unsigned long long bal = __ballot(i >= 0);
+        __shared__ int s_wave2[4];
+        if ((tid & 63) == 0) s_wave2[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        int before = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        for (int w = 0; w < (tid >> 6); ++w) before += s_wave2[w];
+        const int chunk = s_wave2[0] + s_wave2[1] + s_wave2[2] + s_wave2[3];
+        const int base = s_cnt;
+        if (i >= 0) s_src[before] = ids[i];
+        __syncthreads();
+        for (int j = tid >> 4; j < chunk; j += 16) {
+            const int sid = s_src[j], dst = nst + base + j;
+            for (int cc = l16; cc < cpr; cc += 16)
+                *reinterpret_cast<uint4 *>(P.Z + (size_t)dst * Dz + cc * 8) =
+                    *reinterpret_cast<const uint4 *>(Zs + (size_t)sid * Dz + cc * 8);
+            if (l16 == 0) { ps.memb[dst] = sid; ps.row[sid] = dst; }
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt = base + chunk;
+        __syncthreads();
+    }
+    const int cnt = s_cnt;
+    for (int r = cnt + (tid >> 4); r < ncap; r += 16) {
+        pack_padding_row(P.Z + (size_t)(nst + r) * Dz, D, Dz, l16);
+        if (l16 == 0) ps.memb[nst + r] = -1;
+    }
+    // the new tiles' norms from the members' own records (a tile = 32 rows = half a wavefront)
+    for (int r0 = 0; r0 < ncap; r0 += 256) {
+        const int r = r0 + tid;
+        float tn = 0.f;
+        if (r < cnt) tn = ms[ps.memb[nst + r]].z;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) tn = fmaxf(tn, __shfl_xor(tn, off, 64));
+        if ((tid & 31) == 0 && r < ncap) P.tsn[(nst + r) >> 5] = sqrtf(tn) * (1.0f + 2e-6f);
+    }
+    if (tid == 0) { ps.start[c] = nst; ps.fill[c] = cnt; ps.live[c] = cnt; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // the shortlist kernel
 //
@@ -855,7 +1175,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
         ivalid = false;                                                                            \
         while (ic < c1) {                                                                          \
             irow0 = a.P.pad_ptr[ic];                                                               \
-            int_ = (a.P.pad_ptr[ic + 1] - irow0) / kPfP;                                           \
+            int_ = a.P.nt != nullptr ? a.P.nt[ic] : (a.P.pad_ptr[ic + 1] - irow0) / kPfP;          \
             if (SEG == 0 && !UPD && a.seg.gflag != nullptr && a.seg.gflag[ic] >= 0) int_ = 0;     \
             if (SEG != 0) { irow0 += seg_tb * kPfP; int_ = min(int_, seg_te) - seg_tb; }           \
             if (int_ > 0) { ivalid = true; break; }                                                \
@@ -948,7 +1268,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     int wt_seen = 0, wt_skipped = 0, wt_unloaded = 0;   // tiles this wavefront met / skipped / found not loaded (statistics)
     for (int c = c0; c < c1; ++c) {
         const int row0 = a.P.pad_ptr[c];
-        int ntile = (a.P.pad_ptr[c + 1] - row0) / kPfP;
+        int ntile = a.P.nt != nullptr ? a.P.nt[c] : (a.P.pad_ptr[c + 1] - row0) / kPfP;
         if (SEG == 0 && !UPD && a.seg.gflag != nullptr && a.seg.gflag[c] >= 0) continue;   // the segment launches' bin
         if (SEG != 0) ntile = min(ntile, seg_te) - seg_tb;
         bool seg_over = false;   // SEG = 2: a reservation went past the shortlist's capacity
@@ -1546,6 +1866,44 @@ void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const i
     hipLaunchKernelGGL(pack_build_kernel, dim3(npack + B + nqx * nqy), dim3(256), 0, s, Zs,
                        reinterpret_cast<const float4 *>(ms), Dz, memb_id, bin_ptr, P.pad_ptr, B, P, npack, q,
                        std::max(nqx, 1), g_gate);
+}
+
+void launch_pack_state_build(const PackState &ps, const MemberPack &P, const unsigned short *Zs, const void *ms, int D, int Dz,
+                             const int *memb_id, const int *bin_ptr, int B, int N, hipStream_t s)
+{
+    if (B <= 0) return;
+    launch_fill_i32(ps.row, -1, N, s);
+    hipLaunchKernelGGL(pack_state_layout_kernel, dim3(1), dim3(256), 0, s, ps, bin_ptr, B);
+    const long long rows = 2LL * N + 64LL * B;
+    const int ngather = (int)std::max<long long>(1, std::min<long long>((rows + 15) / 16, 16384));
+    hipLaunchKernelGGL(pack_state_build_kernel, dim3(ngather + B), dim3(256), 0, s, ps, P, Zs,
+                       reinterpret_cast<const float4 *>(ms), D, Dz, memb_id, bin_ptr, B, ngather);
+}
+
+void launch_pack_state_start(const PackState &ps, const MemberPack &P, int D, int Dz, const int *labels, int *inb,
+                             const int *open_bq, int open_K, int *open_lab_old, int B, const SegPlan *seg, int *stats,
+                             int *zero_me, const double *X, int Dp, int pos_begin, int pos_end, int Kcap,
+                             const double *centers, double S, void *qn, hipStream_t s)
+{
+    if (B <= 0) return;
+    const int nopen = (open_K + 255) / 256;
+    const int nq = pos_end - pos_begin;
+    const int nqx = nq > 0 ? (nq + 31) / 32 : 0, nqy = (B + 63) / 64;
+    const QnArgs q{X, D, Dp, open_bq, pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn), nullptr};
+    hipLaunchKernelGGL(pack_state_start_kernel, dim3(1 + nopen + nqx * nqy), dim3(256), 0, s, ps, P, D, Dz, labels, inb,
+                       open_bq, open_K, open_lab_old, B, seg ? *seg : SegPlan{}, stats, zero_me, nopen, q, std::max(nqx, 1),
+                       g_gate);
+}
+
+void launch_pack_state_commit(const PackState &ps, const MemberPack &P, const double *X, int D, int Dp, const int *ids, int n,
+                              int *labels, int B, const double *centers, const double *mu_g, double S, unsigned short *Zs,
+                              int Dz, void *ms, const int *new_lab, const int *lab_old, int *inb, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(pack_state_commit_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ps, P, X, D, Dp, ids, n, labels, B,
+                       centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms), new_lab, lab_old, inb, g_gate);
+    hipLaunchKernelGGL(pack_state_fix_kernel, dim3(B), dim3(256), 0, s, ps, P, Zs, reinterpret_cast<const float4 *>(ms), D, Dz,
+                       ids, new_lab, g_gate);
 }
 
 void launch_shortlist(const ShortlistArgs &a_, int *flags64, hipStream_t s)

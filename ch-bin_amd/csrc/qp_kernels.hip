@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64 * WAVES, CHB_FUSED_OCC) void hull_select_qp_kern
         if (a.short_cnt != nullptr) {
             // the shortlist stage's contract (a short list would be a wrong hull with no error, a wild index a fault)
             bool sh = false;
-            if (valid) sh = nb < min(m, a.bin_ptr[c + 1] - a.bin_ptr[c]);
+            if (valid) sh = nb < min(m, a.bin_size != nullptr ? a.bin_size[c] : a.bin_ptr[c + 1] - a.bin_ptr[c]);
             const unsigned long long shm = __ballot(sh);
             if (shm != 0ull && lane == 0) atomicAdd(a.short_cnt, __popcll(shm));
         }
@@ -1430,7 +1430,8 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
             changed = ((__ballot(!same) >> (lane & 48)) & 0xFFFFull) != 0ull;
         }
     }
-    if (a.short_cnt != nullptr && valid && l16 == 0 && nb < min(m, a.bin_ptr[c + 1] - a.bin_ptr[c]))
+    if (a.short_cnt != nullptr && valid && l16 == 0 &&
+        nb < min(m, a.bin_size != nullptr ? a.bin_size[c] : a.bin_ptr[c + 1] - a.bin_ptr[c]))
         atomicAdd(a.short_cnt, 1);   // (the shortlist stage's contract, see FusedArgs)
     QP16_CLK(tc0);
 #ifdef CHB_DEV_CLK

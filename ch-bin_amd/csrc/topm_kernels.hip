@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void tile_kernel(TopmArgs a, int nqt, int tota
         nmem = pw_n - mb < pw_group ? pw_n - mb : pw_group;
     } else {
         mb = a.bin_ptr[c];
-        nmem = a.bin_ptr[c + 1] - mb;
+        nmem = a.bin_cnt != nullptr ? a.bin_cnt[c] : a.bin_ptr[c + 1] - mb;
     }
     const int pos0 = a.pos_begin + qt * kQTile;
     const int m = a.m;
@@ -439,11 +439,12 @@ __global__ __launch_bounds__(64 * WAVES) void select_generic_kernel(TopmArgs a, 
         if (lane < lc) { ld = a.in.d[slot * m + lane]; li = a.in.idx[slot * m + lane]; }
         if (lc >= m) tau = tau_from(a.in.d[slot * m + m - 1]);
     }
-    const int mb = a.bin_ptr[c], nmem = a.bin_ptr[c + 1] - mb;
+    const int mb = a.bin_ptr[c], nmem = a.bin_cnt != nullptr ? a.bin_cnt[c] : a.bin_ptr[c + 1] - mb;
     for (int base = 0; base < nmem; base += 64) {
         const int e = base + lane;
         bool ok = e < nmem;
-        const int mid = ok ? a.memb_id[mb + e] : 0;
+        int mid = ok ? a.memb_id[mb + e] : 0;
+        if (mid < 0) { ok = false; mid = 0; }   // (a hole of the persistent base pack)
         if (ok && a.memb_code != nullptr) {
             const int code = a.memb_code[mb + e];
             if (code > 0) ok = qpos > code - 1;

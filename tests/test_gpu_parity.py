@@ -1106,3 +1106,43 @@ for m in (5, 15):
                        timeout=600)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     assert p.stdout.count("caught") == 2
+
+
+@pytest.mark.parametrize("N,D,B,m,iters,sigma,mix,n_seed,batch", [
+    (6000, 136, 12, 5, 4, 6e-3, 0.5, 12, 512),     # overlapping bins: labels keep changing (appends, holes, moved regions)
+    (20000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 2048),
+    (5000, 140, 9, 15, 3, 4e-3, 0.3, 20, 700),     # 16-lane fused kernel, five coverage columns
+])
+def test_persistent_pack_equals_rebuild(O, N, D, B, m, iters, sigma, mix, n_seed, batch):
+    """The member pack of the shortlist stage kept across the batches of a fit (a batch's members become holes, a commit puts
+    them back in place or appends them to their new bin, full regions move: algorithm.py:50,60 as an update) against the
+    rebuild of CSR and pack at every batch start (CHB_PACK_INCR=0), and both against the oracle.  CHB_TILE_SKIP=0 keeps the
+    tile-skipping builds (which need the rebuild's shell order) out of the way, so the persistent pack serves every batch
+    from the first one on."""
+    X, initial, _ = _synth(N, D, B, S=5 if D == 140 else 1, seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
+    perms = _perms(initial, iters)
+    want, its_o, ch_o = O.fit_cluster(X, B, initial, perms, m, iters)
+    a = _ctx_env({"CHB_TILE_SKIP": "0"})
+    try:
+        a.set_samples(X)
+        got, its, ch, mind = a.fit_cluster(B, initial, perms, m, iters, batch=batch, want_min_dist=True)
+        st = a.fit_stats()
+        assert a.counter("pack_incremental_batches") == st["batches"] and a.counter("pack_builds") >= 1
+        assert a.counter("shortlist_short") == 0
+        got_t, its_t, ch_t = a.fit_cluster(B, initial, perms, m, iters, batch=batch)     # the look-ahead path
+        assert a.counter("pack_incremental_batches") > 0
+    finally:
+        a.close()
+    b = _ctx_env({"CHB_TILE_SKIP": "0", "CHB_PACK_INCR": "0"})
+    try:
+        b.set_samples(X)
+        ref, its_r, ch_r, mind_r = b.fit_cluster(B, initial, perms, m, iters, batch=batch, want_min_dist=True)
+        assert b.counter("pack_incremental_batches") == 0
+    finally:
+        b.close()
+    assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
+    assert its_t == its_o and np.array_equal(ch_t, ch_o) and np.array_equal(got_t, want)
+    assert its_r == its_o and np.array_equal(ref, want)
+    mv = initial < 0
+    assert np.allclose(mind[mv], mind_r[mv], rtol=0, atol=QP_TOL)
+    assert ch_o[1] > 0    # the case really moves contigs after the first sweep
