@@ -242,7 +242,7 @@ struct chb_ctx {
     DevBuf<int> agree;   // chb_bcast_samples: {status, N, D, root} of every rank
     int dev_inject_batches = 0;   // developer builds: batch starts of this context so far (CHB_SL_INJECT_SHORT)
     // the persistent base pack (prefilter_kernels.hip): the member pack kept across the batches of a fit
-    DevBuf<int> pp_start, pp_cap, pp_fill, pp_live, pp_nt, pp_memb, pp_row, pp_ctl, pp_ovf;
+    DevBuf<int> pp_start, pp_cap, pp_fill, pp_live, pp_nt, pp_memb, pp_row, pp_ctl, pp_ovf, pp_dest;
     int pp_arena_rows = 0;
     bool pp_allowed = true;    // CHB_PACK_INCR=0: every batch start rebuilds CSR and pack (the form up to round 3; A/B tests)
     bool pp_fit = false;       // inside chb_fit_cluster (the stepwise entry points and chb_topm_per_bin always rebuild)
@@ -253,7 +253,7 @@ struct chb_ctx {
     chb::PackState pack_state()
     {
         return chb::PackState{pp_start.p, pp_cap.p, pp_fill.p, pp_live.p, pp_nt.p, pp_memb.p, pp_row.p, pp_ctl.p, pp_ovf.p,
-                              pp_arena_rows};
+                              pp_dest.p, pp_arena_rows};
     }
     int64_t short_seen = 0;
     // bins far larger than the rest are cut into segments for the shortlist stage (SegPlan, prefilter_kernels.hip): plan
@@ -514,7 +514,7 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m, bool sy
 int pack_state_build(chb_ctx *h)
 {
     const size_t B = h->B;
-    const int arena = (int)std::min<int64_t>(8 * h->N + 512 * (int64_t)B, 0x7fffff00);
+    const int arena = (int)std::min<int64_t>(8 * h->N + 512 * (int64_t)B, 0x3fffff00);   // (2 * row + 1 must fit an int)
     if (h->pp_arena_rows < arena || !h->pp_memb.p) {
         HIPCHK(h->pk.ensure((size_t)arena, B, (size_t)h->Dz));
         HIPCHK(h->pp_memb.ensure((size_t)arena + 64));
@@ -525,6 +525,7 @@ int pack_state_build(chb_ctx *h)
     for (auto *b : pb) HIPCHK(b->ensure(B + 1));
     { const size_t had = h->pp_ctl.cap; HIPCHK(h->pp_ctl.ensure(4)); if (!had) HIPCHK(hipMemsetAsync(h->pp_ctl.p, 0, 4 * sizeof(int), h->stream)); }
     HIPCHK(h->pp_ovf.ensure((size_t)std::max(h->Kcap, 1)));
+    HIPCHK(h->pp_dest.ensure((size_t)std::max(h->Kcap, 1)));
     launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p, h->memb_id.p, nullptr,
                        nullptr, h->stream);
     launch_pack_state_build(h->pack_state(), h->pk.view(), h->Zs.p, h->ms.p, h->D, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B,
@@ -963,7 +964,7 @@ int chb_destroy(chb_ctx *h)
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
     h->slow.release(); h->n_slow.release(); h->tau.release(); h->short_cnt.release(); h->agree.release();
     h->pp_start.release(); h->pp_cap.release(); h->pp_fill.release(); h->pp_live.release(); h->pp_nt.release();
-    h->pp_memb.release(); h->pp_row.release(); h->pp_ctl.release(); h->pp_ovf.release();
+    h->pp_memb.release(); h->pp_row.release(); h->pp_ctl.release(); h->pp_ovf.release(); h->pp_dest.release();
     h->seg_nseg.release(); h->seg_gflag.release(); h->seg_items.release(); h->seg_lists.release();
     h->shell_inv.release(); h->ckey.release(); h->qord.release(); h->home.release();
     (void)hipStreamDestroy(h->stream);

@@ -177,6 +177,7 @@ struct PackState {
     int *row;      // [N] row of each sample, -1: not in the pack
     int *ctl;      // [4] {rows of the arena handed out, overflowed appends of the commit in flight, error flag, -}
     int *ovf;      // [K] batch positions whose append found its bin's region full (served by the fix kernel)
+    int *dest;     // [K] where each committed sample's row goes: 2 * row + (1: a new row of its bin), -1: nowhere / overflowed
     int arena_rows;
 };
 // from the compact CSR of all labelled samples (launch_bucket_base without shells): regions with room to grow, rows,

@@ -778,23 +778,79 @@ __global__ __launch_bounds__(256) void pack_state_start_kernel(PackState ps, Mem
         return;
     }
     if (b < 1 + nopen) {
+        extern __shared__ int gone[];   // [B] members this block takes out of each bin (one global atomic per block and bin)
+        for (int c = threadIdx.x; c < B; c += 256) gone[c] = 0;
+        __syncthreads();
         const int i = (b - 1) * 256 + (int)threadIdx.x;
-        if (i >= K) return;
-        const int p = bq[i];
-        const int l = labels[p];
-        lab_old[i] = l;
-        inb[p] = i;
-        if (l >= 0 && l < B) {
-            const int r = ps.row[p];
-            if (r >= 0) {
-                P.Z[(size_t)r * Dz + D] = kF16NegInf;   // a hole: never selectable while the batch is open
-                ps.memb[r] = -1;
-                atomicSub(&ps.live[l], 1);
+        if (i < K) {
+            const int p = bq[i];
+            const int l = labels[p];
+            lab_old[i] = l;
+            inb[p] = i;
+            if (l >= 0 && l < B) {
+                const int r = ps.row[p];
+                if (r >= 0) {
+                    P.Z[(size_t)r * Dz + D] = kF16NegInf;   // a hole: never selectable while the batch is open
+                    ps.memb[r] = -1;
+                    atomicAdd(&gone[l], 1);
+                }
             }
         }
+        __syncthreads();
+        for (int c = threadIdx.x; c < B; c += 256)
+            if (gone[c] > 0) atomicSub(&ps.live[c], gone[c]);
         return;
     }
     query_norms_tile(q, (b - 1 - nopen) % nqx, (b - 1 - nopen) / nqx);
+}
+
+// Where every committed sample's row goes, decided for 256 samples per block so that a bin's row counter sees ONE atomic
+// per block instead of one per sample (128 same-address device atomics in a row cost ~30 us): dest[i] = 2 * row + fresh
+// (fresh: a new row of the bin), or -1 (no label, or the bin's region is full: the sample is on the overflow list).
+__global__ __launch_bounds__(256) void pack_state_slots_kernel(PackState ps, const int *ids, int n, int B, const int *new_lab,
+                                                               const int *lab_old, int *dest, Gate gate)
+{
+    CHB_GATE(gate);
+    extern __shared__ int sh[];   // [B] appends of the block -> their first slot, [B] rows restored in place
+    int *app = sh, *res = sh + B;
+    for (int b = threadIdx.x; b < 2 * B; b += 256) sh[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + (int)threadIdx.x;
+    int c = -1, r0 = -1, rank = -1;
+    bool restore = false;
+    if (i < n) {
+        c = new_lab[i];
+        if (c >= 0 && c < B) {
+            r0 = ps.row[ids[i]];
+            restore = lab_old[i] == c && r0 >= 0;
+            if (restore) atomicAdd(&res[c], 1);
+            else rank = atomicAdd(&app[c], 1);
+        } else {
+            c = -1;
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const int na = app[b], nr = res[b];
+        int base = 0;
+        if (na > 0) base = atomicAdd(&ps.fill[b], na);
+        const int within = min(max(ps.cap[b] - base, 0), na);   // (the overflowed ones join `live` in the fix kernel)
+        if (nr + within > 0) atomicAdd(&ps.live[b], nr + within);
+        app[b] = base;
+    }
+    __syncthreads();
+    if (i < n) {
+        int d = -1;
+        if (c >= 0) {
+            if (restore) d = 2 * r0;
+            else {
+                const int slot = app[c] + rank;
+                if (slot < ps.cap[c]) d = 2 * (ps.start[c] + slot) + 1;
+                else ps.ovf[atomicAdd(&ps.ctl[1], 1)] = i;
+            }
+        }
+        dest[i] = d;
+    }
 }
 
 // batch commit: sample_shadow_kernel's commit form + the member's row back into the pack
@@ -802,7 +858,7 @@ __global__ __launch_bounds__(256) void pack_state_commit_kernel(PackState ps, Me
                                                                 const int *ids, int n, int *labels, int B,
                                                                 const double *centers, const double *mu_g, double S,
                                                                 unsigned short *Zs, int Dz, float4 *ms, const int *new_lab,
-                                                                const int *lab_old, int *inb, Gate gate)
+                                                                const int *dest_of, int *inb, Gate gate)
 {
     CHB_GATE(gate);
     const int lane = threadIdx.x & 63;
@@ -815,19 +871,8 @@ __global__ __launch_bounds__(256) void pack_state_commit_kernel(PackState ps, Me
         if (lane == 0) ps.row[p] = -1;   // (its old row, if any, stays a hole)
         return;
     }
-    // where the row goes (lane 0 decides; -1: the bin's region is full -- the fix kernel appends it to the new one)
-    int dest = -1, fresh = 0;
-    if (lane == 0) {
-        const int r0 = ps.row[p];
-        if (lab_old[i] == c && r0 >= 0) {
-            dest = r0;
-        } else {
-            const int slot = atomicAdd(&ps.fill[c], 1);
-            if (slot < ps.cap[c]) { dest = ps.start[c] + slot; fresh = 1; }
-            else ps.ovf[atomicAdd(&ps.ctl[1], 1)] = i;
-        }
-    }
-    dest = __shfl(dest, 0, 64); fresh = __shfl(fresh, 0, 64);
+    const int d = dest_of[i];
+    const int dest = d >= 0 ? d >> 1 : -1, fresh = d >= 0 ? d & 1 : 0;
     float resid = 0.f;
     float4 o = member_shadow_row(X + (size_t)p * Dp, centers + (size_t)c * Dp, mu_g, S, D, Dz, lane,
                                  Zs + (size_t)p * Dz, true, &resid, dest >= 0 ? P.Z + (size_t)dest * Dz : nullptr);
@@ -836,7 +881,6 @@ __global__ __launch_bounds__(256) void pack_state_commit_kernel(PackState ps, Me
         ms[p] = o;
         if (dest >= 0) {
             ps.memb[dest] = p; ps.row[p] = dest;
-            atomicAdd(&ps.live[c], 1);
             if (fresh) {
                 // a new row of the bin: its tile's and its bin's bounds (bin_bounds_from_source's quantities) can only grow
                 atomic_max_nonneg(&P.tsn[dest >> 5], sqrtf(o.z) * (1.0f + 2e-6f));
@@ -1890,7 +1934,7 @@ void launch_pack_state_start(const PackState &ps, const MemberPack &P, int D, in
     const int nq = pos_end - pos_begin;
     const int nqx = nq > 0 ? (nq + 31) / 32 : 0, nqy = (B + 63) / 64;
     const QnArgs q{X, D, Dp, open_bq, pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn), nullptr};
-    hipLaunchKernelGGL(pack_state_start_kernel, dim3(1 + nopen + nqx * nqy), dim3(256), 0, s, ps, P, D, Dz, labels, inb,
+    hipLaunchKernelGGL(pack_state_start_kernel, dim3(1 + nopen + nqx * nqy), dim3(256), (size_t)B * sizeof(int), s, ps, P, D, Dz, labels, inb,
                        open_bq, open_K, open_lab_old, B, seg ? *seg : SegPlan{}, stats, zero_me, nopen, q, std::max(nqx, 1),
                        g_gate);
 }
@@ -1900,8 +1944,10 @@ void launch_pack_state_commit(const PackState &ps, const MemberPack &P, const do
                               int Dz, void *ms, const int *new_lab, const int *lab_old, int *inb, hipStream_t s)
 {
     if (n <= 0) return;
+    hipLaunchKernelGGL(pack_state_slots_kernel, dim3((n + 255) / 256), dim3(256), 2 * (size_t)B * sizeof(int), s, ps, ids, n, B,
+                       new_lab, lab_old, ps.dest, g_gate);
     hipLaunchKernelGGL(pack_state_commit_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ps, P, X, D, Dp, ids, n, labels, B,
-                       centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms), new_lab, lab_old, inb, g_gate);
+                       centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms), new_lab, ps.dest, inb, g_gate);
     hipLaunchKernelGGL(pack_state_fix_kernel, dim3(B), dim3(256), 0, s, ps, P, Zs, reinterpret_cast<const float4 *>(ms), D, Dz,
                        ids, new_lab, g_gate);
 }
