@@ -509,12 +509,13 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m, bool sy
 }
 
 // The persistent base pack from the labels as they stand (no batch open): compact CSR of all labelled samples, then
-// regions with room to grow.  Allocates on first use (8 N + 512 B rows: a commit's moves take at most 2 (N + K) rows, the
-// host rebuilds from 3 N on) -- hence only ever called outside a look-ahead window.
+// regions with room to grow.  Allocates on first use (10 N + 1024 B rows: the layout takes at most 3.5 N + 128 B, a commit's
+// moves at most 2 (N + K) + 96 B, the host rebuilds from 5 N + 512 B on) -- hence only ever called outside a look-ahead window.
 int pack_state_build(chb_ctx *h)
 {
     const size_t B = h->B;
-    const int arena = (int)std::min<int64_t>(8 * h->N + 512 * (int64_t)B, 0x3fffff00);   // (2 * row + 1 must fit an int)
+    // (layout: at most 2 N + 1.5 N + 128 B rows; 2 * row + 1 must fit an int)
+    const int arena = (int)std::min<int64_t>(10 * h->N + 1024 * (int64_t)B, 0x3fffff00);
     if (h->pp_arena_rows < arena || !h->pp_memb.p) {
         HIPCHK(h->pk.ensure((size_t)arena, B, (size_t)h->Dz));
         HIPCHK(h->pp_memb.ensure((size_t)arena + 64));
@@ -528,8 +529,10 @@ int pack_state_build(chb_ctx *h)
     HIPCHK(h->pp_dest.ensure((size_t)std::max(h->Kcap, 1)));
     launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p, h->memb_id.p, nullptr,
                        nullptr, h->stream);
+    // (room to grow: were all N samples labelled and spread evenly, a bin would hold N / B rows -- half as much again)
+    const int grow = (int)std::min<int64_t>((3 * h->N / 2) / std::max<int64_t>(h->B, 1) + 64, 0x3fffffff);
     launch_pack_state_build(h->pack_state(), h->pk.view(), h->Zs.p, h->ms.p, h->D, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B,
-                            (int)h->N, h->stream);
+                            (int)h->N, grow, h->stream);
     HIPCHK(hipGetLastError());
     h->pp_valid = true; h->pp_rebuild = false;
     h->stats_pp_builds += 1;
@@ -1392,7 +1395,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             //  skipping of its shortlist launch achieved: a fit whose first batches skip next to nothing turns it off)
             h->hint_max_tiles = h->fc_host[8 * slot + 1]; h->hint_total_tiles = h->fc_host[8 * slot + 2];
             // (the persistent pack's arena: rows handed out so far, as of that batch's start)
-            if (h->pp_valid && h->fc_host[8 * slot + 6] > 3 * h->N + 128 * (int64_t)h->B) h->pp_rebuild = true;
+            if (h->pp_valid && h->fc_host[8 * slot + 6] > 5 * h->N + 512 * (int64_t)h->B) h->pp_rebuild = true;
             // (the slot's statistics are written by the batch's one base shortlist launch: counted with the batch's first
             //  round only -- later rounds of the same batch bring the same three numbers home again)
             if (active == 0 && h->fc_host[8 * slot + 4] > 0) {

@@ -183,7 +183,8 @@ struct PackState {
 // from the compact CSR of all labelled samples (launch_bucket_base without shells): regions with room to grow, rows,
 // bounds; every sample's row; the arena's fill mark
 void launch_pack_state_build(const PackState &ps, const MemberPack &P, const unsigned short *Zs, const void *ms, int D, int Dz,
-                             const int *memb_id, const int *bin_ptr, int B, int N, hipStream_t s);
+                             const int *memb_id, const int *bin_ptr, int B, int N, int grow, hipStream_t s);
+// (grow: rows every region gets at least -- what a bin is expected to hold once the unlabelled contigs are in)
 // batch start: the batch is opened (labels remembered, members marked, their rows turned into holes), the tiles per bin,
 // bin-size statistics and segment plan are written, and the batch's query norms computed: one launch
 void launch_pack_state_start(const PackState &ps, const MemberPack &P, int D, int Dz, const int *labels, int *inb,

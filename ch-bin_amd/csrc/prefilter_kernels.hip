@@ -670,13 +670,15 @@ __device__ __forceinline__ void pack_padding_row(unsigned short *zrow, int D, in
     }
 }
 
-// regions from the compact CSR: capacity = twice the bin's members (at least 64 rows); one block
-__global__ __launch_bounds__(256) void pack_state_layout_kernel(PackState ps, const int *bin_ptr, int B)
+// regions from the compact CSR: capacity = twice the bin's members, and at least `grow` rows -- the host's estimate of what
+// a bin will hold once the still unlabelled contigs are in (moving a region is one workgroup's copy: rare, but up to
+// 100 us for a 1500-row bin; measured before the estimate existed: a move in most batches of sweep 1); one block
+__global__ __launch_bounds__(256) void pack_state_layout_kernel(PackState ps, const int *bin_ptr, int B, int grow)
 {
     __shared__ int part[257];
     const int per = (B + 255) / 256;
     const int b0 = min(B, (int)threadIdx.x * per), b1 = min(B, b0 + per);
-    auto cap_of = [&](int b) { const int c = bin_ptr[b + 1] - bin_ptr[b]; return (max(2 * c, 64) + 31) / 32 * 32; };
+    auto cap_of = [&](int b) { const int c = bin_ptr[b + 1] - bin_ptr[b]; return (max(2 * c, max(grow, 64)) + 31) / 32 * 32; };
     int sp = 0;
     for (int b = b0; b < b1; ++b) sp += cap_of(b);
     part[threadIdx.x] = sp;
@@ -1913,12 +1915,12 @@ void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const i
 }
 
 void launch_pack_state_build(const PackState &ps, const MemberPack &P, const unsigned short *Zs, const void *ms, int D, int Dz,
-                             const int *memb_id, const int *bin_ptr, int B, int N, hipStream_t s)
+                             const int *memb_id, const int *bin_ptr, int B, int N, int grow, hipStream_t s)
 {
     if (B <= 0) return;
     launch_fill_i32(ps.row, -1, N, s);
-    hipLaunchKernelGGL(pack_state_layout_kernel, dim3(1), dim3(256), 0, s, ps, bin_ptr, B);
-    const long long rows = 2LL * N + 64LL * B;
+    hipLaunchKernelGGL(pack_state_layout_kernel, dim3(1), dim3(256), 0, s, ps, bin_ptr, B, grow);
+    const long long rows = 2LL * N + (long long)B * std::max(grow, 64) + 32LL * B;
     const int ngather = (int)std::max<long long>(1, std::min<long long>((rows + 15) / 16, 16384));
     hipLaunchKernelGGL(pack_state_build_kernel, dim3(ngather + B), dim3(256), 0, s, ps, P, Zs,
                        reinterpret_cast<const float4 *>(ms), D, Dz, memb_id, bin_ptr, B, ngather);
