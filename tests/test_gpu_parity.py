@@ -1110,8 +1110,8 @@ for m in (5, 15):
 
 @pytest.mark.parametrize("N,D,B,m,iters,sigma,mix,n_seed,batch", [
     (6000, 136, 12, 5, 4, 6e-3, 0.5, 12, 512),     # overlapping bins: labels keep changing (appends, holes, moved regions)
-    (20000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 2048),
-    (5000, 140, 9, 15, 3, 4e-3, 0.3, 20, 700),     # 16-lane fused kernel, five coverage columns
+    (9000, 136, 16, 5, 3, 1.5e-3, 0.0, None, 1024),
+    (2500, 140, 9, 15, 3, 4e-3, 0.3, 20, 400),     # 16-lane fused kernel, five coverage columns
 ])
 def test_persistent_pack_equals_rebuild(O, N, D, B, m, iters, sigma, mix, n_seed, batch):
     """The member pack of the shortlist stage kept across the batches of a fit (a batch's members become holes, a commit puts
