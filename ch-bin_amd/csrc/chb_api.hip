@@ -509,13 +509,13 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m, bool sy
 }
 
 // The persistent base pack from the labels as they stand (no batch open): compact CSR of all labelled samples, then
-// regions with room to grow.  Allocates on first use (10 N + 1024 B rows: the layout takes at most 3.5 N + 128 B, a commit's
-// moves at most 2 (N + K) + 96 B, the host rebuilds from 5 N + 512 B on) -- hence only ever called outside a look-ahead window.
+// regions with room to grow.  Allocates on first use (12 N + 1024 B rows: the layout takes at most 3.5 N + 128 B, a commit's
+// moves at most 3 (N + K) + 96 B, the host rebuilds from 5 N + 512 B on) -- hence only ever called outside a look-ahead window.
 int pack_state_build(chb_ctx *h)
 {
     const size_t B = h->B;
     // (layout: at most 2 N + 1.5 N + 128 B rows; 2 * row + 1 must fit an int)
-    const int arena = (int)std::min<int64_t>(10 * h->N + 1024 * (int64_t)B, 0x3fffff00);
+    const int arena = (int)std::min<int64_t>(12 * h->N + 1024 * (int64_t)B, 0x3fffff00);
     if (h->pp_arena_rows < arena || !h->pp_memb.p) {
         HIPCHK(h->pk.ensure((size_t)arena, B, (size_t)h->Dz));
         HIPCHK(h->pp_memb.ensure((size_t)arena + 64));

@@ -897,7 +897,7 @@ __global__ __launch_bounds__(256) void pack_state_commit_kernel(PackState ps, Me
 }
 
 // behind every commit, one block per bin: a bin whose region ran full (fill > cap: the commit's appends past the
-// capacity are on the overflow list) moves to a region of twice its size -- members squeezed together, the overflowed
+// capacity are on the overflow list) moves to a region of three times its size -- members squeezed together, the overflowed
 // samples appended, the rest padding.  Exits at once for every other bin.
 __global__ __launch_bounds__(256) void pack_state_fix_kernel(PackState ps, MemberPack P, const unsigned short *Zs,
                                                              const float4 *ms, int D, int Dz, const int *ids,
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(256) void pack_state_fix_kernel(PackState ps, Membe
     const int tid = threadIdx.x, l16 = tid & 15, cpr = Dz >> 3;
     if (tid == 0) {
         const int want = ps.live[c] + (ps.fill[c] - cap);
-        const int ncap = (2 * want + 64 + 31) / 32 * 32;
+        const int ncap = (3 * want + 64 + 31) / 32 * 32;   // (a bin that outgrew the estimate keeps growing: fewer moves)
         int st = atomicAdd(&ps.ctl[0], ncap);
         if (st + ncap > ps.arena_rows) { ps.ctl[2] = 1; st = -1; }   // (the host sizes the arena so that this cannot happen)
         s_new = st; s_cnt = 0;
@@ -937,13 +937,15 @@ __global__ __launch_bounds__(256) void pack_state_fix_kernel(PackState ps, Membe
         const int base = s_cnt;
         if (id >= 0) s_src[before] = old + r;
         __syncthreads();
-        for (int j = tid >> 4; j < chunk; j += 16) {
-            const int src = s_src[j], dst = nst + base + j;
-            for (int cc = l16; cc < cpr; cc += 16)
-                *reinterpret_cast<uint4 *>(P.Z + (size_t)dst * Dz + cc * 8) =
-                    *reinterpret_cast<const uint4 *>(P.Z + (size_t)src * Dz + cc * 8);
-            if (l16 == 0) { const int sid = ps.memb[src]; ps.memb[dst] = sid; ps.row[sid] = dst; }
+        // (a flat loop over the chunk's 16-byte pieces: independent iterations, many loads in flight -- a loop of 16 rows
+        //  at a time made a 1500-row bin's move take 100 us)
+#pragma unroll 4
+        for (int idx = tid; idx < chunk * cpr; idx += 256) {
+            const int j = idx / cpr, cc = idx - j * cpr;
+            *reinterpret_cast<uint4 *>(P.Z + (size_t)(nst + base + j) * Dz + cc * 8) =
+                *reinterpret_cast<const uint4 *>(P.Z + (size_t)s_src[j] * Dz + cc * 8);
         }
+        if (tid < chunk) { const int sid = ps.memb[s_src[tid]]; ps.memb[nst + base + tid] = sid; ps.row[sid] = nst + base + tid; }
         __syncthreads();
         if (tid == 0) s_cnt = base + chunk;
         __syncthreads();
@@ -963,13 +965,13 @@ __global__ __launch_bounds__(256) void pack_state_fix_kernel(PackState ps, Membe
         const int base = s_cnt;
         if (i >= 0) s_src[before] = ids[i];
         __syncthreads();
-        for (int j = tid >> 4; j < chunk; j += 16) {
-            const int sid = s_src[j], dst = nst + base + j;
-            for (int cc = l16; cc < cpr; cc += 16)
-                *reinterpret_cast<uint4 *>(P.Z + (size_t)dst * Dz + cc * 8) =
-                    *reinterpret_cast<const uint4 *>(Zs + (size_t)sid * Dz + cc * 8);
-            if (l16 == 0) { ps.memb[dst] = sid; ps.row[sid] = dst; }
+#pragma unroll 4
+        for (int idx = tid; idx < chunk * cpr; idx += 256) {
+            const int j = idx / cpr, cc = idx - j * cpr;
+            *reinterpret_cast<uint4 *>(P.Z + (size_t)(nst + base + j) * Dz + cc * 8) =
+                *reinterpret_cast<const uint4 *>(Zs + (size_t)s_src[j] * Dz + cc * 8);
         }
+        if (tid < chunk) { const int sid = s_src[tid]; ps.memb[nst + base + tid] = sid; ps.row[sid] = nst + base + tid; }
         __syncthreads();
         if (tid == 0) s_cnt = base + chunk;
         __syncthreads();
