@@ -26,7 +26,9 @@
  *       CHB_SPECULATE=0     no look-ahead across batches in chb_fit_cluster
  *       CHB_FORCE_GATHER=1  exchange path of the sharded loop even with one rank
  *       CHB_SEGMENTS=0      bins far larger than the rest are never cut into segments for the shortlist stage
- *       CHB_FUSED_STRIPE=0  position-major work order in the m <= 5 fused kernel (default: striped over the XCDs by bin)
+ *       CHB_FUSED_STRIPE=0  position-major work order in the fused kernels (default: striped over the XCDs by bin)
+ *       CHB_PACK_INCR=0     CSR and member pack of the shortlist stage rebuilt from the labels at every batch start (default:
+ *                           kept across the batches of a fit and updated by each commit, where tiles are not skipped)
  *       CHB_TILE_SKIP=0     the shortlist stage never skips member tiles (default: on for fits whose first batches
  *                           show that tiles can be skipped -- data with several coverage columns)
  */
