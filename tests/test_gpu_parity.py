@@ -945,10 +945,11 @@ def test_segmented_giant_bin(O, m):
     initial = np.where(initial_t >= 0, remap[np.maximum(initial_t, 0)], -1).astype(np.int64)
     true = remap[true_t]
     perms = _perms(initial, 2)
-    a = _lib.Context(0)
+    a = _ctx_env({"CHB_TILE_SKIP": "0"})   # (the persistent base pack then serves every batch: segments on its regions)
     try:
         a.set_samples(X)
         got, its, changed = a.fit_cluster(B, initial, perms, m, 2)
+        assert a.counter("pack_incremental_batches") == a.fit_stats()["batches"]
         seg_batches = a.counter("segment_batches")
         overflow = a.counter("prefilter_overflow")
         assert a.counter("shortlist_short") == 0   # the product build's check of the shortlist stage's contract

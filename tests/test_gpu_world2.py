@@ -99,3 +99,22 @@ def test_sharded_cpp_loop_more_than_one_rank_one_gpu(world):
         assert len({int(outs[r][f"rounds{case}"]) for r in range(world)}) == 1
         if D == 140:   # tiles really were skipped on the ranks' slices (the first workgroups of a launch are sampled)
             assert sum(int(outs[r][f"unloaded{case}"]) for r in range(world)) > 0
+
+
+def test_bench_self_launch_two_ranks_one_gpu():
+    """`python bench.py --gpus 2` with no launcher in the environment, on a box with ONE GPU: the two ranks are started as
+    children (before anything touches the GPU), share cuda:0 over gloo and -- RCCL refuses two ranks on one device -- run the
+    Python driver; exactly one JSON line comes back and the status is 0.  (The driver's own multi-GPU runs go through RCCL;
+    this covers the launch path on a GPU box.)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-gpu",
+                        "--allow-fallback", "--contigs", "12000", "--bins", "16", "--steps", "1", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    ev = j["config"]["parallelism_evidence"]
+    assert len(ev["hull_evaluated_per_rank_last_step"]) == 2 and all(v > 0 for v in ev["hull_evaluated_per_rank_last_step"])
