@@ -241,6 +241,9 @@ struct chb_ctx {
     DevBuf<int> short_cnt;
     DevBuf<int> agree;   // chb_bcast_samples: {status, N, D, root} of every rank
     int dev_inject_batches = 0;   // developer builds: batch starts of this context so far (CHB_SL_INJECT_SHORT)
+#ifdef CHB_DEV_KNOBS
+    chb::ShortlistArgs dev_pa{}; bool dev_pa_valid = false;   // the open batch's base shortlist launch (CHB_DEV_OVERLAP)
+#endif
     // the persistent base pack (prefilter_kernels.hip): the member pack kept across the batches of a fit
     DevBuf<int> pp_start, pp_cap, pp_fill, pp_live, pp_nt, pp_memb, pp_row, pp_ctl, pp_ovf, pp_dest;
     int pp_arena_rows = 0;
@@ -650,6 +653,9 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             launch_shortlist(pa, h->flags64.p, s);
         }
 #ifdef CHB_DEV_KNOBS
+        h->dev_pa = pa; h->dev_pa_valid = true;   // (CHB_DEV_OVERLAP)
+#endif
+#ifdef CHB_DEV_KNOBS
         if (pa.dbg != nullptr) {
             std::vector<unsigned long long> hostd(dbg_words);
             HIPCHK(hipStreamSynchronize(s));
@@ -774,10 +780,41 @@ int batch_round_dev(chb_ctx *h, int active)
             f.dist = h->dist.p; f.metric = h->metric; f.slow = h->slow.p; f.n_slow = h->n_slow.p;
             f.bin_ptr = h->bin_ptr.p; f.short_cnt = h->short_cnt.p;
             if (h->pp_batch) f.bin_size = h->pp_live.p;
+#ifdef CHB_DEV_KNOBS
+            // CHB_DEV_OVERLAP=1: how much would the base shortlist launch of the NEXT batch gain from running beside this
+            // batch's hull kernel?  The batch's own base shortlist launch is repeated into scratch buffers on a second
+            // stream while the hull kernel runs (2: the same repeat in line on the main stream -- the additive baseline).
+            static const int dev_overlap = getenv("CHB_DEV_OVERLAP") ? atoi(getenv("CHB_DEV_OVERLAP")) : 0;
+            static hipStream_t dev_s2 = nullptr; static hipEvent_t dev_e1 = nullptr, dev_e2 = nullptr;
+            static int *dev_scratch = nullptr; static size_t dev_scratch_n = 0;
+            bool dev_side = false;
+            if (dev_overlap && h->round_in_batch == 0 && h->dev_pa_valid) {
+                const size_t KB = (size_t)h->Kcap * h->B;
+                const size_t need = KB * kCandCap + 4 * KB + 64;
+                if (dev_scratch_n < need) { if (dev_scratch) (void)hipFree(dev_scratch); HIPCHK(hipMalloc(&dev_scratch, need * sizeof(int))); dev_scratch_n = need; HIPCHK(hipMemset(dev_scratch, 0, need * sizeof(int))); }
+                if (!dev_s2) { HIPCHK(hipStreamCreateWithFlags(&dev_s2, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&dev_e1, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&dev_e2, hipEventDisableTiming)); }
+                ShortlistArgs pb = h->dev_pa;
+                pb.cand = dev_scratch; pb.cand_cnt = dev_scratch + KB * kCandCap; pb.tau_out = reinterpret_cast<float *>(dev_scratch + KB * kCandCap + KB);
+                pb.overflow = dev_scratch + KB * kCandCap + 2 * KB; pb.nflag = pb.overflow + 1; pb.flaglist = pb.overflow + 8;
+                pb.skip_stat = nullptr;
+                int *fl = dev_scratch + KB * kCandCap + 3 * KB;
+                if (dev_overlap == 1) {
+                    HIPCHK(hipEventRecord(dev_e1, s)); HIPCHK(hipStreamWaitEvent(dev_s2, dev_e1, 0));
+                    launch_shortlist(pb, fl, dev_s2);
+                    HIPCHK(hipEventRecord(dev_e2, dev_s2));
+                    dev_side = true;
+                } else {
+                    launch_shortlist(pb, fl, s);
+                }
+            }
+#endif
             {
                 Timed t(h, "hull_qp", (double)(hi - lo) * h->B);
                 launch_hull_select_qp(f, s);
             }
+#ifdef CHB_DEV_KNOBS
+            if (dev_side) HIPCHK(hipStreamWaitEvent(s, dev_e2, 0));
+#endif
             {
                 // the exact path for what the fused kernel left: cdist-rounded distances on both shortlists,
                 // (distance, index) order, then the list-based hull kernel
