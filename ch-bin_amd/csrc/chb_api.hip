@@ -1432,7 +1432,13 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             //  skipping of its shortlist launch achieved: a fit whose first batches skip next to nothing turns it off)
             h->hint_max_tiles = h->fc_host[8 * slot + 1]; h->hint_total_tiles = h->fc_host[8 * slot + 2];
             // (the persistent pack's arena: rows handed out so far, as of that batch's start)
-            if (h->pp_valid && h->fc_host[8 * slot + 6] > 5 * h->N + 512 * (int64_t)h->B) h->pp_rebuild = true;
+            {
+                int64_t mark_at = 5 * h->N + 512 * (int64_t)h->B;
+#ifdef CHB_DEV_KNOBS   // CHB_PACK_REBUILD_AT=<rows>: rebuild (compact) the pack from that fill mark on -- tests of the rebuild path
+                { static const char *e = getenv("CHB_PACK_REBUILD_AT"); if (e) mark_at = atoll(e); }
+#endif
+                if (h->pp_valid && h->fc_host[8 * slot + 6] > mark_at) h->pp_rebuild = true;
+            }
             // (the slot's statistics are written by the batch's one base shortlist launch: counted with the batch's first
             //  round only -- later rounds of the same batch bring the same three numbers home again)
             if (active == 0 && h->fc_host[8 * slot + 4] > 0) {

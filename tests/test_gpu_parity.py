@@ -1148,3 +1148,46 @@ def test_persistent_pack_equals_rebuild(O, N, D, B, m, iters, sigma, mix, n_seed
     assert np.allclose(mind[mv], mind_r[mv], rtol=0, atol=QP_TOL)
     if mix >= 0.5:
         assert ch_o[1] > 0    # the case really moves contigs after the first sweep
+
+
+def test_persistent_pack_rebuilds_under_pressure(tmp_path):
+    """The persistent base pack is rebuilt from the labels (holes squeezed out, regions re-sized) when much of its row arena
+    has been handed out -- a path ordinary data never reaches (the arena holds 12 N + 1024 B rows).  The developer library
+    takes the fill mark from CHB_PACK_REBUILD_AT: with a mark below the initial layout EVERY batch start outside a look-ahead
+    window rebuilds.  Labels must equal the oracle's, with the look-ahead on and off.  Child process (its own library);
+    skipped where the developer library has not been built."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = os.path.join(root, "ch-bin_amd", "libchbin_hip_dev.so")
+    if not os.path.exists(dev):
+        pytest.skip("developer library not built")
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import chbin_amd
+from chbin_amd import _lib, synth
+from oracle import oracle as O
+X, initial, _ = synth.make_synthetic(5000, 136, 10, seed=21, sigma=6e-3, mix=0.5, n_seed=10)
+perms = synth.draw_permutations(initial, 4, seed=0)
+want, its_o, ch_o = O.fit_cluster(X, 10, initial, perms, 5, 4)
+ctx = _lib.Context(0)
+ctx.set_samples(X)
+got, its, ch, mind = ctx.fit_cluster(10, initial, perms, 5, 4, batch=400, want_min_dist=True)
+builds_a = ctx.counter("pack_builds")
+assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
+got2, its2, ch2 = ctx.fit_cluster(10, initial, perms, 5, 4, batch=400)
+builds_b = ctx.counter("pack_builds")
+assert its2 == its_o and np.array_equal(got2, want)
+assert ctx.counter("shortlist_short") == 0
+print("builds", builds_a, builds_b, ctx.counter("pack_incremental_batches"), ctx.counter("lookahead_batches"))
+assert builds_a > 10 and builds_b > 10
+ctx.close()
+""" % root
+    script = tmp_path / "rebuild.py"
+    script.write_text(code)
+    env = dict(os.environ, CHBIN_LIB=dev, CHB_TILE_SKIP="0", CHB_PACK_REBUILD_AT="1")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
