@@ -813,9 +813,8 @@ __global__ __launch_bounds__(256) void pack_state_slots_kernel(PackState ps, con
                                                                const int *lab_old, int *dest, Gate gate)
 {
     CHB_GATE(gate);
-    extern __shared__ int sh[];   // [B] appends of the block -> their first slot, [B] rows restored in place
-    int *app = sh, *res = sh + B;
-    for (int b = threadIdx.x; b < 2 * B; b += 256) sh[b] = 0;
+    extern __shared__ int app[];   // [B] per bin: appends of the block (low half; then: their first slot) | rows restored in place (high half)
+    for (int b = threadIdx.x; b < B; b += 256) app[b] = 0;
     __syncthreads();
     const int i = blockIdx.x * 256 + (int)threadIdx.x;
     int c = -1, r0 = -1, rank = -1;
@@ -825,15 +824,15 @@ __global__ __launch_bounds__(256) void pack_state_slots_kernel(PackState ps, con
         if (c >= 0 && c < B) {
             r0 = ps.row[ids[i]];
             restore = lab_old[i] == c && r0 >= 0;
-            if (restore) atomicAdd(&res[c], 1);
-            else rank = atomicAdd(&app[c], 1);
+            if (restore) atomicAdd(&app[c], 0x10000);
+            else rank = atomicAdd(&app[c], 1) & 0xffff;
         } else {
             c = -1;
         }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += 256) {
-        const int na = app[b], nr = res[b];
+        const int na = app[b] & 0xffff, nr = app[b] >> 16;   // (at most 256 of either per block)
         int base = 0;
         if (na > 0) base = atomicAdd(&ps.fill[b], na);
         const int within = min(max(ps.cap[b] - base, 0), na);   // (the overflowed ones join `live` in the fix kernel)
@@ -905,24 +904,26 @@ __global__ __launch_bounds__(256) void pack_state_fix_kernel(PackState ps, Membe
 {
     CHB_GATE(gate);
     const int c = blockIdx.x;
-    const int cap = ps.cap[c];
-    if (ps.fill[c] <= cap) return;
-    __shared__ int s_new, s_cnt, s_src[256];
+    const int cap = ps.cap[c], fill0 = ps.fill[c];
+    if (fill0 <= cap) return;   // (nobody writes the bin's records in this launch then: every wavefront of the block sees the same)
+    __shared__ int s_new, s_ncap, s_cnt, s_src[256];
     const int nov = ps.ctl[1];
     const int old = ps.start[c];
     const int tid = threadIdx.x, l16 = tid & 15, cpr = Dz >> 3;
+    // every wavefront has read the OLD capacity, start and fill before thread 0 changes any of them (a wavefront that
+    // started late would otherwise take the early return above against the new capacity and miss the barriers below)
+    __syncthreads();
     if (tid == 0) {
-        const int want = ps.live[c] + (ps.fill[c] - cap);
-        const int ncap = (3 * want + 64 + 31) / 32 * 32;   // (a bin that outgrew the estimate keeps growing: fewer moves)
-        int st = atomicAdd(&ps.ctl[0], ncap);
-        if (st + ncap > ps.arena_rows) { ps.ctl[2] = 1; st = -1; }   // (the host sizes the arena so that this cannot happen)
-        s_new = st; s_cnt = 0;
-        if (st >= 0) ps.cap[c] = ncap;
+        const int want = ps.live[c] + (fill0 - cap);
+        const int nc = (3 * want + 64 + 31) / 32 * 32;   // (a bin that outgrew the estimate keeps growing: fewer moves)
+        int st = atomicAdd(&ps.ctl[0], nc);
+        if (st + nc > ps.arena_rows) { ps.ctl[2] = 1; st = -1; }   // (the host sizes the arena so that this cannot happen)
+        s_new = st; s_ncap = nc; s_cnt = 0;
     }
     __syncthreads();
     const int nst = s_new;
     if (nst < 0) { if (tid == 0) ps.fill[c] = cap; return; }
-    const int ncap = ps.cap[c];
+    const int ncap = s_ncap;
     // members of the old region, in row order, 256 rows at a time
     for (int r0 = 0; r0 < cap; r0 += 256) {
         const int r = r0 + tid;
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(256) void pack_state_fix_kernel(PackState ps, Membe
         for (int off = 16; off >= 1; off >>= 1) tn = fmaxf(tn, __shfl_xor(tn, off, 64));
         if ((tid & 31) == 0 && r < ncap) P.tsn[(nst + r) >> 5] = sqrtf(tn) * (1.0f + 2e-6f);
     }
-    if (tid == 0) { ps.start[c] = nst; ps.fill[c] = cnt; ps.live[c] = cnt; }
+    if (tid == 0) { ps.start[c] = nst; ps.cap[c] = ncap; ps.fill[c] = cnt; ps.live[c] = cnt; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1948,7 +1949,7 @@ void launch_pack_state_commit(const PackState &ps, const MemberPack &P, const do
                               int Dz, void *ms, const int *new_lab, const int *lab_old, int *inb, hipStream_t s)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(pack_state_slots_kernel, dim3((n + 255) / 256), dim3(256), 2 * (size_t)B * sizeof(int), s, ps, ids, n, B,
+    hipLaunchKernelGGL(pack_state_slots_kernel, dim3((n + 255) / 256), dim3(256), (size_t)B * sizeof(int), s, ps, ids, n, B,
                        new_lab, lab_old, ps.dest, g_gate);
     hipLaunchKernelGGL(pack_state_commit_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ps, P, X, D, Dp, ids, n, labels, B,
                        centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms), new_lab, ps.dest, inb, g_gate);
