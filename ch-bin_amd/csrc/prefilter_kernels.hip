@@ -1373,7 +1373,10 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
         if (h == 0) sCnt[32 * w + col] = 0;
         // (per-tile bests assume that the m nearest members sit in different tiles, i.e. a random member order; with the
         //  shell order of tile skipping they crowd into the same few tiles, so every value competes then)
-        const bool tile_best = !SKIP && (SEG != 0 || ntile >= a.tile_best_min) && !(!UPD && a.skip != 0);
+        // (... nor when the top m are likely to share tile halves anyway -- m^2 / (4 tiles) of them do: at m = 15 and bins of
+        //  25-49 tiles the per-tile-best tau is so loose that the hull kernel gathers 17 instead of ~15.5 rows per pair:
+        //  39.5 against 43.5 ms per sweep with every value competing; at m <= 8 the cheaper sweep 0 wins, at m = 12 it is a tie)
+        const bool tile_best = !SKIP && (SEG != 0 || (ntile >= a.tile_best_min && 4 * ntile >= m * m)) && !(!UPD && a.skip != 0);
         int wcnt = 0;   // entries parked by this wavefront and not yet written out (wave-uniform)
         if (SEG == 2) {
             // the m best accumulators of every segment of this bin (phase-1 launch): their union's m-th best
