@@ -164,6 +164,7 @@ struct ShortlistArgs {
     SegPlan seg;         // base mode: segmented bins (seg.gflag == nullptr: none)
     float gamma;         // accumulation error factor g (set by launch_shortlist)
     int tile_best_min;   // bins with at least this many tiles learn tau from per-tile bests (ditto)
+    int tile_k2;         // ... or, where the top m crowd into tile halves (4 tiles < m^2), from the tile_k2 best per tile half
 };
 // ---- the persistent base pack (prefilter_kernels.hip, "persistent base pack"): the member pack of the shortlist stage
 // kept across the batches of a fit instead of being rebuilt from the labels at every batch start

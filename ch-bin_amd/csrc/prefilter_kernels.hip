@@ -1375,8 +1375,12 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
         //  shell order of tile skipping they crowd into the same few tiles, so every value competes then)
         // (... nor when the top m are likely to share tile halves anyway -- m^2 / (4 tiles) of them do: at m = 15 and bins of
         //  25-49 tiles the per-tile-best tau is so loose that the hull kernel gathers 17 instead of ~15.5 rows per pair:
-        //  39.5 against 43.5 ms per sweep with every value competing; at m <= 8 the cheaper sweep 0 wins, at m = 12 it is a tie)
+        //  39.5 against 43.5 ms per sweep with every value competing, 39.1 with the three best per tile half (kmax below);
+        //  at m <= 8 the cheaper sweep 0 wins, at m = 12 it is a tie)
         const bool tile_best = !SKIP && (SEG != 0 || (ntile >= a.tile_best_min && 4 * ntile >= m * m)) && !(!UPD && a.skip != 0);
+        // (in between: a bin with enough tiles for the shortcut but crowded tile halves lets its tile_k2 best values per tile
+        //  half compete -- a bounded loop)
+        const int kmax = (ML > 8 && !SKIP && !tile_best && SEG == 0 && ntile >= a.tile_best_min && !(!UPD && a.skip != 0)) ? a.tile_k2 : 0x7fffffff;
         int wcnt = 0;   // entries parked by this wavefront and not yet written out (wave-uniform)
         if (SEG == 2) {
             // the m best accumulators of every segment of this bin (phase-1 launch): their union's m-th best
@@ -1472,7 +1476,9 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                                 tau_run = (sqrtf(fmaxf(-2.0f * thr_s + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum) * (1.0f + 4.0f * kSlack);
                         }
                     } else
-                    while (mx - dlt > thr_s) {
+                    // (the counted form only in the builds for m > 8, the only ones that can reach kmax: in the 128-register
+                    //  builds the counter costs the shortlist kernel 1.5 %)
+                    for (int left = ML > 8 ? kmax : 1; left > 0 && mx - dlt > thr_s; left -= ML > 8 ? 1 : 0) {
                         list_insert_desc<ML>(lb, mx - dlt);
                         thr_s = lb[ML - 1];
                         if (can_skip && thr_s > -INFINITY)
@@ -1965,13 +1971,14 @@ void launch_shortlist(const ShortlistArgs &a_, int *flags64, hipStream_t s)
     ShortlistArgs a = a_;
     // The accumulation-error factor is part of the proof that the shortlist contains the exact
     // top-m: the product library takes it from the constant only.
-    a.gamma = kGamma; a.tile_best_min = 16;
+    a.gamma = kGamma; a.tile_best_min = 16; a.tile_k2 = 3;
 #ifdef CHB_DEV_KNOBS   // developer builds (tools/): never below kGamma
     {
         static float g = -1.f; static int tb = -1;
         if (g < 0.f) { const char *e = getenv("CHB_SL_GAMMA"); g = e ? std::max((float)atof(e), kGamma) : kGamma; }
         if (tb < 0) { const char *e = getenv("CHB_SL_TILEBEST"); tb = e ? atoi(e) : 16; }
         a.gamma = g; a.tile_best_min = tb;
+        { static int tk = -1; if (tk < 0) { const char *e = getenv("CHB_SL_TILEK"); tk = e ? std::max(1, atoi(e)) : 3; } a.tile_k2 = tk; }
     }
 #endif
     const int nq = a.pos_end - a.pos_begin;
