@@ -458,11 +458,13 @@ def test_shortlist_stage_equals_brute_force(ctx, O, kind):
             assert np.array_equal(got[0][qi, c, :len(want_idx)], want_idx)
 
 
-@pytest.mark.parametrize("N,D,B,m", [(20000, 136, 500, 5), (12000, 140, 64, 15), (9000, 146, 3, 8)])
+@pytest.mark.parametrize("N,D,B,m", [(20000, 136, 500, 5), (12000, 140, 64, 15), (9000, 146, 3, 8), (12000, 136, 12, 15)])
 def test_fit_two_stage_equals_brute_force_selection(O, N, D, B, m):
     """Whole fits with the two-stage selection against the same fits with CHB_PREFILTER=0 (brute-force
     selection kernel) at sizes the oracle cannot replay: many small bins, long lists (m = 15, where
-    the shortlist pool is emptied mid-bin and overflow fallbacks occur), few huge bins."""
+    the shortlist pool is emptied mid-bin and overflow fallbacks occur), few huge bins, and (round 4) m = 15 on bins
+    of ~1000 members = 31 tiles: >= 16 tiles but 4 x tiles < m^2, where sweep 0 lets the three best values per tile
+    half compete."""
     from chbin_amd import _lib
     S = 1 if D <= 136 else (5 if D == 140 else 10)
     X, initial, _ = _synth(N, D, B, S=S, seed=3, sigma=3e-3, mix=0.3, n_seed=3)
