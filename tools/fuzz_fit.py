@@ -39,7 +39,7 @@ for t in range(n_cases):
         S = 1 if D < 140 else (5 if D < 146 else 10)
         iters = int(rng.integers(1, 4)); n_seed = int(rng.integers(1, 24))
     metric = str(rng.choice(["convex", "convex", "convex", "affine"]))
-    if m > D or D < 24:
+    if m > D or D < 24 or (D < 40 and m > 8):   # (round 4, case `120 91 m16` #101: 14 vertices in D = 24 straddle orth's cutoff too)
         # m > D: the affine hull of > D generic points is the whole space, every distance is rounding
         # noise.  Small D: the reference formula (scipy.linalg.orth with its default cutoff eps * max(m, D),
         # restated in the oracle) can admit the pure-noise direction of the centred vertex matrix

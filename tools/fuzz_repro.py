@@ -35,7 +35,7 @@ for t in range(index + 1):
         S = 1 if D < 140 else (5 if D < 146 else 10)
         iters = int(rng.integers(1, 4)); n_seed = int(rng.integers(1, 24))
     metric = str(rng.choice(["convex", "convex", "convex", "affine"]))
-    if m > D or D < 24:
+    if m > D or D < 24 or (D < 40 and m > 8):   # (round 4, case `120 91 m16` #101: 14 vertices in D = 24 straddle orth's cutoff too)
         metric = "convex"
     X, initial, _ = synth.make_synthetic(N, D, B, S=min(S, max(D - 4, 1)), seed=int(rng.integers(1 << 30)), sigma=sigma,
                                          mix=mix, n_seed=n_seed)
