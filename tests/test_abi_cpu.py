@@ -75,3 +75,41 @@ def test_solve_qp_recognises_the_reference_tuples():
     assert _recognise(P, q, None, np.zeros(m), A, b) is None
     with pytest.raises(NotImplementedError):
         check_solver("nosuch")
+
+
+def test_traffic_table_formulas(tmp_path):
+    """tools/traffic_from_pmc.py turns rocprofv3 --pmc counter CSVs into the per-kernel table behind bench.py's
+    `roofline.traffic` / `roofline.limiter`: per launch (2 x FETCH_SIZE + WRITE_SIZE) KiB on the fabric side, TCP -> TCC read
+    requests x 128 B on the L2 side, hit rate, busy shares.  A hand-made CSV with known totals pins the formulas (no GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / "passes" / "pmc_x"
+    d.mkdir(parents=True)
+    rows = [("Kernel_Name", "Counter_Name", "Counter_Value")]
+    kern = "void chb::(anonymous namespace)::demo_kernel<5, true>(int, int)"
+    per_launch = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 500.0, "TCP_TCC_READ_REQ_sum": 2.0e6, "TCC_HIT_sum": 900.0,
+                  "TCC_MISS_sum": 100.0, "SQ_WAVE_CYCLES": 1000.0, "SQ_BUSY_CU_CYCLES": 400.0, "SQ_ACTIVE_INST_VALU": 100.0,
+                  "SQ_VALU_MFMA_BUSY_CYCLES": 320.0, "SQ_VALU_MFMA_COEXEC_CYCLES": 80.0, "SQ_WAIT_ANY": 500.0,
+                  "SQ_WAIT_INST_ANY": 300.0, "SQ_ACTIVE_INST_ANY": 200.0}
+    for _launch in range(4):
+        for c, v in per_launch.items():
+            rows.append((kern, c, str(v)))
+    with open(d / "t_counter_collection.csv", "w") as fh:
+        for r in rows:
+            fh.write(",".join('"%s"' % x for x in r) + "\n")
+    prefix = str(tmp_path / "out")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "traffic_from_pmc.py"), str(tmp_path / "passes"), prefix],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-1500:]
+    t = json.load(open(prefix + "_traffic.json"))
+    k = t["kernels"]["demo_kernel<5, true>"]
+    assert k["launches"] == 4
+    assert k["traffic_bytes_per_launch"] == (2 * 1000.0 + 500.0) * 1024.0
+    assert k["l2_read_bytes_per_launch"] == 2.0e6 * 128.0
+    assert abs(k["l2_hit_rate"] - 0.9) < 1e-12
+    assert abs(k["valu_busy"] - 0.25) < 1e-12 and abs(k["mfma_busy"] - 0.2) < 1e-12 and abs(k["mfma_coexec"] - 0.25) < 1e-12
+    assert (k["wait_any"], k["wait_inst"], k["active"]) == (0.5, 0.3, 0.2)
+    import bench
+    assert t["kernel_source_stamp"] == bench.kernel_source_stamp()
