@@ -44,10 +44,8 @@ __device__ __forceinline__ int member_key(int l, int p, const float4 *ms, const 
 
 // bq != nullptr: the batch is opened in the same launch (labels remembered, members marked) -- the count then takes every labelled sample and the batch's own entries are subtracted again, so
 // that neither part reads what the other writes.
-// (ckey, optional: the nearest-centre keys of the positions [ck_lo, ck_hi) are reset to ~0 for the coming query-norm launch)
 __global__ void count_base_kernel(const int *labels, int *inb, int N, int B, int *cnt, const int *bq, int K,
-                                  int *lab_old, const float4 *ms, const float *shell_inv, int nsh,
-                                  unsigned long long *ckey, int ck_lo, int ck_hi, Gate gate)
+                                  int *lab_old, const float4 *ms, const float *shell_inv, int nsh, Gate gate)
 {
     CHB_GATE(gate);
     extern __shared__ int hist[];
@@ -70,7 +68,6 @@ __global__ void count_base_kernel(const int *labels, int *inb, int N, int B, int
             lab_old[i] = l;
             inb[p] = i;
             if (l >= 0 && l < B) atomicSub(&hist[member_key(l, p, ms, shell_inv, nsh)], 1);
-            if (ckey != nullptr && i >= ck_lo && i < ck_hi) ckey[i - ck_lo] = ~0ull;
         }
     }
     __syncthreads();
@@ -679,7 +676,7 @@ void launch_batch_close(int *labels, int *inb, const int *bq, const int *lab, in
 void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int *bin_ptr,
                         int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s, const int *open_bq,
                         int open_K, int *open_lab_old, const SegPlan *seg, int *stats, const void *ms,
-                        const float *shell_inv, int nsh, unsigned long long *ckey, int ck_lo, int ck_hi)
+                        const float *shell_inv, int nsh)
 {
     // (cnt is all zero here: allocated zeroed, and scan_kernel clears what it has read; cnt / cursor hold B * nsh keys)
     if (ms == nullptr || shell_inv == nullptr || nsh < 1) nsh = 1;
@@ -687,7 +684,7 @@ void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int
     int blocks = (N + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(count_base_kernel, dim3(blocks), dim3(256), B * nsh * sizeof(int), s, labels, inb, N, B, cnt, open_bq,
-                       open_K, open_lab_old, ms4, shell_inv, nsh, ckey, ck_lo, ck_hi, g_gate);
+                       open_K, open_lab_old, ms4, shell_inv, nsh, g_gate);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, s, cnt, B, nsh, bin_ptr, cursor, pad_ptr, zero_me,
                        seg ? *seg : SegPlan{}, stats, g_gate);
     hipLaunchKernelGGL(fill_base_kernel, dim3((N + 255) / 256), dim3(256), 2 * B * nsh * sizeof(int), s, labels, inb, N, B,

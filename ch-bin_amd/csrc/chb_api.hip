@@ -223,7 +223,7 @@ struct chb_ctx {
     DevBuf<unsigned int> rmax;
     double shadow_scale = 1.0;         // S
     PackBufs pk, pk2;                  // padded member packs: base members, the batch's own entries
-    DevBuf<float> qn;                  // [B][Kcap] float2 exact query-to-centre norms
+    DevBuf<float> qn;                  // [N][B] float2 exact sample-to-centre norms (per fit)
     DevBuf<double> centers;
     int Dz = 0;
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
@@ -412,11 +412,9 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->nflag.ensure(1));
         launch_fill_i32(h->flags64.p, 0, (int)(B * ((K + kQTile - 1) / kQTile)), h->stream);   // kept zero by its consumer
         HIPCHK(h->overflow.ensure(1));
-        HIPCHK(h->qn.ensure(K * B * 2));
         HIPCHK(h->pk.ensure((size_t)h->N + 32 * B, B, (size_t)h->Dz));
         HIPCHK(h->pk2.ensure(2 * K + 32 * B, B, (size_t)h->Dz));
         h->seg_gcap = (int)std::min<size_t>(64, B / 4 + 1);
-        HIPCHK(h->ckey.ensure(K));
         HIPCHK(h->qord.ensure(K));
         HIPCHK(h->home.ensure(B));
         HIPCHK(h->seg_nseg.ensure(1));
@@ -493,6 +491,10 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m, bool sy
         launch_bin_centers(h->X.p, h->D, h->Dp, h->memb_id.p, h->bin_ptr.p, h->B, h->centers.p, h->stream);
         launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
                              h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, nullptr, nullptr, h->stream);
+        // every sample's exact norm against every (fixed) centre, and its nearest centre: once per fit, not per batch
+        HIPCHK(h->qn.ensure((size_t)h->N * (size_t)B * 2));
+        HIPCHK(h->ckey.ensure((size_t)h->N));
+        launch_query_norms(h->X.p, h->D, h->Dp, (int)h->N, h->B, h->centers.p, h->shadow_scale, h->qn.p, h->ckey.p, h->stream);
         // the unit of the CSR's shell key per bin (from the initially labelled members; fixed for the fit)
         int nsh = kShells;
         while (nsh > 1 && (int64_t)B * nsh > kMaxKeys) nsh >>= 1;
@@ -582,8 +584,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         // query norms computed: one launch instead of count + scan + fill + gather
         Timed t(h, "bucket", (double)K);
         launch_pack_state_start(h->pack_state(), h->pk.view(), h->D, h->Dz, h->labels.p, h->inb.p, h->bq_cur, K, h->lab_old.p,
-                                h->B, sp.gflag ? &sp : nullptr, h->fc_cur + 1, h->nflag.p, h->X.p, h->Dp, q_lo, q_hi, h->Kcap,
-                                h->centers.p, h->shadow_scale, h->qn.p, s);
+                                h->B, sp.gflag ? &sp : nullptr, h->fc_cur + 1, h->nflag.p, s);
         h->stats_pp_batches += 1;
     } else {
         // (the batch is opened -- labels remembered, members marked -- inside the CSR count's launch)
@@ -591,8 +592,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p,
                            h->cursor.p, h->memb_id.p, h->pk.pad_ptr.p, h->nflag.p, s, h->bq_cur, K, h->lab_old.p,
                            sp.gflag ? &sp : nullptr, h->fc_cur + 1, pf_base_path ? h->ms.p : nullptr,
-                           skip_on ? h->shell_inv.p : nullptr, skip_on ? h->nsh : 1,
-                           skip_on ? h->ckey.p : nullptr, q_lo, q_hi);
+                           skip_on ? h->shell_inv.p : nullptr, skip_on ? h->nsh : 1);
     }
     TopmArgs a{};
     a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = q_lo; a.pos_end = q_hi;
@@ -608,13 +608,11 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         (void)nq64;   // (flags64 is all zero here: launch_topm_flagged clears what it serves)
         if (!h->overflow_total_valid) { launch_fill_i32(h->overflow.p, 0, 1, s); h->overflow_total_valid = true; }
         if (!pp_now) {
-            // the members' shadow rows (relative to their bin's centre) gathered into padded CSR order, the per-bin
-            // bounds, and the batch's query-to-centre norms: one launch
+            // the members' shadow rows (relative to their bin's centre) gathered into padded CSR order, and the per-bin
+            // bounds: one launch
             Timed t(h, "bucket", 0.0);
-            launch_pack_build(h->Zs.p, h->ms.p, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->pk.view(), h->X.p,
-                              h->D, h->Dp, h->bq_cur, q_lo, q_hi, h->Kcap, h->centers.p, h->shadow_scale, h->qn.p, s,
-                              skip_on ? h->ckey.p : nullptr);
-            if (skip_on) launch_query_order(h->ckey.p, q_lo, q_hi, h->B, h->qord.p, h->home.p, s);
+            launch_pack_build(h->Zs.p, h->ms.p, h->D, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->pk.view(), skip_on, s);
+            if (skip_on) launch_query_order(h->ckey.p, h->bq_cur, q_lo, q_hi, h->B, h->qord.p, h->home.p, s);
         }
         ShortlistArgs pa{};
         pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
@@ -703,11 +701,9 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
                         herr[1], herr[2], herr[3], q_lo, q_hi, (int)skip_on);
                 if (herr[0] >= 5 && skip_on && q_hi - q_lo <= 256) {
                     const int nq = q_hi - q_lo;
-                    std::vector<unsigned long long> ck(nq); std::vector<int> qo(nq);
-                    HIPCHK(hipMemcpy(ck.data(), h->ckey.p, 8 * (size_t)nq, hipMemcpyDeviceToHost));
+                    std::vector<int> qo(nq);
                     HIPCHK(hipMemcpy(qo.data(), h->qord.p, 4 * (size_t)nq, hipMemcpyDeviceToHost));
-                    for (int i = 0; i < nq; ++i)
-                        fprintf(stderr, "  i %d key bin %d bits %08x  qord %d\n", i, (int)(ck[i] & 0xffffffffu), (unsigned)(ck[i] >> 32), qo[i]);
+                    for (int i = 0; i < nq; ++i) fprintf(stderr, "  i %d qord %d\n", i, qo[i]);
                 }
                 return fail(CHB_ESTATE, "shortlist validation failed");
             }

@@ -105,17 +105,18 @@ void launch_sample_shadow(const double *X, int D, int Dp, const int *ids, int n,
 void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, const int *memb_code,
                           const int *bin_ptr, int B, int rows_hint, const double *centers, const double *mu_g,
                           double S, int Dz, const MemberPack &P, hipStream_t s);
-// Three independent pieces of a batch start in ONE launch (each too small to fill the chip on its own): the base
-// members' shadow rows (CSR; P.pad_ptr from launch_bucket_base) gathered into the padded pack; the per-bin bounds
-// P.bb; qn[B][Kcap] = float2 {||(x_j - mu_c) S||^2 rounded up, rounded down} of the batch's queries
-void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
-                       int B, int rows_hint, const MemberPack &P, const double *X, int D, int Dp, const int *bq,
-                       int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s,
-                       unsigned long long *ckey = nullptr);
-// (ckey, optional: [pos_end - pos_begin], pre-set to ~0 by the caller: the query-norm tiles leave {N_jc bits, bin} of every
-//  position's nearest bin centre there)
-// qord[0 .. pos_end - pos_begin) = the positions sorted by the bin of their key (positions without a key last)
-void launch_query_order(const unsigned long long *ckey, int pos_begin, int pos_end, int B, int *qord, int *home, hipStream_t s);
+// Two independent pieces of a batch start in ONE launch (each too small to fill the chip on its own): the base
+// members' shadow rows (CSR; P.pad_ptr from launch_bucket_base) gathered into the padded pack, and the per-bin bounds
+// P.bb (shells: the CSR is in shell order -- the tile-skipping build)
+void launch_pack_build(const unsigned short *Zs, const void *ms, int D, int Dz, const int *memb_id, const int *bin_ptr,
+                       int B, int rows_hint, const MemberPack &P, bool shells, hipStream_t s);
+// Once per fit (the bin centres are fixed for the fit): qn[N][B] = float2 {||(x_j - mu_c) S||^2 rounded up, rounded down}
+// of EVERY sample against every bin centre; ckey (optional, [N]) = {N_jc bits, bin} of every sample's nearest bin centre
+void launch_query_norms(const double *X, int D, int Dp, int N, int B, const double *centers, double S, void *qn,
+                        unsigned long long *ckey, hipStream_t s);
+// qord[0 .. pos_end - pos_begin) = the positions sorted by the bin of their sample's key (samples without a key last)
+void launch_query_order(const unsigned long long *ckey, const int *bq, int pos_begin, int pos_end, int B, int *qord, int *home,
+                        hipStream_t s);
 
 // Plan of the bins that are cut into segments for the shortlist stage (see shortlist_kernel, SEG): made on the device
 // by the CSR scan of the batch start, consumed by the three shortlist launches of the batch.
@@ -134,7 +135,7 @@ constexpr int kSegLenTiles = 128;   // shortest segment (a bin has at most 16)
 struct ShortlistArgs {
     const unsigned short *Gs;  // [N][Dz] query-side rows
     const float2 *gq;          // [N]
-    const float2 *qn;          // [B][Kcap]
+    const float2 *qn;          // [N][B] (per fit: launch_query_norms)
     MemberPack P;
     int Dz;
     double S;
@@ -187,11 +188,10 @@ void launch_pack_state_build(const PackState &ps, const MemberPack &P, const uns
                              const int *memb_id, const int *bin_ptr, int B, int N, int grow, hipStream_t s);
 // (grow: rows every region gets at least -- what a bin is expected to hold once the unlabelled contigs are in)
 // batch start: the batch is opened (labels remembered, members marked, their rows turned into holes), the tiles per bin,
-// bin-size statistics and segment plan are written, and the batch's query norms computed: one launch
+// bin-size statistics and segment plan are written: one launch
 void launch_pack_state_start(const PackState &ps, const MemberPack &P, int D, int Dz, const int *labels, int *inb,
                              const int *open_bq, int open_K, int *open_lab_old, int B, const SegPlan *seg, int *stats,
-                             int *zero_me, const double *X, int Dp, int pos_begin, int pos_end, int Kcap,
-                             const double *centers, double S, void *qn, hipStream_t s);
+                             int *zero_me, hipStream_t s);
 // batch commit: launch_sample_shadow's commit form, which also puts every committed sample's row back into the pack (in
 // place when its label is the one it was removed under, else appended to its new bin), then the regions that ran full are
 // moved to larger ones
@@ -310,9 +310,7 @@ void launch_bucket_base(const int *labels, int *inb, int N, int B, int *cnt, int
                         int *cursor, int *memb_id, int *pad_ptr, int *zero_me, hipStream_t s,
                         const int *open_bq = nullptr, int open_K = 0, int *open_lab_old = nullptr,
                         const SegPlan *seg = nullptr, int *stats = nullptr, const void *ms = nullptr,
-                        const float *shell_inv = nullptr, int nsh = 1, unsigned long long *ckey = nullptr, int ck_lo = 0,
-                        int ck_hi = 0);
-// (ckey, optional, with open_bq: nearest-centre keys of the batch positions [ck_lo, ck_hi) reset to ~0)
+                        const float *shell_inv = nullptr, int nsh = 1);
 // (stats: [4] ints -- tiles of the largest bin, tiles of all bins, and two counters zeroed here for the shortlist launch)
 // (ms + shell_inv + nsh > 1, optional: the members of a bin are grouped by SHELLS of their distance from the bin's centre,
 //  outermost first -- cnt / cursor then hold B * nsh entries; see member_key in aux_kernels.hip)

@@ -448,25 +448,27 @@ __device__ __forceinline__ void bin_bounds_from_source(const float4 *ms, const i
     if (threadIdx.x == 0) bb[c] = make_float4(red[0][0], sqrtf(red[1][0]) * (1.0f + 1e-6f), red[2][0], red[3][0]);
 }
 
-// qn[c][pos] = ||(x_j - mu_c) S||^2 in fp64, rounded {up, down}.  A 32 positions x 64 bins tile per
-// block, features staged through LDS 16 at a time (already scaled by S: exact, and keeps tiny
-// feature scales away from underflow); each thread owns a 2 x 4 micro-tile.
+// qn[j][c] = ||(x_j - mu_c) S||^2 in fp64, rounded {up, down}, for every sample j and bin c: the centres are fixed for
+// the whole fit, so this is computed ONCE per fit (fit_begin_impl) instead of per batch for the batch's positions (up to
+// round 4 these tiles rode in every batch-start launch: 12 us on the critical path of each of the 13 batches of a sweep
+// at 100k x 64, and the same work again every sweep).  A 32 samples x 64 bins tile per block, features staged through
+// LDS 16 at a time (already scaled by S: exact, and keeps tiny feature scales away from underflow); each thread owns a
+// 2 x 4 micro-tile.
 struct QnArgs {
     const double *X;
     int D, Dp;
-    const int *bq;
-    int pos_begin, pos_end, B, Kcap;
+    int N, B;
     const double *centers;
     double S;
-    float2 *qn;
-    unsigned long long *ckey;   // optional, [pos_end - pos_begin] (pre-set to ~0): 64-bit minimum of {N_jc bits, bin} over the
-                                // bins = the position's nearest bin centre (the shortlist launch's query order)
+    float2 *qn;                 // [N][B]
+    unsigned long long *ckey;   // optional, [N] (pre-set to ~0): 64-bit minimum of {N_jc bits, bin} over the bins = the
+                                // sample's nearest bin centre (the tile-skipping shortlist launch's query order)
 };
 
 __device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, int tile_y)
 {
-    const double *X = q.X; const int D = q.D, Dp = q.Dp; const int *bq = q.bq;
-    const int pos_begin = q.pos_begin, pos_end = q.pos_end, B = q.B, Kcap = q.Kcap;
+    const double *X = q.X; const int D = q.D, Dp = q.Dp;
+    const int pos_begin = 0, pos_end = q.N, B = q.B;
     const double *centers = q.centers; const double S = q.S; float2 *qn = q.qn;
     constexpr int KC = 16;
     __shared__ double xs[32][KC + 1], cs[64][KC + 1];
@@ -475,7 +477,7 @@ __device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, in
     // staging roles: centre row tid / 4 with four consecutive features, query row tid / 8 with two
     const int crow_i = tid >> 2, ck = (tid & 3) * 4;
     const int xrow_i = tid >> 3, xk = (tid & 7) * 2;
-    const double *xrow = p0 + xrow_i < pos_end ? X + (size_t)bq[p0 + xrow_i] * Dp : nullptr;
+    const double *xrow = p0 + xrow_i < pos_end ? X + (size_t)(p0 + xrow_i) * Dp : nullptr;
     const double *crow = c0 + crow_i < B ? centers + (size_t)(c0 + crow_i) * Dp : nullptr;
     double acc[2][4];
 #pragma unroll
@@ -530,8 +532,8 @@ __device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, in
         for (int j = 0; j < 4; ++j) {
             const int pos = p0 + 2 * ty + i, c = c0 + tx + 16 * j;
             if (pos < pos_end && c < B)
-                qn[(size_t)c * Kcap + pos] = make_float2(round_up_f32(acc[i][j] * (1.0 + 1e-12)),
-                                                        (float)(acc[i][j] * (1.0 - 1e-6)));
+                qn[(size_t)pos * B + c] = make_float2(round_up_f32(acc[i][j] * (1.0 + 1e-12)),
+                                                     (float)(acc[i][j] * (1.0 - 1e-6)));
         }
     if (q.ckey != nullptr) {
         // nearest centre of my two positions among this tile's 64 bins: 4 bins here, 16 lanes (tx) per position
@@ -563,8 +565,8 @@ __device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, in
 // home[b] = the query tile (of kPfQ seats) where the positions nearest to bin b start: the shortlist launch runs the
 // query tiles of a bin from there on, wrapping round -- the long work items of a bin (its own neighbourhood) first, the
 // short ones (far queries, most of their tiles skipped) last, so that the launch does not end on long ones.
-__global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long long *ckey, int pos_begin, int nq, int B,
-                                                           int *qord, int *home, Gate gate)
+__global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long long *ckey, const int *bq, int pos_begin,
+                                                           int nq, int B, int *qord, int *home, Gate gate)
 {
     CHB_GATE(gate);
     extern __shared__ int sh[];   // [B + 1] counts -> cursors, [1024] scan partials
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long l
     for (int b = tid; b <= B; b += 1024) cnt[b] = 0;
     __syncthreads();
     for (int i = tid; i < nq; i += 1024) {
-        const unsigned long long k = ckey[i];
+        const unsigned long long k = ckey[bq[pos_begin + i]];
         const unsigned c = (unsigned)(k & 0xffffffffu);
         atomicAdd(&cnt[(k != ~0ull && c < (unsigned)B) ? (int)c : B], 1);
     }
@@ -610,24 +612,28 @@ __global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long l
     }
     __syncthreads();
     for (int i = tid; i < nq; i += 1024) {
-        const unsigned long long k = ckey[i];
+        const unsigned long long k = ckey[bq[pos_begin + i]];
         const unsigned c = (unsigned)(k & 0xffffffffu);
         qord[atomicAdd(&cnt[(k != ~0ull && c < (unsigned)B) ? (int)c : B], 1)] = pos_begin + i;
     }
 }
 
-// One launch for three independent pieces of a batch start (each used to be a launch of its own, each too small to fill
+__global__ __launch_bounds__(256) void query_norms_kernel(QnArgs q, int nqx)
+{
+    query_norms_tile(q, (int)blockIdx.x % nqx, (int)blockIdx.x / nqx);
+}
+
+// One launch for two independent pieces of a batch start (each used to be a launch of its own, each too small to fill
 // the chip): blocks [0, npack) gather the base members' shadow rows into the padded pack (pack_rows_block); blocks
-// [npack, npack + B) reduce the per-bin bounds from the same source rows; the rest are the query-norm tiles.
-__global__ __launch_bounds__(256) void pack_build_kernel(const unsigned short *Zs, const float4 *ms, int Dz,
+// [npack, npack + B) reduce the per-bin bounds from the same source rows.
+__global__ __launch_bounds__(256) void pack_build_kernel(const unsigned short *Zs, const float4 *ms, int D, int Dz,
                                                          const int *memb_id, const int *bin_ptr, const int *pad_ptr,
-                                                         int B, MemberPack P, int npack, QnArgs q, int nqx, Gate gate)
+                                                         int B, MemberPack P, int npack, bool shells, Gate gate)
 {
     CHB_GATE(gate);
     const int b = blockIdx.x;
-    if (b < npack) pack_rows_block(Zs, q.D, Dz, memb_id, bin_ptr, pad_ptr, B, P, b, npack);
-    else if (b < npack + B) bin_bounds_from_source(ms, memb_id, bin_ptr, b - npack, P.bb, P.tsn, pad_ptr[b - npack], q.ckey != nullptr);
-    else query_norms_tile(q, (b - npack - B) % nqx, (b - npack - B) / nqx);
+    if (b < npack) pack_rows_block(Zs, D, Dz, memb_id, bin_ptr, pad_ptr, B, P, b, npack);
+    else bin_bounds_from_source(ms, memb_id, bin_ptr, b - npack, P.bb, P.tsn, pad_ptr[b - npack], shells);
 }
 
 
@@ -732,11 +738,10 @@ __global__ __launch_bounds__(256) void pack_state_build_kernel(PackState ps, Mem
 }
 
 // batch start in one launch: block 0 = the plan (tiles per bin, statistics, segment plan: what scan_kernel does for the
-// rebuilt pack), blocks [1, 1 + nopen) open the batch, the rest are the query-norm tiles
+// rebuilt pack), blocks [1, 1 + nopen) open the batch
 __global__ __launch_bounds__(256) void pack_state_start_kernel(PackState ps, MemberPack P, int D, int Dz, const int *labels,
                                                                int *inb, const int *bq, int K, int *lab_old, int B,
-                                                               SegPlan seg, int *stats, int *zero_me, int nopen, QnArgs q,
-                                                               int nqx, Gate gate)
+                                                               SegPlan seg, int *stats, int *zero_me, Gate gate)
 {
     CHB_GATE(gate);
     const int b = blockIdx.x;
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(256) void pack_state_start_kernel(PackState ps, Mem
         }
         return;
     }
-    if (b < 1 + nopen) {
+    {
         extern __shared__ int gone[];   // [B] members this block takes out of each bin (one global atomic per block and bin)
         for (int c = threadIdx.x; c < B; c += 256) gone[c] = 0;
         __syncthreads();
@@ -801,9 +806,7 @@ __global__ __launch_bounds__(256) void pack_state_start_kernel(PackState ps, Mem
         __syncthreads();
         for (int c = threadIdx.x; c < B; c += 256)
             if (gone[c] > 0) atomicSub(&ps.live[c], gone[c]);
-        return;
     }
-    query_norms_tile(q, (b - 1 - nopen) % nqx, (b - 1 - nopen) / nqx);
 }
 
 // Where every committed sample's row goes, decided for 256 samples per block so that a bin's row counter sees ONE atomic
@@ -1183,8 +1186,8 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     if (kSeated && h == 0) sQpos[32 * w + col] = qpos;
     f16x8 qreg[KS];
     float nq, rg;
+    const int sidx = a.bq[qvalid ? qpos : a.pos_end - 1];
     {
-        const int sidx = a.bq[qvalid ? qpos : a.pos_end - 1];
         const unsigned short *zq = a.Gs + (size_t)sidx * (KS * 16) + h * 8;
 #pragma unroll
         for (int sx = 0; sx < KS; ++sx) qreg[sx] = *reinterpret_cast<const f16x8 *>(zq + sx * 16);
@@ -1325,7 +1328,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
         // ---- per-(query, bin) bounds
         float4 bb = a.P.bb[c];                            // {rho_bin, snb, Bmax, -}
         if (UPD) bb.y = sqrtf(bb.y) * (1.0f + 1e-6f);     // (the batch-entry pack accumulates the largest ||zh||^2)
-        const float2 qn2 = a.qn[slot];                    // N_jc {up, down}
+        const float2 qn2 = a.qn[(size_t)sidx * a.B + c];  // N_jc {up, down}
         // base mode: bias exact up to the measured residual of its pieces (2 r_c on T = N - 2 acc); update mode: bias
         // rounded to fp32 (2^-24 Bmax)
         const float E = ((UPD ? 1.2e-7f * bb.z : 2.0f * bb.w) + a.gamma * (1.001f * bb.z + 2.0f * snq * bb.y)) *
@@ -1903,27 +1906,32 @@ void launch_pack_centered(const double *X, int D, int Dp, const int *memb_id, co
                        P.pad_ptr, centers, mu_g, S, Dz, P, g_gate);   // (bounds: into P.bb, zeroed by the batch-CSR kernel)
 }
 
-void launch_query_order(const unsigned long long *ckey, int pos_begin, int pos_end, int B, int *qord, int *home, hipStream_t s)
+void launch_query_order(const unsigned long long *ckey, const int *bq, int pos_begin, int pos_end, int B, int *qord, int *home,
+                        hipStream_t s)
 {
     if (pos_end > pos_begin)
-        hipLaunchKernelGGL(query_order_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 1 + 1024), s, ckey, pos_begin,
-                           pos_end - pos_begin, B, qord, home, g_gate);
+        hipLaunchKernelGGL(query_order_kernel, dim3(1), dim3(1024), sizeof(int) * ((size_t)B + 1 + 1024), s, ckey, bq,
+                           pos_begin, pos_end - pos_begin, B, qord, home, g_gate);
 }
 
-void launch_pack_build(const unsigned short *Zs, const void *ms, int Dz, const int *memb_id, const int *bin_ptr,
-                       int B, int rows_hint, const MemberPack &P, const double *X, int D, int Dp, const int *bq,
-                       int pos_begin, int pos_end, int Kcap, const double *centers, double S, void *qn, hipStream_t s,
-                       unsigned long long *ckey)
+void launch_query_norms(const double *X, int D, int Dp, int N, int B, const double *centers, double S, void *qn,
+                        unsigned long long *ckey, hipStream_t s)
+{
+    if (N <= 0 || B <= 0) return;
+    if (ckey != nullptr) (void)hipMemsetAsync(ckey, 0xFF, sizeof(unsigned long long) * (size_t)N, s);
+    const int nqx = (N + 31) / 32, nqy = (B + 63) / 64;
+    const QnArgs q{X, D, Dp, N, B, centers, S, reinterpret_cast<float2 *>(qn), ckey};
+    hipLaunchKernelGGL(query_norms_kernel, dim3((unsigned)nqx * (unsigned)nqy), dim3(256), 0, s, q, nqx);
+}
+
+void launch_pack_build(const unsigned short *Zs, const void *ms, int D, int Dz, const int *memb_id, const int *bin_ptr,
+                       int B, int rows_hint, const MemberPack &P, bool shells, hipStream_t s)
 {
     if (B <= 0) return;
     const long long rows = (long long)rows_hint + 32LL * B;
     const int npack = (int)std::max<long long>(1, std::min<long long>((rows + 15) / 16, 16384));
-    const int nq = pos_end - pos_begin;
-    const int nqx = nq > 0 ? (nq + 31) / 32 : 0, nqy = (B + 63) / 64;
-    const QnArgs q{X, D, Dp, bq, pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn), ckey};
-    hipLaunchKernelGGL(pack_build_kernel, dim3(npack + B + nqx * nqy), dim3(256), 0, s, Zs,
-                       reinterpret_cast<const float4 *>(ms), Dz, memb_id, bin_ptr, P.pad_ptr, B, P, npack, q,
-                       std::max(nqx, 1), g_gate);
+    hipLaunchKernelGGL(pack_build_kernel, dim3(npack + B), dim3(256), 0, s, Zs, reinterpret_cast<const float4 *>(ms), D, Dz,
+                       memb_id, bin_ptr, P.pad_ptr, B, P, npack, shells, g_gate);
 }
 
 void launch_pack_state_build(const PackState &ps, const MemberPack &P, const unsigned short *Zs, const void *ms, int D, int Dz,
@@ -1940,17 +1948,12 @@ void launch_pack_state_build(const PackState &ps, const MemberPack &P, const uns
 
 void launch_pack_state_start(const PackState &ps, const MemberPack &P, int D, int Dz, const int *labels, int *inb,
                              const int *open_bq, int open_K, int *open_lab_old, int B, const SegPlan *seg, int *stats,
-                             int *zero_me, const double *X, int Dp, int pos_begin, int pos_end, int Kcap,
-                             const double *centers, double S, void *qn, hipStream_t s)
+                             int *zero_me, hipStream_t s)
 {
     if (B <= 0) return;
     const int nopen = (open_K + 255) / 256;
-    const int nq = pos_end - pos_begin;
-    const int nqx = nq > 0 ? (nq + 31) / 32 : 0, nqy = (B + 63) / 64;
-    const QnArgs q{X, D, Dp, open_bq, pos_begin, pos_end, B, Kcap, centers, S, reinterpret_cast<float2 *>(qn), nullptr};
-    hipLaunchKernelGGL(pack_state_start_kernel, dim3(1 + nopen + nqx * nqy), dim3(256), (size_t)B * sizeof(int), s, ps, P, D, Dz, labels, inb,
-                       open_bq, open_K, open_lab_old, B, seg ? *seg : SegPlan{}, stats, zero_me, nopen, q, std::max(nqx, 1),
-                       g_gate);
+    hipLaunchKernelGGL(pack_state_start_kernel, dim3(1 + nopen), dim3(256), (size_t)B * sizeof(int), s, ps, P, D, Dz, labels,
+                       inb, open_bq, open_K, open_lab_old, B, seg ? *seg : SegPlan{}, stats, zero_me, g_gate);
 }
 
 void launch_pack_state_commit(const PackState &ps, const MemberPack &P, const double *X, int D, int Dp, const int *ids, int n,
