@@ -580,8 +580,8 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
     if (!pp_now) h->pp_valid = false;   // (this batch's commit will not maintain the pack)
     h->pp_batch = pp_now;
     if (pp_now) {
-        // the batch is opened (its members' rows become holes), tiles per bin / statistics / segment plan written and the
-        // query norms computed: one launch instead of count + scan + fill + gather
+        // the batch is opened (its members' rows become holes) and tiles per bin / statistics / segment plan written:
+        // one launch instead of count + scan + fill + gather
         Timed t(h, "bucket", (double)K);
         launch_pack_state_start(h->pack_state(), h->pk.view(), h->D, h->Dz, h->labels.p, h->inb.p, h->bq_cur, K, h->lab_old.p,
                                 h->B, sp.gflag ? &sp : nullptr, h->fc_cur + 1, h->nflag.p, s);
