@@ -746,7 +746,7 @@ int batch_round_dev(chb_ctx *h, int active)
                                  h->centers.p, h->mu_g.p, h->shadow_scale, h->Dz, h->pk2.view(), s);
             ShortlistArgs pa{};
             pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
-            pa.qn = reinterpret_cast<const float2 *>(h->qn.p);   // built at batch start
+            pa.qn = reinterpret_cast<const float2 *>(h->qn.p);   // (the fit's table)
             pa.P = h->pk2.view(); pa.Dz = h->Dz; pa.S = h->shadow_scale;
             pa.bq = h->bq_cur; pa.pos_begin = lo; pa.pos_end = hi;
             pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.update = true;
@@ -841,7 +841,7 @@ int batch_round_dev(chb_ctx *h, int active)
                                  h->centers.p, h->mu_g.p, h->shadow_scale, h->Dz, h->pk2.view(), s);
             ShortlistArgs pa{};
             pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
-            pa.qn = reinterpret_cast<const float2 *>(h->qn.p);   // built at batch start
+            pa.qn = reinterpret_cast<const float2 *>(h->qn.p);   // (the fit's table)
             pa.P = h->pk2.view(); pa.Dz = h->Dz; pa.S = h->shadow_scale;
             pa.bq = h->bq_cur; pa.pos_begin = lo; pa.pos_end = hi;
             pa.bin_ptr = h->bin_ptr2.p; pa.memb_id = h->memb2_id.p; pa.update = true;

@@ -14,7 +14,7 @@
 //                        rho_p = ||zh_p - (x_p - mu_c) S||   measured exactly when the row is built
 //                        bias_p = ||zh_p||^2 + 2 <(mu_c - mu_g) S, zh_p>
 //   query j (any bin) :  qh_j = fp16((x_j - mu_g) S),  rho_j = ||qh_j - (x_j - mu_g) S||   (once per fit)
-//   query j vs bin c  :  N_jc = ||(x_j - mu_c) S||^2 in fp64 (query_norms_kernel, once per batch)
+//   query j vs bin c  :  N_jc = ||(x_j - mu_c) S||^2 in fp64 (query_norms_kernel, once per fit, for every sample)
 // Members are centred on their own bin, so their rounding error is relative to the within-bin spread
 // whatever the absolute scale of the features; the query keeps ONE row for all bins.
 //
