@@ -50,17 +50,48 @@ def gather_ceiling_gbs(table_mb):
     return pts[-1][1]
 
 
+def _code_only(text):
+    """C++ source without comments, whitespace runs collapsed (string / character literals kept as they are)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            if out and out[-1] != " ":
+                out.append(" ")
+            i = n if j < 0 else j + 2
+        elif c.isspace():
+            if out and out[-1] != " ":
+                out.append(" ")
+            i += 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out).strip()
+
+
 def kernel_source_stamp():
-    """sha256 over the kernel sources: profiles/*_traffic.json carries the stamp of the build it was measured on, and
-    its numbers are only quoted while the sources are still the same."""
+    """sha256 over the kernel sources' CODE (comments and layout do not count): profiles/*_traffic.json carries the stamp
+    of the build it was measured on, and its numbers are only quoted while the code is still the same."""
     import glob
     import hashlib
     hh = hashlib.sha256()
     src = os.path.join(ROOT, "ch-bin_amd", "csrc")
     for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
         hh.update(os.path.basename(f).encode())
-        hh.update(open(f, "rb").read())
+        hh.update(_code_only(open(f, "r", encoding="utf-8", errors="replace").read()).encode())
     return hh.hexdigest()[:16]
+
+
 FP64_PEAK_TFLOPS = 78.6        # fp64 vector == matrix peak (AMD public spec; the local guide lists no fp64 row)
 
 # BASELINE.json configs: index -> (contigs, dim, bins)

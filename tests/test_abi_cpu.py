@@ -113,3 +113,27 @@ def test_traffic_table_formulas(tmp_path):
     assert (k["wait_any"], k["wait_inst"], k["active"]) == (0.5, 0.3, 0.2)
     import bench
     assert t["kernel_source_stamp"] == bench.kernel_source_stamp()
+
+
+def test_source_stamp_ignores_comments_and_layout():
+    """bench.kernel_source_stamp() hashes the kernels' CODE: a reworded comment or a re-wrapped line must not retire
+    the committed counter tables, a changed token must."""
+    import bench
+    a = 'int a = 1; // one\n/* block\n x */ const char *s = "// kept /* kept */ \\"q"; char c = \'"\';   int b;\n'
+    b = 'int a = 1;   // two words\nconst char *s = "// kept /* kept */ \\"q";\nchar c = \'"\'; int b; // tail\n'
+    assert bench._code_only(a) == bench._code_only(b) == 'int a = 1; const char *s = "// kept /* kept */ \\"q"; char c = \'"\'; int b;'
+    assert bench._code_only(a) != bench._code_only(a.replace("a = 1", "a = 2"))
+    assert bench._code_only('x = "a  b";') == 'x = "a  b";'   # (literals keep their spacing)
+
+
+def test_committed_traffic_tables_match_the_sources():
+    """profiles/r04_*traffic.json (what bench.py quotes as roofline.traffic / roofline.limiter) were measured on the
+    kernel code as committed."""
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("r04_traffic.json", "r04_m15_traffic.json"):
+        t = json.load(open(os.path.join(root, "profiles", name)))
+        if t["kernel_source_stamp"] != bench.kernel_source_stamp():
+            # (not a failure: bench.py then leaves roofline.traffic / limiter out and says why)
+            pytest.skip(f"profiles/{name} was measured on other kernel code: re-run tools/collect_profiles.sh + copy_profiles.sh")
