@@ -26,7 +26,7 @@ import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import kernel_source_stamp  # noqa: E402  (bench.py quotes the table only for byte-identical kernel sources)
+from bench import kernel_source_stamp  # noqa: E402  (bench.py quotes the table only for the same kernel code (comments and layout aside))
 
 src, prefix = sys.argv[1], sys.argv[2]
 exclude = sys.argv[sys.argv.index("--exclude") + 1] if "--exclude" in sys.argv else None
