@@ -315,7 +315,7 @@ def main():
                     "rounds_per_rank_last_step": [v["rounds_last_step"] for v in allv]}
 
     # ---- untimed pass with an event pair around every kernel: the full table
-    names = ("prefilter", "rescore", "prefilter_update", "rescore_update", "query_norms", "topm_fallback", "topm_base",
+    names = ("prefilter", "rescore", "prefilter_update", "rescore_update", "query_norms", "fit_start", "topm_fallback", "topm_base",
              "topm_update", "hull_qp", "slow_path", "argmin", "bucket")
     prof_steps = max(1, min(args.steps, 3))
     ctx.profile_reset()
@@ -383,7 +383,7 @@ def main():
                     kern.append(gather_entry(name, p, 8.0 * m * D, "pair",
                                              "exact cdist-rounded distances on the shortlists (at least the m winners' "
                                              "rows have to be read); " + gather_note))
-            for name in ("prefilter_update", "query_norms", "topm_fallback", "slow_path", "argmin", "bucket"):
+            for name in ("prefilter_update", "query_norms", "fit_start", "topm_fallback", "slow_path", "argmin", "bucket"):
                 p = pr.get(name)
                 if p and p["launches"]:
                     kern.append({"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,

@@ -486,15 +486,21 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m, bool sy
         // (the seeds), fixed for the whole fit -- any fixed point keeps the bounds valid, one near
         // the bin keeps them tight.  Then every labelled sample's shadow row against its own bin.
         HIPCHK(h->centers.ensure((size_t)B * h->Dp));
-        launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p,
-                           h->memb_id.p, nullptr, nullptr, h->stream);
-        launch_bin_centers(h->X.p, h->D, h->Dp, h->memb_id.p, h->bin_ptr.p, h->B, h->centers.p, h->stream);
-        launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
-                             h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, nullptr, nullptr, h->stream);
+        {
+            Timed t(h, "fit_start", (double)h->N);
+            launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p,
+                               h->memb_id.p, nullptr, nullptr, h->stream);
+            launch_bin_centers(h->X.p, h->D, h->Dp, h->memb_id.p, h->bin_ptr.p, h->B, h->centers.p, h->stream);
+            launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
+                                 h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, nullptr, nullptr, h->stream);
+        }
         // every sample's exact norm against every (fixed) centre, and its nearest centre: once per fit, not per batch
         HIPCHK(h->qn.ensure((size_t)h->N * (size_t)B * 2));
         HIPCHK(h->ckey.ensure((size_t)h->N));
-        launch_query_norms(h->X.p, h->D, h->Dp, (int)h->N, h->B, h->centers.p, h->shadow_scale, h->qn.p, h->ckey.p, h->stream);
+        {
+            Timed t(h, "query_norms", (double)h->N * (double)B);
+            launch_query_norms(h->X.p, h->D, h->Dp, (int)h->N, h->B, h->centers.p, h->shadow_scale, h->qn.p, h->ckey.p, h->stream);
+        }
         // the unit of the CSR's shell key per bin (from the initially labelled members; fixed for the fit)
         int nsh = kShells;
         while (nsh > 1 && (int64_t)B * nsh > kMaxKeys) nsh >>= 1;
@@ -532,12 +538,15 @@ int pack_state_build(chb_ctx *h)
     { const size_t had = h->pp_ctl.cap; HIPCHK(h->pp_ctl.ensure(4)); if (!had) HIPCHK(hipMemsetAsync(h->pp_ctl.p, 0, 4 * sizeof(int), h->stream)); }
     HIPCHK(h->pp_ovf.ensure((size_t)std::max(h->Kcap, 1)));
     HIPCHK(h->pp_dest.ensure((size_t)std::max(h->Kcap, 1)));
-    launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p, h->memb_id.p, nullptr,
-                       nullptr, h->stream);
     // (room to grow: were all N samples labelled and spread evenly, a bin would hold N / B rows -- half as much again)
     const int grow = (int)std::min<int64_t>((3 * h->N / 2) / std::max<int64_t>(h->B, 1) + 64, 0x3fffffff);
-    launch_pack_state_build(h->pack_state(), h->pk.view(), h->Zs.p, h->ms.p, h->D, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B,
-                            (int)h->N, grow, h->stream);
+    {
+        Timed t(h, "bucket", (double)h->N);
+        launch_bucket_base(h->labels.p, h->inb.p, (int)h->N, h->B, h->cnt.p, h->bin_ptr.p, h->cursor.p, h->memb_id.p, nullptr,
+                           nullptr, h->stream);
+        launch_pack_state_build(h->pack_state(), h->pk.view(), h->Zs.p, h->ms.p, h->D, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B,
+                                (int)h->N, grow, h->stream);
+    }
     HIPCHK(hipGetLastError());
     h->pp_valid = true; h->pp_rebuild = false;
     h->stats_pp_builds += 1;

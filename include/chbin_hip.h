@@ -194,7 +194,8 @@ int chb_kmer_frequencies(chb_ctx *h, const unsigned char *seq, const int64_t *of
  * event records per batch, cheap enough to leave on inside a timed region) */
 int chb_profile_enable(chb_ctx *h, int on);
 int chb_profile_reset(chb_ctx *h);
-/* kernel: "prefilter" | "prefilter_update" | "rescore" | "rescore_update" | "query_norms" |
+/* kernel: "prefilter" | "prefilter_update" | "rescore" | "rescore_update" | "query_norms" (once per fit) |
+ * "fit_start" (bin centres + every labelled sample's shadow row, once per fit) |
  * "topm_fallback" | "topm_base" | "topm_update" | "hull_qp" | "slow_path" | "argmin" | "bucket" |
  * "pairwise" | "kmer_count".  For m <= 16 "hull_qp" is the fused selection + hull-distance kernel and
  * "slow_path" the exact path for what it leaves over; "rescore*" then only appear for m > 16 or CHB_FUSED=0. */
