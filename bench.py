@@ -11,8 +11,10 @@ HBM before the timed region; labels/permutation cross the boundary every step ex
 reference's call does.  `value` = hull distances the sequential loop needs / wall time
 (speculative re-evaluations are NOT counted as work).
 
-The timed steps carry HIP events only around the two dominant kernels (four event records per
-batch); the full per-kernel table comes from a separate, untimed pass of the same steps.
+The LAST timed step carries HIP events around every launch of the two dominant kernels (four event records
+per batch: the roofline's live launch durations; a pair costs the stream about 8 us, 0.2 ms of a 10 ms step, so the
+other timed steps run without them -- `--kernel-events-every-step` keeps them on); the full per-kernel table comes
+from a separate, untimed pass of the same steps.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -171,6 +173,9 @@ def main():
                     help="PMC traffic table to quote instead of profiles/%s (tools/collect_profiles.sh: the table it has "
                          "just measured on this very build)" % TRAFFIC_FILE)
     ap.add_argument("--no-kernel-events", action="store_true", help="dev: no HIP events at all in the timed steps")
+    ap.add_argument("--kernel-events-every-step", action="store_true",
+                    help="HIP events around the two dominant kernels in EVERY timed step instead of the last one only "
+                         "(an event pair costs the stream ~8 us per launch: 0.2 ms of a 10 ms step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (dev: gloo)")
     ap.add_argument("--same-gpu", action="store_true", help="dev only: all ranks on cuda:0")
     ap.add_argument("--allow-fallback", action="store_true",
@@ -280,10 +285,16 @@ def main():
     for _ in range(args.warmup):
         labels1 = one_step()
     ctx.profile_reset()
-    ctx.profile_enable(0 if args.no_kernel_events else 2)    # events around the two dominant kernels only
+    # (the event pairs around the two dominant kernels -- the roofline's live launch durations -- cost the stream about
+    #  8 us per launch, 0.2 ms of a 10 ms step: they are recorded in the LAST timed step only, i.e. around every launch
+    #  of one whole sweep; --kernel-events-every-step keeps them on throughout)
+    event_steps = 0 if args.no_kernel_events else (args.steps if args.kernel_events_every_step else min(1, args.steps))
+    ctx.profile_enable(2 if event_steps == args.steps and event_steps > 0 else 0)    # events around the two dominant kernels only
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if 0 < event_steps < args.steps and i == args.steps - event_steps:
+            ctx.profile_enable(2)
         labels1 = one_step()
     sync()
     dt = time.perf_counter() - t0
@@ -480,8 +491,9 @@ def main():
         if timed:
             timed.sort(key=lambda k: -k["total_ms"])
             roofline = dict(timed[0])
-            roofline["ms_per_step"] = roofline["total_ms"] / max(args.steps, 1)
-            roofline["measured"] = "HIP events on the library's stream inside the timed steps"
+            roofline["ms_per_step"] = roofline["total_ms"] / max(event_steps, 1)
+            roofline["measured"] = ("HIP events on the library's stream around every launch of the kernel in the last %d of "
+                                    "the %d timed steps" % (event_steps, args.steps))
             if roofline["kernel"] in traffic:
                 roofline["traffic"], roofline["traffic_source"] = traffic[roofline["kernel"]]
             elif traffic_note:
@@ -489,7 +501,7 @@ def main():
             roofline["limiter"] = limiter_of(roofline)
             if len(timed) > 1:
                 o = timed[1]
-                roofline["runner_up"] = {"kernel": o["kernel"], "ms_per_step": o["total_ms"] / max(args.steps, 1),
+                roofline["runner_up"] = {"kernel": o["kernel"], "ms_per_step": o["total_ms"] / max(event_steps, 1),
                                          "frac": o["frac"], "bound": o["bound"], "unit": o["unit"],
                                          "achieved": o["achieved"], "peak": o["peak"], "limiter": limiter_of(o)}
         # whole-path view in SURVEY 8(d)'s no-reuse gather model against the HBM spec: every hull distance the
