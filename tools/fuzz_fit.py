@@ -1,6 +1,7 @@
 """Developer soak: random small configurations, HIP fit_cluster vs the CPU oracle (labels, sweep
 counts, per-sweep change counts must be identical).  usage: python tools/fuzz_fit.py [n_cases] [seed] [big|m16]   (big: bins of > 512 members, few bins; m16: the fused
-16-lane kernel, 6 <= m <= 16)"""
+16-lane kernel, 6 <= m <= 16; manybins: 65 .. 400 bins of a handful of members -- more than one 64-bin tile of the
+per-fit query-norm table)"""
 import os
 import sys
 
@@ -14,6 +15,7 @@ from oracle import oracle as O  # noqa: E402
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 m16 = len(sys.argv) > 3 and sys.argv[3] == "m16"
+manybins = len(sys.argv) > 3 and sys.argv[3] == "manybins"
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ctx = _lib.default_context()
 bad = 0
@@ -38,6 +40,10 @@ for t in range(n_cases):
         N = int(rng.integers(200, 1100)); m = int(rng.integers(6, 17)); D = int(rng.choice([24, 40, 100, 136, 140, 146, 160]))
         S = 1 if D < 140 else (5 if D < 146 else 10)
         iters = int(rng.integers(1, 4)); n_seed = int(rng.integers(1, 24))
+    if manybins:
+        N = int(rng.integers(2000, 5000)); B = int(rng.integers(65, 400)); m = int(rng.choice([1, 3, 5, 5]))
+        D = int(rng.choice([100, 136, 140, 146])); S = 1 if D < 140 else (5 if D < 146 else 10)
+        iters = int(rng.integers(1, 3)); batch = int(rng.choice([0, 300, 1000])); n_seed = int(rng.integers(1, 4))
     metric = str(rng.choice(["convex", "convex", "convex", "affine"]))
     if m > D or D < 24 or (D < 40 and m > 8):   # (round 4, case `120 91 m16` #101: 14 vertices in D = 24 straddle orth's cutoff too)
         # m > D: the affine hull of > D generic points is the whole space, every distance is rounding

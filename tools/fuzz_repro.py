@@ -13,6 +13,7 @@ from oracle import oracle as O  # noqa: E402
 index, seed = int(sys.argv[1]), int(sys.argv[2])
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
 big, m16 = mode == "big", mode == "m16"
+manybins = mode == "manybins"
 rng = np.random.default_rng(seed)
 for t in range(index + 1):
     N = int(rng.integers(200, 1800))
@@ -34,6 +35,10 @@ for t in range(index + 1):
         N = int(rng.integers(200, 1100)); m = int(rng.integers(6, 17)); D = int(rng.choice([24, 40, 100, 136, 140, 146, 160]))
         S = 1 if D < 140 else (5 if D < 146 else 10)
         iters = int(rng.integers(1, 4)); n_seed = int(rng.integers(1, 24))
+    if manybins:
+        N = int(rng.integers(2000, 5000)); B = int(rng.integers(65, 400)); m = int(rng.choice([1, 3, 5, 5]))
+        D = int(rng.choice([100, 136, 140, 146])); S = 1 if D < 140 else (5 if D < 146 else 10)
+        iters = int(rng.integers(1, 3)); batch = int(rng.choice([0, 300, 1000])); n_seed = int(rng.integers(1, 4))
     metric = str(rng.choice(["convex", "convex", "convex", "affine"]))
     if m > D or D < 24 or (D < 40 and m > 8):   # (round 4, case `120 91 m16` #101: 14 vertices in D = 24 straddle orth's cutoff too)
         metric = "convex"
