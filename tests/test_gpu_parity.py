@@ -159,6 +159,25 @@ def test_hull_distance_golden_qp_problems(ctx, O, golden_dir):
         x, P = g["x"][k], g["P"][k][:m]
         d = clustering.calculate_distance(x, P, "quadprog", "convex")
         assert abs(d - g["dist_with_oracle_gi"][k]) < QP_TOL
+    # ... and against numbers NO solver of this repository produced: the reference's own calculate_distance with scipy's
+    # SLSQP answering quadprog.solve_qp (qp_args_slsqp.npz; north-star tolerance 1e-5, observed maximum 2.2e-9)
+    s = np.load(os.path.join(golden_dir, "qp_args_slsqp.npz"))
+    worst = max(abs(clustering.calculate_distance(g["x"][k], g["P"][k][:int(g["m"][k])], "quadprog", "convex") -
+                    s["dist_with_slsqp"][k]) for k in range(len(g["m"])))
+    assert worst < 1e-5 and worst < 1e-8, worst
+
+
+def test_hull_distance_loop_problems_of_the_reference_with_a_second_solver(ctx, golden_dir):
+    """504 (contig, bin) evaluations sampled from the reference's own fit_cluster loop on the 600-contig case, with the
+    member sets the reference's find_nearest_from_cluster selected and the distances its calculate_distance returned
+    while scipy's SLSQP answered quadprog.solve_qp (fit_cluster_flow_slsqp.npz): the indexed hull kernel on the same
+    rows.  North-star tolerance 1e-5; observed maximum ~1e-15."""
+    f = np.load(os.path.join(golden_dir, "fit_cluster_flow.npz"))
+    t = np.load(os.path.join(golden_dir, "fit_cluster_flow_slsqp.npz"))
+    ctx.set_samples(f["X"])
+    d = ctx.hull_distance_batch(t["loop_query"], t["loop_hull"])
+    worst = float(np.abs(d - t["loop_dist_slsqp"]).max())
+    assert worst < 1e-5 and worst < 1e-11, worst
 
 
 def test_hull_distance_batch_indexed(ctx, O):

@@ -83,6 +83,31 @@ def test_fit_cluster_flow_does_not_depend_on_the_solver(golden_dir):
     assert np.array_equal(labels, s["labels_slsqp"])
 
 
+def test_distances_against_numbers_a_second_solver_produced(golden_dir):
+    """Distances that a solver OTHER than the oracle's Goldfarb-Idnani produced, through the reference's own glue
+    (hull_distance.py:7-35 imported unchanged, scipy's SLSQP answering quadprog.solve_qp on the reference's tuple;
+    tests/golden/make_golden_second_solver.py): the 24 captured hull problems of qp_args.npz and every 45th of the 22,680
+    (contig, bin) evaluations of the reference's loop on the 600-contig case.  North-star tolerance 1e-5; observed
+    maxima 2.2e-9 (qp_args: random points in D = 136, SLSQP's own stopping accuracy) and 4e-16 (loop problems)."""
+    g = _load(golden_dir, "qp_args.npz")
+    s = _load(golden_dir, "qp_args_slsqp.npz")
+    worst = 0.0
+    for k in range(len(g["m"])):
+        m = int(g["m"][k])
+        d = O.convex_hull_distance(g["x"][k], g["P"][k][:m])
+        worst = max(worst, abs(d - s["dist_with_slsqp"][k]))
+        assert abs(O.enum_hull_distance(g["x"][k], g["P"][k][:m]) - s["dist_with_slsqp"][k]) < 1e-5
+    assert worst < 1e-5 and worst < 1e-8, worst
+    f = _load(golden_dir, "fit_cluster_flow.npz")
+    t = _load(golden_dir, "fit_cluster_flow_slsqp.npz")
+    assert len(t["loop_query"]) == 504
+    X, worst = f["X"], 0.0
+    for q, h, c, d in zip(t["loop_query"], t["loop_hull"], t["loop_bin"], t["loop_dist_slsqp"]):
+        h = h[h >= 0]
+        worst = max(worst, abs(O.convex_hull_distance(X[q], X[h]) - d))
+    assert worst < 1e-5 and worst < 1e-12, worst
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_gi_vs_enumerator_random(seed):
     rng = np.random.default_rng(seed)
