@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 # MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_PEAK_GBS = 6290.0     # the measured-copy peak BASELINE.md 3 also quotes the path figure against
 F16_PEAK_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak
 TRAFFIC_FILE = "r04_traffic.json"   # rocprofv3 --pmc passes of this round (tools/traffic_from_pmc.py); m > 5: r04_m15_traffic.json
 # MI355X_MICROARCH.md: indexed rows out of an L2-resident table gather at 16.8-18.8 TB/s chip-wide (mid-point); L2 aggregate 34.5
@@ -508,7 +509,10 @@ def main():
         # sweep needs x bytes_QP over the sweep's wall time (the north star's 40 % target is on this figure)
         path_roofline = {"bound": "hbm", "achieved": value * bytes_qp / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": value * bytes_qp / 1e9 / HBM_PEAK_GBS,
-                         "bytes_per_qp": bytes_qp}
+                         "bytes_per_qp": bytes_qp,
+                         # BASELINE.md 3 / SURVEY 8(d): the same figure against the measured-copy peak of the part
+                         "measured_copy_peak": HBM_COPY_PEAK_GBS,
+                         "frac_of_measured_copy_peak": value * bytes_qp / 1e9 / HBM_COPY_PEAK_GBS}
 
         # ---- end-to-end bin-assign wall clock (all sweeps until no label changes, max 10)
         e2e = None
@@ -538,6 +542,17 @@ def main():
                              f"against the full N={N} (oracle/chb_oracle.c:chbo_sweep, {cdt:.1f} s); "
                              "labels of the sample verified identical to the GPU's",
                    "host_cpus": os.cpu_count()}
+            # "at run time probe `import quadprog`; only if present also time genuine quadprog" -- and
+            # always quote the reference's own non-solver Python overhead beside the port's figure
+            try:
+                import quadprog  # noqa: F401
+                cpu["quadprog"] = "importable (not timed: the port above is the baseline this line reports)"
+            except Exception as e:  # noqa: BLE001
+                cpu["quadprog"] = f"unavailable ({type(e).__name__}): the reference's solver cannot be timed on this box"
+            cpu["reference_python_overhead_us_per_qp"] = 195
+            cpu["reference_python_overhead_source"] = ("SURVEY.md 8(a)/8(d): 124 us find_nearest_from_cluster + 71 us "
+                                                       "hull_distance glue per (contig, bin), measured with a no-op solver "
+                                                       "=> <= 5.1e3 QP/s per core for the reference, before quadprog")
             # same arithmetic on all the host cores this process may use: the sampled
             # contigs are evaluated independently against the frozen seed-state labels, so this times
             # the per-(contig, bin) work of a sweep in parallel; it is not itself a sequential sweep

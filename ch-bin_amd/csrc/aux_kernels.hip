@@ -381,6 +381,68 @@ __global__ void copy_i32_kernel(int *dst, const int *src, int n, Gate gate)
     if (i < n) dst[i] = src[i];
 }
 
+// ---- framed exchange of the sharded loop (chb_api.hip: open_batch / finish_round).  What a rank sends in a round's
+// all-gather is a FRAME: kXchgHdr header words -- {tag = exchange number of the fit << 4 | kind, wave-tiles skipped / seen /
+// never loaded by its base shortlist launch, fill mark of its persistent pack's arena, 0, 0, 0} -- followed by the C labels
+// of its slice.  Everything that steers the host loop (and with it the ORDER of the collectives) is then derived from what
+// ALL ranks sent: the statistics are summed / maximised over the frames before they travel home with the verdict, so every
+// rank takes the same decisions in the same batch; and a rank that is out of step (its tag differs) is noticed on the
+// device and fails the fit at the sweep's end instead of silently mixing label buffers.
+// (preset: slot[0] = K, the start value of the unpack kernel's first-change minimum -- this launch is ordered before the
+//  all-gather and the unpack launch on the stream)
+__global__ void xchg_pack_kernel(int *frames, int rank, int C, const int *src, int tag, int *slot, int with_stats,
+                                 int with_mark, int preset, int K, Gate gate)
+{
+    CHB_GATE(gate);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int *f = frames + (size_t)rank * (C + kXchgHdr);
+    if (i < C) f[kXchgHdr + i] = src[(size_t)rank * C + i];
+    if (i == 0) {
+        f[0] = tag;
+        f[1] = with_stats ? slot[3] : 0; f[2] = with_stats ? slot[4] : 0; f[3] = with_stats ? slot[5] : 0;
+        f[4] = with_mark ? slot[6] : 0;
+        f[5] = 0; f[6] = 0; f[7] = 0;
+        if (preset) slot[0] = K;
+    }
+}
+
+// labels of every rank's frame -> dst[pos]; round kind (lab_prev != nullptr): positions >= active are compared with
+// lab_prev (first change -> slot[0], preset to K by the pack launch) and then written to it; thread r < world checks rank
+// r's tag; with_stats: slot[3..5] = sums over the ranks, slot[6] = largest fill mark
+__global__ void xchg_unpack_kernel(const int *frames, int world, int C, int K, int tag, int *dst, int *lab_prev, int active,
+                                   int *slot, int with_stats, int *xerr, Gate gate)
+{
+    CHB_GATE(gate);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int F = C + kXchgHdr;
+    if (idx < world * C) {
+        const int r = idx / C, i = idx - r * C, pos = r * C + i;
+        if (pos < K) {
+            const int v = frames[(size_t)r * F + kXchgHdr + i];
+            if (lab_prev == nullptr) dst[pos] = v;
+            else if (pos >= active) {
+                if (v != lab_prev[pos]) atomicMin(slot, pos);
+                lab_prev[pos] = v;
+                dst[pos] = v;
+            }
+        }
+    }
+    if (idx < world) {
+        const int theirs = frames[(size_t)idx * F];
+        if (theirs != tag && atomicCAS(&xerr[0], 0, 1) == 0) { xerr[1] = tag; xerr[2] = theirs; xerr[3] = idx; }
+    }
+    if (idx == 0 && with_stats) {
+        int a = 0, b = 0, c = 0, mk = 0;
+        for (int r = 0; r < world; ++r) {
+            const int *f = frames + (size_t)r * F;
+            // (saturating: the sums only feed a ratio test)
+            a = (int)min(0x7fffffffll, (long long)a + f[1]); b = (int)min(0x7fffffffll, (long long)b + f[2]);
+            c = (int)min(0x7fffffffll, (long long)c + f[3]); mk = max(mk, f[4]);
+        }
+        slot[3] = a; slot[4] = b; slot[5] = c; slot[6] = mk;
+    }
+}
+
 // First-round label guess for batch members that carry no label yet (sweep 1): the bin of the
 // single nearest outside member.  Only a guess -- the rounds converge to the exact sequential
 // labels from any starting point; a good guess just saves a round.
@@ -584,6 +646,21 @@ void launch_first_change(const int *lab_new, const int *lab_prev, int p0, int K,
 void launch_copy_i32(int *dst, const int *src, int n, hipStream_t s)
 {
     if (n > 0) hipLaunchKernelGGL(copy_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n, g_gate);
+}
+
+void launch_xchg_pack(int *frames, int rank, int C, const int *src, int tag, int *slot, bool with_stats, bool with_mark,
+                      bool preset, int K, hipStream_t s)
+{
+    hipLaunchKernelGGL(xchg_pack_kernel, dim3((std::max(C, 1) + 255) / 256), dim3(256), 0, s, frames, rank, C, src, tag, slot,
+                       with_stats ? 1 : 0, with_mark ? 1 : 0, preset ? 1 : 0, K, g_gate);
+}
+
+void launch_xchg_unpack(const int *frames, int world, int C, int K, int tag, int *dst, int *lab_prev, int active, int *slot,
+                        bool with_stats, int *xerr, hipStream_t s)
+{
+    const int n = std::max(world * C, world);
+    hipLaunchKernelGGL(xchg_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, frames, world, C, K, tag, dst, lab_prev,
+                       active, slot, with_stats ? 1 : 0, xerr, g_gate);
 }
 
 void launch_compact_active(const int *cand_cnt, int pos_begin, int pos_end, int B, int Kcap, int *blk_cnt,

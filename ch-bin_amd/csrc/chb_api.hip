@@ -239,7 +239,12 @@ struct chb_ctx {
     // the shortlist stage's contract as checked by the fused kernels (FusedArgs::short_cnt): pairs of this fit whose base
     // shortlist held fewer than min(m, bin size) candidates or a wild index -- any is an internal error of the fit
     DevBuf<int> short_cnt;
-    DevBuf<int> agree;   // chb_bcast_samples: {status, N, D, root} of every rank
+    DevBuf<int> agree;   // chb_bcast_samples: {status, N, D, root} of every rank; chb_fit_cluster: the fit's agreement table
+    // framed exchange of the sharded loop (aux_kernels.hip: xchg_pack / xchg_unpack): every rank's {header, label slice},
+    // the number of the fit's next exchange (part of the tag every frame carries), and the device's "a rank was out of
+    // step" record {flag, my tag, its tag, rank}
+    DevBuf<int> xg, xerr;
+    int xseq = 0;
     int dev_inject_batches = 0;   // developer builds: batch starts of this context so far (CHB_SL_INJECT_SHORT)
 #ifdef CHB_DEV_KNOBS
     chb::ShortlistArgs dev_pa{}; bool dev_pa_valid = false;   // the open batch's base shortlist launch (CHB_DEV_OVERLAP)
@@ -291,6 +296,7 @@ struct chb_ctx {
     int64_t stats[4] = {0, 0, 0, 0};
     int64_t stats_seg_batches = 0;   // batches of the last fit that ran the segment launches
     int64_t stats_lookahead = 0;     // batches of the last fit whose successor was enqueued ahead of their verdict and kept
+    int64_t stats_lookahead_failed = 0;   // ... and discarded (the batch needed further rounds)
     // multi-GPU: one context per process per GPU, RCCL communicator over all ranks
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -380,6 +386,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->lab_new.ensure(Kpad));
     HIPCHK(h->first_change.ensure(16));
     h->fc_cur = h->first_change.p;
+    HIPCHK(h->xg.ensure(Kpad + (size_t)(kXchgHdr + 1) * (size_t)h->world));
+    { const size_t had = h->xerr.cap; HIPCHK(h->xerr.ensure(4)); if (!had) HIPCHK(hipMemsetAsync(h->xerr.p, 0, 4 * sizeof(int), h->stream)); }
     HIPCHK(h->mind.ensure(Kpad));
     HIPCHK(h->mind2.ensure(Kpad));
     HIPCHK(h->dist.ensure(K * B));
@@ -936,6 +944,62 @@ int batch_commit_dev(chb_ctx *h, const int *final_dev)
     return CHB_OK;
 }
 
+// Under an exchange the ranks run ONE fit together: the order of its collectives is a function of the arguments, of the
+// context's switches and of the tile-skipping memo -- so before the first batch every rank all-gathers what it was given
+// and how it is set up.  Arguments (and the formulation the switches select) must be equal: a difference fails the call on
+// EVERY rank with the same message instead of leaving some of them inside a collective.  What may legitimately differ --
+// the memo a context keeps from earlier fits, the A/B switches of the look-ahead, the tile skipping and the persistent
+// pack -- is settled by taking the most conservative value of all ranks for this fit.
+struct FitAgree {
+    static constexpr int W = 24, kEq = 16;
+    int v[W];
+};
+const char *const kAgreeNames[FitAgree::kEq] = {
+    "library", "num_clusters", "num_neighbors", "n_move", "max_iter", "batch size", "N", "D", "metric", "CHB_FUSED / fused path",
+    "CHB_PREFILTER / shortlist stage", "min_dist_out", "perms", "perms", "initial_bins", "initial_bins"};
+
+uint64_t hash_i64(const int64_t *p, int64_t n)
+{
+    // four independent multiply-xor lanes (the order of the elements matters, which is the point)
+    uint64_t a = 0x9e3779b97f4a7c15ull, b = 0xc2b2ae3d27d4eb4full, c = 0x165667b19e3779f9ull, d = 0x27d4eb2f165667c5ull;
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        a = (a ^ (uint64_t)p[i]) * 0x100000001b3ull;     b = (b ^ (uint64_t)p[i + 1]) * 0x100000001b3ull;
+        c = (c ^ (uint64_t)p[i + 2]) * 0x100000001b3ull; d = (d ^ (uint64_t)p[i + 3]) * 0x100000001b3ull;
+    }
+    for (; i < n; ++i) a = (a ^ (uint64_t)p[i]) * 0x100000001b3ull;
+    uint64_t x = a ^ (b * 3) ^ (c * 5) ^ (d * 7);
+    x ^= x >> 29; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 32;
+    return x;
+}
+
+// mine: this rank's table; on success `mine` holds the agreed table (equal entries as given, entries >= kEq the minimum
+// over the ranks)
+int fit_agree(chb_ctx *h, FitAgree *mine)
+{
+    constexpr int W = FitAgree::W;
+    const int world = h->world;
+    HIPCHK(h->agree.ensure((size_t)W * world));
+    std::vector<int> all((size_t)W * world, 0);
+    memcpy(all.data() + (size_t)W * h->rank, mine->v, sizeof(int) * W);
+    HIPCHK(hipMemcpyAsync(h->agree.p + (size_t)W * h->rank, mine->v, sizeof(int) * W, hipMemcpyHostToDevice, h->stream));
+    { const int r_ = exchange_all_gather(h, h->agree.p, (size_t)W, sizeof(int), ncclInt32); if (r_) return r_; }
+    HIPCHK(hipMemcpyAsync(all.data(), h->agree.p, sizeof(int) * all.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int r = 0; r < world; ++r)
+        for (int k = 0; k < FitAgree::kEq; ++k)
+            if (all[(size_t)W * r + k] != all[k])   // (against rank 0's: every rank then reports the same pair)
+                return fail(CHB_EINVAL, std::string("chb_fit_cluster: rank ") + std::to_string(r) + " and rank 0 differ in `" +
+                                        kAgreeNames[k] + "` -- every rank of the communicator must make the same call on the "
+                                        "same data with the same switches");
+    for (int k = FitAgree::kEq; k < W; ++k) {
+        int mn = all[k];
+        for (int r = 1; r < world; ++r) mn = std::min(mn, all[(size_t)W * r + k]);
+        mine->v[k] = mn;
+    }
+    return CHB_OK;
+}
+
 std::vector<int> to_i32(const int64_t *p, size_t n)
 {
     std::vector<int> v(n);
@@ -977,7 +1041,7 @@ int chb_create(int device_id, chb_ctx **out)
     if (const char *e = getenv("CHB_PF_UPDATE")) h->pf_update = atoi(e) != 0;
 #endif
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&h->fc_host, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->fc_host, 128, hipHostMallocDefault);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->fc_event[i], hipEventDisableTiming);
     if (const char *ev = getenv("CHB_SPECULATE")) h->speculate = atoi(ev) != 0;
     if (const char *ev = getenv("CHB_SEGMENTS")) h->allow_segments = atoi(ev) != 0;
@@ -1008,6 +1072,7 @@ int chb_destroy(chb_ctx *h)
     h->active.release(); h->n_active.release(); h->act_blk.release();
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
     h->slow.release(); h->n_slow.release(); h->tau.release(); h->short_cnt.release(); h->agree.release();
+    h->xg.release(); h->xerr.release();
     h->pp_start.release(); h->pp_cap.release(); h->pp_fill.release(); h->pp_live.release(); h->pp_nt.release();
     h->pp_memb.release(); h->pp_row.release(); h->pp_ctl.release(); h->pp_ovf.release(); h->pp_dest.release();
     h->seg_nseg.release(); h->seg_gflag.release(); h->seg_items.release(); h->seg_lists.release();
@@ -1320,7 +1385,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         if (lo < 0 || hi >= h->N) return fail(CHB_EINVAL, "perm entry out of range");
     }
     int rc = fit_begin_impl(h, B, initial_bins, m, /*sync=*/false);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }   // (an upload from pin_a may be in flight: the next call rewrites it)
     struct FitCloser {   // an error return must not leave an open fit / batch behind
         chb_ctx *h; bool ok = false;
         ~FitCloser() { if (!ok) { (void)hipStreamSynchronize(h->stream); h->fit_open = false; h->batch_open = false; } }
@@ -1343,7 +1408,41 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     hipStream_t s = h->stream;
     memset(h->stats, 0, sizeof(h->stats));
     h->stats_seg_batches = 0;
-    h->stats_lookahead = 0;
+    h->stats_lookahead = 0; h->stats_lookahead_failed = 0;
+
+    // ---- more than one rank: agree on the fit before its first collective (fit_agree above)
+    const bool xchg_fit = (h->comm != nullptr || h->hook != nullptr) && (h->world > 1 || h->force_gather);
+    struct SwitchRestore {   // (the agreed switches hold for this fit only)
+        chb_ctx *h; bool skip, pack, spec;
+        ~SwitchRestore() { h->allow_skip = skip; h->pp_allowed = pack; h->speculate = spec; }
+    } switch_restore{h, h->allow_skip, h->pp_allowed, h->speculate};
+    h->xseq = 0;
+    if (xchg_fit) {
+        FitAgree fa{};
+        const uint64_t hp = hash_i64(perms, (int64_t)max_iter * n_move), hi_ = hash_i64(initial_bins, h->N);
+        const int eq[FitAgree::kEq] = {0x43480005, (int)B, m, (int)(n_move & 0x7fffffff), max_iter, Kmax, (int)(h->N & 0x7fffffff),
+                                       h->D, h->metric, h->fused ? 1 : 0, h->pf_fit ? 1 : 0, min_dist_out ? 1 : 0,
+                                       (int)(hp & 0x7fffffff), (int)((hp >> 32) & 0x7fffffff), (int)(hi_ & 0x7fffffff),
+                                       (int)((hi_ >> 32) & 0x7fffffff)};
+        memcpy(fa.v, eq, sizeof(eq));
+        fa.v[16] = h->skip_state; fa.v[17] = h->speculate ? 1 : 0; fa.v[18] = h->allow_skip ? 1 : 0; fa.v[19] = h->pp_allowed ? 1 : 0;
+        rc = fit_agree(h, &fa);
+        if (rc) return rc;
+        h->skip_state = fa.v[16]; h->speculate = fa.v[17] != 0; h->allow_skip = fa.v[18] != 0; h->pp_allowed = fa.v[19] != 0;
+    }
+#ifdef CHB_DEV_KNOBS
+    // developer builds, tests of the exchange schedule (tests/test_gpu_world2.py): CHB_DEV_HOOK_SPEC=1 lets the look-ahead run
+    // over the host-staged hook (its exchanges synchronise the stream, so nothing is gained -- but the ORDER of the exchanges
+    // is the RCCL path's); CHB_DEV_SKIP_STATS=<skipped>,<seen>,<unloaded> replaces this rank's tile-skipping statistics of
+    // every batch; CHB_DEV_LOCAL_VERDICT=1 restores the behaviour before round 5 (every rank decides from its OWN statistics)
+    const bool dev_hook_spec = getenv("CHB_DEV_HOOK_SPEC") != nullptr && atoi(getenv("CHB_DEV_HOOK_SPEC")) != 0;
+    const bool dev_local_verdict = getenv("CHB_DEV_LOCAL_VERDICT") != nullptr && atoi(getenv("CHB_DEV_LOCAL_VERDICT")) != 0;
+    int dev_stats[3] = {0, 0, 0};
+    const bool dev_stats_on = getenv("CHB_DEV_SKIP_STATS") != nullptr &&
+                              sscanf(getenv("CHB_DEV_SKIP_STATS"), "%d,%d,%d", &dev_stats[0], &dev_stats[1], &dev_stats[2]) == 3;
+#else
+    const bool dev_hook_spec = false, dev_local_verdict = false;
+#endif
 
     // (fit_begin_impl left the converted initial labels in pin_a; their upload and the kernels of the fit's start are
     //  still running -- nothing below touches pin_a again before the sweep's final synchronisation)
@@ -1396,8 +1495,10 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         //  a round is computed on the device right behind it and feeds the same gate as on one GPU; every rank sees the same
         //  labels, hence the same verdict, and the all-gathers of a gated-off batch move identical bytes between the ranks'
         //  identical buffers.  The hook transport needs the host between rounds anyway.)
-        const bool can_spec = h->speculate && h->fused && (!xchg || (h->hook == nullptr && h->comm != nullptr)) &&
+        const bool can_spec = h->speculate && h->fused && (!xchg || (h->hook == nullptr && h->comm != nullptr) || dev_hook_spec) &&
                               min_dist_out == nullptr;
+        // the tag of the fit's next exchange (kind 1: a batch's label guess, 2: a round's labels)
+        auto next_tag = [&](int kind) { const int t = ((h->xseq & 0x7ffffff) << 4) | kind; h->xseq += 1; return t; };
         struct Geom { int64_t t0; int K, q_lo, q_hi, C; };
         auto geom_at = [&](int64_t t0) {
             // sweep 1 starts from few labelled members: do not let a batch outnumber them by much
@@ -1419,12 +1520,21 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         // after a round's kernels: (multi-GPU: exchange) + first-changed position on its way to the host
         auto finish_round = [&](const Geom &g, int active, int slot) -> int {
             if (xchg) {
-                { const int r_ = exchange_all_gather(h, h->lab_new.p, (size_t)g.C, sizeof(int), ncclInt32); if (r_) return r_; }
-                launch_fill_i32(h->fc_cur, g.K, 1, s);
-                launch_first_change(h->lab_new.p, h->lab_prev.p, active, g.K, h->fc_cur, s);
-                // positions [active, K) now carry this round's labels (single rank: the argmin kernel has already
-                // written them to lab_prev); a gated kernel, not a memcpy: inside a look-ahead window it must not run
-                launch_copy_i32(h->lab_prev.p + active, h->lab_new.p + active, g.K - active, s);
+                // this rank's frame {tag, statistics of the batch's base shortlist launch and pack, label slice} -> all-gather
+                // -> every rank's labels into lab_new / lab_prev, first changed position, statistics summed over the ranks
+                // (gated kernels, not memcpys: inside a look-ahead window they must not run; single rank without exchange:
+                // the argmin kernel has already written lab_prev).  What comes home in the verdict slot is then the SAME on
+                // every rank -- first change, bin sizes (functions of the replicated labels), skip statistics, arena mark --
+                // and with it every decision of this loop, in particular whether the next batch is enqueued ahead.
+                const int tag = next_tag(2);
+                const bool first = active == 0;
+#ifdef CHB_DEV_KNOBS
+                if (first && dev_stats_on) for (int k = 0; k < 3; ++k) launch_fill_i32(h->fc_cur + 3 + k, dev_stats[k], 1, s);
+#endif
+                launch_xchg_pack(h->xg.p, h->rank, g.C, h->lab_new.p, tag, h->fc_cur, first, first && h->pp_batch, true, g.K, s);
+                { const int r_ = exchange_all_gather(h, h->xg.p, (size_t)(g.C + kXchgHdr), sizeof(int), ncclInt32); if (r_) return r_; }
+                launch_xchg_unpack(h->xg.p, world, g.C, g.K, tag, h->lab_new.p, h->lab_prev.p, active, h->fc_cur,
+                                   first && !dev_local_verdict, h->xerr.p, s);
             }
             HIPCHK(hipMemcpyAsync(h->fc_host + 8 * slot, h->fc_cur, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(h->fc_event[slot], s));
@@ -1472,8 +1582,12 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             // (sweep 1) the bin whose m-th nearest outside member is closest
             if (h->fused && !h->lists_valid) launch_guess_near(h->tau.p, h->lab_old.p, g.q_lo, g.q_hi, h->B, h->Kcap, h->lab_prev.p, s);
             else launch_guess(h->l0d.p, h->l0c.p, h->lab_old.p, g.q_lo, g.q_hi, h->B, h->m, h->Kcap, h->lab_prev.p, s);
-            if (xchg)
-                { const int r_ = exchange_all_gather(h, h->lab_prev.p, (size_t)g.C, sizeof(int), ncclInt32); if (r_) return r_; }
+            if (xchg) {
+                const int tag = next_tag(1);
+                launch_xchg_pack(h->xg.p, h->rank, g.C, h->lab_prev.p, tag, h->fc_cur, false, false, false, g.K, s);
+                { const int r_ = exchange_all_gather(h, h->xg.p, (size_t)(g.C + kXchgHdr), sizeof(int), ncclInt32); if (r_) return r_; }
+                launch_xchg_unpack(h->xg.p, world, g.C, g.K, tag, h->lab_prev.p, nullptr, 0, h->fc_cur, false, h->xerr.p, s);
+            }
             r = batch_round_dev(h, 0);
             if (r) return r;
             return finish_round(g, 0, slot);
@@ -1532,7 +1646,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             if (rc) return rc;
             if (f < K) {
                 // the guess was off at position f: everything enqueued behind the gate has skipped itself
-                if (spec) { restore(snap); spec_ok = false; }
+                if (spec) { restore(snap); spec_ok = false; h->stats_lookahead_failed += 1; }
                 int active = f + 1;
                 while (active < K) {
                     rc = batch_round_dev(h, active);
@@ -1578,7 +1692,24 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         h->fc_host[15] = 0;
         if (h->pp_ctl.p)   // (fc_host[15]: the spare word of the second slot -- the persistent pack's error flag)
             HIPCHK(hipMemcpyAsync(h->fc_host + 15, h->pp_ctl.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+        std::vector<int> xend;
+        if (xchg) {
+            // every rank's "a rank was out of step" record: all ranks then leave the sweep with the same status
+            xend.assign((size_t)4 * world, 0);
+            HIPCHK(hipMemcpyAsync(h->agree.p + 4 * h->rank, h->xerr.p, 4 * sizeof(int), hipMemcpyDeviceToDevice, s));
+            { const int r_ = exchange_all_gather(h, h->agree.p, 4, sizeof(int), ncclInt32); if (r_) return r_; }
+            HIPCHK(hipMemcpyAsync(xend.data(), h->agree.p, sizeof(int) * xend.size(), hipMemcpyDeviceToHost, s));
+        }
         HIPCHK(hipStreamSynchronize(s));
+        for (int r = 0; r < (int)xend.size() / 4; ++r)
+            if (xend[(size_t)4 * r] != 0) {
+                HIPCHK(hipMemsetAsync(h->xerr.p, 0, 4 * sizeof(int), s));
+                const int *e = xend.data() + 4 * r;
+                return fail(CHB_ESTATE, "internal error: the ranks' exchanges fell out of step (rank " + std::to_string(r) + " was at exchange " +
+                                        std::to_string(e[1] >> 4) + " kind " + std::to_string(e[1] & 15) + " when rank " + std::to_string(e[3]) +
+                                        " sent exchange " + std::to_string(e[2] >> 4) + " kind " + std::to_string(e[2] & 15) +
+                                        "); labels not returned");
+            }
         if (h->fc_host[15] != 0)
             return fail(CHB_ESTATE, "internal error: the persistent member pack ran out of rows; labels not returned");
         if (h->fused && h->short_cnt.p && h->fc_host[7] != 0) {
@@ -1965,6 +2096,8 @@ int chb_counter(chb_ctx *h, const char *name, int64_t *out)
         return CHB_OK;
     }
     if (!strcmp(name, "lookahead_batches")) { *out = h->stats_lookahead; return CHB_OK; }
+    if (!strcmp(name, "lookahead_failed")) { *out = h->stats_lookahead_failed; return CHB_OK; }
+    if (!strcmp(name, "exchanges")) { *out = h->xseq; return CHB_OK; }
     if (!strcmp(name, "pack_incremental_batches")) { *out = h->stats_pp_batches; return CHB_OK; }
     if (!strcmp(name, "pack_builds")) { *out = h->stats_pp_builds; return CHB_OK; }
     if (!strcmp(name, "shortlist_short")) {   // pairs of the last fit that broke the shortlist stage's contract (0, or the fit failed)

@@ -332,6 +332,17 @@ void launch_guess(const double *list_d, const int *list_cnt, const int *lab_old,
 // members): the bin with the smallest one
 void launch_guess_near(const float *tau, const int *lab_old, int p0, int p1, int B, int Kcap, int *lab_prev,
                        hipStream_t s);
+// ---- framed exchange of the sharded loop (aux_kernels.hip): a rank's slice of a round's all-gather = kXchgHdr header
+// words {tag, skipped, seen, unloaded, arena mark, 0, 0, 0} + the C labels of its positions
+constexpr int kXchgHdr = 8;
+// frames[rank] <- header + src[rank * C .. + C); slot = the batch's verdict slot (statistics in slot[3..6]); preset: slot[0] = K
+void launch_xchg_pack(int *frames, int rank, int C, const int *src, int tag, int *slot, bool with_stats, bool with_mark,
+                      bool preset, int K, hipStream_t s);
+// dst[pos] <- every frame's labels (pos < K); lab_prev != nullptr: round form -- positions >= active compared with lab_prev
+// (first change -> slot[0]) and written to it; tags checked against `tag` (xerr[0..3] = {1, mine, theirs, rank} on the first
+// mismatch); with_stats: slot[3..5] = sums over the ranks' headers, slot[6] = their largest mark
+void launch_xchg_unpack(const int *frames, int world, int C, int K, int tag, int *dst, int *lab_prev, int active, int *slot,
+                        bool with_stats, int *xerr, hipStream_t s);
 // active[] = the pairs (pos - pos_begin) * B + bin whose cand_cnt is positive, *n_active their number
 // (blk_cnt: scratch, one int per 4096 pairs)
 void launch_compact_active(const int *cand_cnt, int pos_begin, int pos_end, int B, int Kcap, int *blk_cnt,

@@ -115,7 +115,8 @@ int chb_hull_distance_points(chb_ctx *h, const double *x, const double *pts, int
  *   perms[max_iter*n_move] the permutations algorithm.py:45 would draw, pre-drawn by the caller
  *                        from the legacy numpy RNG so the MT19937 stream matches ch_bin.py:22
  *   batch               speculative batch size (0 = default)
- *   labels_out[N], *iters_run, changed_per_iter[max_iter] (algorithm.py:63-68 counts),
+ *   labels_out[N], *iters_run, changed_per_iter[max_iter] (algorithm.py:63-68 counts); on an error return the
+ *                        contents of labels_out are undefined (it may hold an earlier sweep's labels),
  *   min_dist_out[N] (may be NULL): winning hull distance of each movable contig's last visit */
 int chb_fit_cluster(chb_ctx *h, int64_t B, const int64_t *initial_bins, const int64_t *perms,
                     int64_t n_move, int m, int max_iter, int batch, int64_t *labels_out,
@@ -150,7 +151,13 @@ int chb_fit_labels(chb_ctx *h, int64_t *labels_out);
  * 128-byte RCCL unique id, the host side broadcasts it (torch.distributed / MPI / files), every
  * rank calls chb_comm_init.  chb_fit_cluster then shards each speculative batch's positions over
  * the ranks and exchanges the label slices with RCCL all-gathers over xGMI; every rank must make
- * the same call with the same arguments and receives the same, complete result. */
+ * the same call with the same arguments and receives the same, complete result.  Before the first batch the ranks
+ * all-gather {B, m, n_move, max_iter, batch size, N, D, metric, formulation switches, hashes of perms and initial_bins}:
+ * a rank that was given something else makes the call fail with CHB_EINVAL on EVERY rank (nobody is left inside a
+ * collective); the switches that may differ per context (CHB_SPECULATE, CHB_TILE_SKIP, CHB_PACK_INCR, the tile-skipping
+ * memo of earlier fits) take their most conservative value of all ranks for that fit.  Every later exchange carries a
+ * {sequence number, kind} tag and the statistics that steer the loop, so that all ranks take the same decisions; ranks
+ * found out of step make the fit fail with CHB_ESTATE on every rank at the sweep's end. */
 int chb_comm_unique_id(char *out128);
 int chb_comm_init(chb_ctx *h, const char *id128, int rank, int world);
 int chb_comm_destroy(chb_ctx *h);
@@ -216,7 +223,9 @@ int chb_fit_stats(chb_ctx *h, int64_t *out4);
  * min(num_neighbors, members of the bin) candidates or with a wild index: always 0, or chb_fit_cluster has returned
  * CHB_ESTATE at the end of that sweep -- the product build checks the shortlist stage's contract in every fused hull
  * launch), "lookahead_batches" (batches of the last fit whose successor was enqueued ahead of their convergence verdict
- * and kept: on one GPU and, since round 4, under the RCCL exchange) */
+ * and kept: on one GPU and, since round 4, under the RCCL exchange), "lookahead_failed" (... and discarded because the
+ * batch needed further rounds), "exchanges" (framed all-gathers of the last fit under an exchange: one per batch for the
+ * label guess, one per round) */
 int chb_counter(chb_ctx *h, const char *name, int64_t *out);
 
 #ifdef __cplusplus

@@ -118,3 +118,115 @@ def test_bench_self_launch_two_ranks_one_gpu():
     assert j["n_gpus"] == 2 and j["value"] > 0
     ev = j["config"]["parallelism_evidence"]
     assert len(ev["hull_evaluated_per_rank_last_step"]) == 2 and all(v > 0 for v in ev["hull_evaluated_per_rank_last_step"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The ORDER of the exchanges under the look-ahead (round 5).  Under the RCCL transport a rank that looks ahead enqueues the
+# next batch's all-gathers before the current batch's verdict; whether it does depends on the tile-skipping verdict and on
+# the persistent pack's state, which up to round 4 every rank derived from its OWN launches' statistics: ranks on different
+# sides of the threshold issued their collectives in different orders (mixed label buffers, a hang at the sweep's end).
+# Now the statistics travel in the frames of the label all-gather and every rank decides from their sum.  RCCL cannot run
+# two ranks on one GPU, so the developer library lets the host-staged hook run the look-ahead path (CHB_DEV_HOOK_SPEC=1:
+# same order of exchanges, speculative ones included) and replaces a rank's statistics (CHB_DEV_SKIP_STATS), and the hook
+# of this test checks that all ranks are in the same exchange (equal byte counts) before it moves data.
+SCHED_WORKER = r"""
+import os, sys, datetime
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+stats = sys.argv[6].split(";")
+os.environ["CHB_DEV_SKIP_STATS"] = stats[min(rank, len(stats) - 1)]
+import torch
+import torch.distributed as dist
+import chbin_amd
+from chbin_amd import _lib, synth
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                        timeout=datetime.timedelta(seconds=25))
+calls = [0]
+
+def allgather(send):
+    calls[0] += 1
+    n = torch.tensor([send.size, calls[0]], dtype=torch.int64)
+    ns = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(ns, n)
+    if any(int(v[0]) != send.size for v in ns):
+        raise RuntimeError("ranks in different exchanges")
+    t = torch.from_numpy(send)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return torch.cat(outs).numpy()
+
+res = {"error": ""}
+try:
+    N, D, B, m, iters, batch = 6000, 140, 12, 5, 3, 96
+    X, initial, _ = synth.make_synthetic(N, D, B, S=5, seed=N + B, sigma=4e-3, mix=0.35, n_seed=40)
+    perms = synth.draw_permutations(initial, iters, seed=0)
+    ctx = _lib.Context(0)
+    ctx.comm_init_hook(rank, world, allgather)
+    ctx.set_samples(X)
+    lab, its, ch = ctx.fit_cluster(B, initial, perms, m, iters, batch=batch)
+    st = ctx.fit_stats()
+    res.update(lab=lab, its=its, batches=st["batches"], rounds=st["rounds"], lookahead=ctx.counter("lookahead_batches"),
+               skip_state=ctx.counter("tile_skip_state"), calls=calls[0], failed=ctx.counter("lookahead_failed"),
+               exchanges=ctx.counter("exchanges"))
+    ctx.comm_destroy()
+    ctx.close()
+except Exception as e:  # noqa: BLE001
+    res["error"] = repr(e)
+np.savez(out, **res)
+os._exit(0)     # (after a failed exchange the other rank may sit in a collective: no barrier, no destructor)
+"""
+
+
+def _run_sched(world, stats, extra_env):
+    root_dev = os.path.join(ROOT, "ch-bin_amd", "libchbin_hip_dev.so")
+    if not os.path.exists(root_dev):
+        pytest.skip("developer library not built")
+    with tempfile.TemporaryDirectory() as td:
+        script = os.path.join(td, "worker.py")
+        open(script, "w").write(SCHED_WORKER)
+        port = str(31500 + (os.getpid() + 13 * world + len(stats)) % 2000)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CHBIN_LIB=root_dev, CHB_DEV_HOOK_SPEC="1", **extra_env)
+        procs = [subprocess.Popen([sys.executable, script, ROOT, str(r), str(world), port, os.path.join(td, f"o{r}.npz"), stats],
+                                  env=env) for r in range(world)]
+        for p in procs:
+            p.wait(timeout=600)
+        return [dict(np.load(os.path.join(td, f"o{r}.npz"))) if os.path.exists(os.path.join(td, f"o{r}.npz")) else None
+                for r in range(world)]
+
+
+def _sched_oracle():
+    from oracle import oracle as O
+    import chbin_amd
+    X, initial, _ = chbin_amd.synth.make_synthetic(6000, 140, 12, S=5, seed=6012, sigma=4e-3, mix=0.35, n_seed=40)
+    perms = chbin_amd.synth.draw_permutations(initial, 3, seed=0)
+    return oracle_fit_replay(O, X, 12, initial, perms, 5, 3, key=("sched", 0))
+
+
+# rank 0 reports that its launch skipped everything, the others that theirs skipped nothing / (second case) nobody skips,
+# and rank 1's launches report no wave-tile at all (an empty shard counts its batches later)
+@pytest.mark.parametrize("world,stats", [(2, "1000,1000,1000;0,1000,0"), (3, "1000,1000,1000;0,1000,0"),
+                                         (2, "0,1000,0;0,0,0"), (3, "0,1000,0;0,0,0;0,2000,0")])
+def test_lookahead_schedule_is_the_same_on_every_rank(world, stats):
+    outs = _run_sched(world, stats, {})
+    want, its_o, _, _ = _sched_oracle()
+    for r, o in enumerate(outs):
+        assert o is not None and str(o["error"]) == "", (r, o and str(o["error"]))
+        assert int(o["its"]) == its_o and np.array_equal(o["lab"], want)
+        # look-aheads were kept AND failed (batches with more than one round), so speculative exchanges did go out
+        assert int(o["lookahead"]) > 0 and int(o["failed"]) > 0 and int(o["rounds"]) > int(o["batches"])
+        # (every speculative exchange of a discarded look-ahead went out as well: more exchanges than batches + rounds)
+        assert int(o["exchanges"]) >= int(o["batches"]) + int(o["rounds"]) + 2 * int(o["failed"])
+    for key in ("batches", "rounds", "lookahead", "failed", "skip_state", "calls", "exchanges"):
+        assert len({int(o[key]) for o in outs}) == 1, key                 # one schedule, one verdict
+    assert int(outs[0]["skip_state"]) == (1 if stats.startswith("1000") else -1)
+
+
+def test_per_rank_verdicts_do_break_the_schedule_and_are_caught():
+    """The behaviour before round 5 (CHB_DEV_LOCAL_VERDICT=1: every rank decides from its own statistics) on the same
+    inputs: the ranks end up in different exchanges -- the self-checking hook or the frames' tags notice it and the fit
+    FAILS on the ranks instead of returning mixed labels.  (What the RCCL transport would have done here is undefined.)"""
+    outs = _run_sched(2, "1000,1000,1000;0,1000,0", {"CHB_DEV_LOCAL_VERDICT": "1"})
+    errs = [None if o is None else str(o["error"]) for o in outs]
+    assert any(e is None or e != "" for e in errs), errs
+    assert any(e and ("out of step" in e or "exchange hook" in e) for e in errs), errs
