@@ -158,8 +158,9 @@ def allgather(send):
 
 res = {"error": ""}
 try:
-    N, D, B, m, iters, batch = 6000, 140, 12, 5, 3, 96
-    X, initial, _ = synth.make_synthetic(N, D, B, S=5, seed=N + B, sigma=4e-3, mix=0.35, n_seed=40)
+    N, D, B, S, m, iters, batch, n_seed = (int(v) for v in sys.argv[7].split(","))
+    sigma, mix = (float(v) for v in sys.argv[8].split(","))
+    X, initial, _ = synth.make_synthetic(N, D, B, S=S, seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
     perms = synth.draw_permutations(initial, iters, seed=0)
     ctx = _lib.Context(0)
     ctx.comm_init_hook(rank, world, allgather)
@@ -178,7 +179,11 @@ os._exit(0)     # (after a failed exchange the other rank may sit in a collectiv
 """
 
 
-def _run_sched(world, stats, extra_env):
+# bins that overlap enough for some batches to need further rounds (failed look-aheads) while others converge at once
+SCHED_DATA = ((3000, 136, 8, 1, 5, 3, 32, 8), (4.5e-3, 0.4))
+
+
+def _run_sched(world, stats, extra_env, data=SCHED_DATA):
     root_dev = os.path.join(ROOT, "ch-bin_amd", "libchbin_hip_dev.so")
     if not os.path.exists(root_dev):
         pytest.skip("developer library not built")
@@ -187,8 +192,9 @@ def _run_sched(world, stats, extra_env):
         open(script, "w").write(SCHED_WORKER)
         port = str(31500 + (os.getpid() + 13 * world + len(stats)) % 2000)
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CHBIN_LIB=root_dev, CHB_DEV_HOOK_SPEC="1", **extra_env)
-        procs = [subprocess.Popen([sys.executable, script, ROOT, str(r), str(world), port, os.path.join(td, f"o{r}.npz"), stats],
-                                  env=env) for r in range(world)]
+        procs = [subprocess.Popen([sys.executable, script, ROOT, str(r), str(world), port, os.path.join(td, f"o{r}.npz"), stats,
+                                   ",".join(str(v) for v in data[0]), ",".join(str(v) for v in data[1])], env=env)
+                 for r in range(world)]
         for p in procs:
             p.wait(timeout=600)
         return [dict(np.load(os.path.join(td, f"o{r}.npz"))) if os.path.exists(os.path.join(td, f"o{r}.npz")) else None
@@ -198,9 +204,10 @@ def _run_sched(world, stats, extra_env):
 def _sched_oracle():
     from oracle import oracle as O
     import chbin_amd
-    X, initial, _ = chbin_amd.synth.make_synthetic(6000, 140, 12, S=5, seed=6012, sigma=4e-3, mix=0.35, n_seed=40)
-    perms = chbin_amd.synth.draw_permutations(initial, 3, seed=0)
-    return oracle_fit_replay(O, X, 12, initial, perms, 5, 3, key=("sched", 0))
+    (N, D, B, S, m, iters, batch, n_seed), (sigma, mix) = SCHED_DATA
+    X, initial, _ = chbin_amd.synth.make_synthetic(N, D, B, S=S, seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
+    perms = chbin_amd.synth.draw_permutations(initial, iters, seed=0)
+    return oracle_fit_replay(O, X, B, initial, perms, m, iters, key=("sched", 0))
 
 
 # rank 0 reports that its launch skipped everything, the others that theirs skipped nothing / (second case) nobody skips,
@@ -226,7 +233,9 @@ def test_per_rank_verdicts_do_break_the_schedule_and_are_caught():
     """The behaviour before round 5 (CHB_DEV_LOCAL_VERDICT=1: every rank decides from its own statistics) on the same
     inputs: the ranks end up in different exchanges -- the self-checking hook or the frames' tags notice it and the fit
     FAILS on the ranks instead of returning mixed labels.  (What the RCCL transport would have done here is undefined.)"""
-    outs = _run_sched(2, "1000,1000,1000;0,1000,0", {"CHB_DEV_LOCAL_VERDICT": "1"})
+    # (CHB_PACK_REBUILD_AT=1: the rank that turned skipping off rebuilds its persistent pack at every batch start and so
+    #  never looks ahead -- the divergence of ONE batch that per-rank verdicts cause, made permanent)
+    outs = _run_sched(2, "1000,1000,1000;0,1000,0", {"CHB_DEV_LOCAL_VERDICT": "1", "CHB_PACK_REBUILD_AT": "1"})
     errs = [None if o is None else str(o["error"]) for o in outs]
     assert any(e is None or e != "" for e in errs), errs
     assert any(e and ("out of step" in e or "exchange hook" in e) for e in errs), errs
