@@ -328,7 +328,7 @@ def main():
 
     # ---- untimed pass with an event pair around every kernel: the full table
     names = ("prefilter", "rescore", "prefilter_update", "rescore_update", "query_norms", "fit_start", "topm_fallback", "topm_base",
-             "topm_update", "hull_qp", "slow_path", "argmin", "bucket")
+             "topm_update", "hull_qp", "slow_path", "argmin", "bucket", "pool", "prefilter_retry")
     prof_steps = max(1, min(args.steps, 3))
     ctx.profile_reset()
     ctx.profile_enable(1)
@@ -395,7 +395,7 @@ def main():
                     kern.append(gather_entry(name, p, 8.0 * m * D, "pair",
                                              "exact cdist-rounded distances on the shortlists (at least the m winners' "
                                              "rows have to be read); " + gather_note))
-            for name in ("prefilter_update", "query_norms", "fit_start", "topm_fallback", "slow_path", "argmin", "bucket"):
+            for name in ("prefilter_update", "query_norms", "fit_start", "topm_fallback", "slow_path", "argmin", "bucket", "pool", "prefilter_retry"):
                 p = pr.get(name)
                 if p and p["launches"]:
                     kern.append({"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS,
@@ -422,10 +422,12 @@ def main():
             tr = tj["kernels"]
             # (kernel names as rocprofv3 prints them: the shortlist kernel's template list has grown over the rounds)
             ml = 5 if m <= 5 else (8 if m <= 8 else 16)
-            tmap = {"prefilter": [f"shortlist_kernel<{ml}, false, 9, 0, false>", f"shortlist_kernel<{ml}, false, 9, 0>",
+            tmap = {"prefilter": [f"shortlist_kernel<{ml}, false, 9, 0, false, true>", f"shortlist_kernel<{ml}, false, 9, 0, false, false>",
+                                  f"shortlist_kernel<{ml}, false, 9, 0, false>", f"shortlist_kernel<{ml}, false, 9, 0>",
                                   f"shortlist_kernel<{ml}, false, 9>"],
                     "hull_qp": ["hull_select_qp_kernel<5, 7, 4, true>"] if m <= 5 else ["hull_select_qp16_kernel<4>"],
-                    "prefilter_update": [f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false>",
+                    "prefilter_update": [f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false, false>",
+                                         f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false>",
                                          "shortlist_kernel<1, true, 9, 0>", "shortlist_kernel<1, true, 9>"]}
             stamp = kernel_source_stamp()
             if tj.get("kernel_source_stamp") != stamp:

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void scan_kernel(int *cnt, int B, int nsh, int
         if (threadIdx.x == 0) {
             if (seg.nseg != nullptr) *seg.nseg = s_ni;
             // (stats[2], stats[3]: wave-tiles skipped / seen, accumulated by the coming shortlist launch)
-            if (stats != nullptr) { stats[0] = s_max_tiles; stats[1] = (int)tot_tiles; stats[2] = 0; stats[3] = 0; stats[4] = 0; }
+            if (stats != nullptr) { stats[0] = s_max_tiles; stats[1] = (int)tot_tiles; stats[2] = 0; stats[3] = 0; stats[4] = 0; stats[6] = 0; stats[7] = 0; }
         }
     }
 }
@@ -401,7 +401,7 @@ __global__ void xchg_pack_kernel(int *frames, int rank, int C, const int *src, i
         f[0] = tag;
         f[1] = with_stats ? slot[3] : 0; f[2] = with_stats ? slot[4] : 0; f[3] = with_stats ? slot[5] : 0;
         f[4] = with_mark ? slot[6] : 0;
-        f[5] = 0; f[6] = 0; f[7] = 0;
+        f[5] = with_stats ? slot[7] : 0; f[6] = with_stats ? slot[8] : 0; f[7] = 0;
         if (preset) slot[0] = K;
     }
 }
@@ -432,14 +432,15 @@ __global__ void xchg_unpack_kernel(const int *frames, int world, int C, int K, i
         if (theirs != tag && atomicCAS(&xerr[0], 0, 1) == 0) { xerr[1] = tag; xerr[2] = theirs; xerr[3] = idx; }
     }
     if (idx == 0 && with_stats) {
-        int a = 0, b = 0, c = 0, mk = 0;
+        int a = 0, b = 0, c = 0, mk = 0, pc = 0, pp = 0;
         for (int r = 0; r < world; ++r) {
             const int *f = frames + (size_t)r * F;
-            // (saturating: the sums only feed a ratio test)
+            // (saturating: the sums only feed ratio tests)
             a = (int)min(0x7fffffffll, (long long)a + f[1]); b = (int)min(0x7fffffffll, (long long)b + f[2]);
             c = (int)min(0x7fffffffll, (long long)c + f[3]); mk = max(mk, f[4]);
+            pc = (int)min(0x7fffffffll, (long long)pc + f[5]); pp = (int)min(0x7fffffffll, (long long)pp + f[6]);
         }
-        slot[3] = a; slot[4] = b; slot[5] = c; slot[6] = mk;
+        slot[3] = a; slot[4] = b; slot[5] = c; slot[6] = mk; slot[7] = pc; slot[8] = pp;
     }
 }
 

@@ -36,6 +36,11 @@ namespace {
 
 thread_local std::string g_err;
 
+// a batch's verdict slot: [0] first changed position of the round, [1] tiles of the largest bin, [2] tiles of all bins,
+// [3..5] wave-tiles skipped / seen / never loaded (tile skipping), [6] fill mark of the persistent pack's arena,
+// [7..8] candidates admitted / pairs (threshold pools), sampled by the batch's base shortlist launch; the rest spare
+constexpr int kSlotInts = 16;
+
 int fail(int code, const std::string &msg)
 {
     g_err = msg;
@@ -199,8 +204,8 @@ struct chb_ctx {
     bool batch_open = false;
     DevBuf<int> bq, lab_old, lab_prev, lab_new, first_change;
     int *bq_cur = nullptr;      // the open batch's sample indices: bq.p, or a window of perm (no copy)
-    int *fc_host = nullptr;     // pinned landing places of the two first_change slots (4 ints each, as on the device)
-    int *fc_cur = nullptr;      // slot of the open batch (first_change.p + 0 / 8): {first changed position, tiles of the
+    int *fc_host = nullptr;     // pinned landing places of the two verdict slots (kSlotInts ints each, as on the device)
+    int *fc_cur = nullptr;      // slot of the open batch (first_change.p + 0 / kSlotInts): {first changed position, tiles of the
                                 // batch's largest bin, tiles of all bins, wave-tiles skipped / seen by the first
                                 // workgroups of its shortlist launch}: bin sizes and skip statistics ride home with the
                                 // verdict in one 20-byte copy
@@ -229,6 +234,7 @@ struct chb_ctx {
     bool shadow_ok = false, use_prefilter = true, overflow_total_valid = false;
     bool pf_base = true, pf_update = true;   // developer switches (CHB_PF_BASE / CHB_PF_UPDATE; -DCHB_DEV_KNOBS builds only)
     DevBuf<int> cand, cand_cnt, flags64, flaglist, nflag, overflow;
+    DevBuf<int> flaglist2, nflag2;   // what the second-chance launch of a pool batch leaves for the brute-force kernel
     DevBuf<int> active, n_active, act_blk;
     // fused selection + hull distance (m <= 16): batch-entry candidates of this / the previous round,
     // the base stage's tau (bound of the m-th nearest distance), the exact path's work list
@@ -263,6 +269,24 @@ struct chb_ctx {
         return chb::PackState{pp_start.p, pp_cap.p, pp_fill.p, pp_live.p, pp_nt.p, pp_memb.p, pp_row.p, pp_ctl.p, pp_ovf.p,
                               pp_dest.p, pp_arena_rows};
     }
+    // threshold pools of the shortlist stage (prefilter_kernels.hip, "threshold pools"): for every (bin, home bin) the 32
+    // base members of the bin nearest to the home bin's centre; built at a fit's start, maintained by every commit
+    DevBuf<unsigned short> pool_Z;
+    DevBuf<int> pool_id, pool_hole, pool_ok, pool_stat;
+    DevBuf<float> pool_key, pool_sn, pool_tsn;
+    bool pool_allowed = true;   // CHB_POOL_TAU=0: the base shortlist launch always streams a bin twice (the form up to round 4; A/B tests)
+    bool pool_fit = false;      // inside chb_fit_cluster (the stepwise entry points and chb_topm_per_bin never use pools)
+    bool pool_valid = false;    // the pools on the device match the labels
+    bool pool_holes = true;     // the open batch may hold labelled samples (their pool slots are holes until the commit)
+    int pool_state = 0;         // this fit: 0 undecided = on, 1 kept on, -1 off (its shortlists came out long: overlapping bins)
+    int pool_batches = 0;
+    long long pool_cand = 0, pool_pairs = 0;
+    long long pool_off_key = -1;   // (bins, neighbours, metric) of the fit that turned them off on these samples
+    int64_t stats_pool_batches = 0;
+    chb::PoolState pool_view()
+    {
+        return chb::PoolState{pool_Z.p, pool_id.p, pool_key.p, pool_sn.p, pool_hole.p, pool_tsn.p, pool_ok.p};
+    }
     int64_t short_seen = 0;
     // bins far larger than the rest are cut into segments for the shortlist stage (SegPlan, prefilter_kernels.hip): plan
     // buffers, and the bin sizes last seen by the host (they come home with the rounds' verdicts)
@@ -280,6 +304,11 @@ struct chb_ctx {
     // nearest-centre keys, the seating order, and the fit's verdict on whether it pays (0 undecided = on, 1 on, -1 off)
     DevBuf<unsigned long long> ckey;
     DevBuf<int> qord, home;
+    // (the fit loop orders the positions of ALL batches of a sweep in one launch; the open batch's part: qord_cur / home_cur)
+    DevBuf<int> qord_all, home_all;
+    DevBuf<int4> geo_all;
+    PinBuf<int4> pin_geo;
+    int *qord_cur = nullptr, *home_cur = nullptr;
     bool allow_skip = true;       // CHB_TILE_SKIP=0: never (A/B tests)
     int skip_state = 0, skip_batches = 0;
     long long skip_off_key = -1;   // (bins, neighbours, metric) of the fit that found nothing to skip on these samples
@@ -384,7 +413,7 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
     HIPCHK(h->lab_old.ensure(K));
     HIPCHK(h->lab_prev.ensure(Kpad));
     HIPCHK(h->lab_new.ensure(Kpad));
-    HIPCHK(h->first_change.ensure(16));
+    HIPCHK(h->first_change.ensure(2 * kSlotInts));
     h->fc_cur = h->first_change.p;
     HIPCHK(h->xg.ensure(Kpad + (size_t)(kXchgHdr + 1) * (size_t)h->world));
     { const size_t had = h->xerr.cap; HIPCHK(h->xerr.ensure(4)); if (!had) HIPCHK(hipMemsetAsync(h->xerr.p, 0, 4 * sizeof(int), h->stream)); }
@@ -418,6 +447,8 @@ int ensure_batch_buffers(chb_ctx *h, int Kcap)
         HIPCHK(h->flags64.ensure(B * ((K + kQTile - 1) / kQTile)));
         HIPCHK(h->flaglist.ensure(B * ((K + kQTile - 1) / kQTile)));
         HIPCHK(h->nflag.ensure(1));
+        HIPCHK(h->flaglist2.ensure(B * ((K + kQTile - 1) / kQTile)));
+        HIPCHK(h->nflag2.ensure(1));
         launch_fill_i32(h->flags64.p, 0, (int)(B * ((K + kQTile - 1) / kQTile)), h->stream);   // kept zero by its consumer
         HIPCHK(h->overflow.ensure(1));
         HIPCHK(h->pk.ensure((size_t)h->N + 32 * B, B, (size_t)h->Dz));
@@ -561,6 +592,30 @@ int pack_state_build(chb_ctx *h)
     return CHB_OK;
 }
 
+// The threshold pools from the labels as they stand at a fit's start (the CSR fit_begin_impl has just made): allocated on
+// first use, B x B tiles of 32 shadow rows -- 38 MB at 100k x 136 x 64, 410 MB at 1M x 146 x 200; a fit whose pools would
+// take more than kPoolMaxBytes keeps the two-sweep shortlist launch.
+constexpr size_t kPoolMaxBytes = (size_t)1 << 30;
+int pool_build(chb_ctx *h)
+{
+    h->pool_valid = false;
+    const size_t B = h->B, slots = B * B * (size_t)kPoolRows;
+    if (!h->pool_allowed || !h->fused || !h->pf_fit || !h->pf_base || h->ckey.p == nullptr || B < 2 ||
+        slots * (size_t)h->Dz * sizeof(unsigned short) > kPoolMaxBytes)
+        return CHB_OK;
+    HIPCHK(h->pool_Z.ensure(slots * (size_t)h->Dz));
+    HIPCHK(h->pool_id.ensure(slots)); HIPCHK(h->pool_hole.ensure(slots));
+    HIPCHK(h->pool_key.ensure(slots)); HIPCHK(h->pool_sn.ensure(slots));
+    HIPCHK(h->pool_tsn.ensure(B * B + 64)); HIPCHK(h->pool_ok.ensure(B * B));
+    {
+        Timed t(h, "pool", (double)h->N);
+        launch_pool_build(h->pool_view(), h->Zs.p, h->ms.p, h->qn.p, h->D, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, h->stream);
+    }
+    HIPCHK(hipGetLastError());
+    h->pool_valid = true;
+    return CHB_OK;
+}
+
 // bq already holds the K sample indices (device).  need_lists: the caller wants the exact base lists
 // L0 (chb_topm_per_bin); the fit loop of the fused path (m <= 16) works on the shortlists directly.
 int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
@@ -596,6 +651,10 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
     }
     if (!pp_now) h->pp_valid = false;   // (this batch's commit will not maintain the pack)
     h->pp_batch = pp_now;
+    // threshold pools: the base shortlist launch streams a bin once where a pool tile gives the threshold
+    if (!(h->pool_fit && fusedp && pf_base_path)) h->pool_valid = false;   // (this batch will not maintain them)
+    if (h->pool_state < 0) h->pool_valid = false;                          // (turned off for this fit: no upkeep either)
+    const bool pool_on = h->pool_valid && h->pool_state >= 0;
     if (pp_now) {
         // the batch is opened (its members' rows become holes) and tiles per bin / statistics / segment plan written:
         // one launch instead of count + scan + fill + gather
@@ -611,6 +670,12 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
                            sp.gflag ? &sp : nullptr, h->fc_cur + 1, pf_base_path ? h->ms.p : nullptr,
                            skip_on ? h->shell_inv.p : nullptr, skip_on ? h->nsh : 1);
     }
+    if (h->pool_valid) {
+        // (the batch's samples are marked: their slots in the pools are holes while it is open)
+        Timed t(h, "pool", (double)K);
+        launch_pool_open(h->pool_view(), h->inb.p, h->D, h->Dz, h->B, h->nflag2.p, s);
+    }
+    h->pool_holes = true;
     TopmArgs a{};
     a.X = h->X.p; a.Dp = h->Dp; a.bq = h->bq_cur; a.pos_begin = q_lo; a.pos_end = q_hi;
     a.bin_ptr = h->bin_ptr.p; a.memb_id = h->memb_id.p; a.memb_code = nullptr;
@@ -629,7 +694,12 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             // bounds: one launch
             Timed t(h, "bucket", 0.0);
             launch_pack_build(h->Zs.p, h->ms.p, h->D, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, (int)h->N, h->pk.view(), skip_on, s);
-            if (skip_on) launch_query_order(h->ckey.p, h->bq_cur, q_lo, q_hi, h->B, h->qord.p, h->home.p, s);
+        }
+        int *qord_p = h->qord.p, *home_p = h->home.p;
+        if ((skip_on || pool_on) && h->qord_cur != nullptr) { qord_p = h->qord_cur; home_p = h->home_cur; }   // (done for the whole sweep)
+        else if (skip_on || pool_on) {   // (the queries are seated in the order of their nearest bin centre)
+            Timed t(h, "bucket", 0.0);
+            launch_query_order(h->ckey.p, h->bq_cur, q_lo, q_hi, h->B, h->qord.p, h->home.p, s);
         }
         ShortlistArgs pa{};
         pa.Gs = h->Gs.p; pa.gq = reinterpret_cast<const float2 *>(h->gq.p);
@@ -646,7 +716,11 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         if (fusedp) pa.tau_out = h->tau.p;
         pa.seg = sp;
         if (sp.launch) h->stats_seg_batches += 1;
-        if (skip_on) { pa.qord = h->qord.p; pa.home = h->home.p; pa.skip = 1; pa.skip_stat = h->fc_cur + 3; }
+        if (skip_on) { pa.qord = qord_p; pa.home = home_p; pa.skip = 1; pa.skip_stat = h->fc_cur + 3; }
+        if (pool_on) {
+            pa.qord = qord_p; pa.home = home_p; pa.ckey = h->ckey.p; pa.pool = h->pool_view(); pa.pool_stat = h->fc_cur + 7;
+            h->stats_pool_batches += 1;
+        }
 #ifdef CHB_DEV_KNOBS
         if (skip_on) { if (const char *ev = getenv("CHB_SKIP_NEVER")) if (atoi(ev)) pa.skip = 1 | 2 * atoi(ev); }
 #endif
@@ -662,12 +736,45 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             pa.dbg = dbg_dev;
         }
 #endif
+#ifdef CHB_DEV_KNOBS
+        // CHB_SL_BOUNDS=1: the base shortlist launch checks its tile DMA sources and member reads against the buffers' extents,
+        // skips an access that is out of range and reports the first one (instead of a GPU memory fault)
+        static int *viol_dev = nullptr;
+        if (getenv("CHB_SL_BOUNDS") != nullptr) {
+            if (viol_dev == nullptr) HIPCHK(hipMalloc(&viol_dev, 8 * sizeof(int)));
+            HIPCHK(hipMemsetAsync(viol_dev, 0, 8 * sizeof(int), s));
+            pa.viol = viol_dev;
+            pa.viol_rows = pp_now ? (long long)h->pp_arena_rows : (long long)h->N + 32LL * h->B + 64;
+            pa.viol_pool_rows = (long long)h->B * h->B * kPoolRows;
+            pa.viol_members = pp_now ? (long long)h->pp_arena_rows : (long long)h->N;
+        }
+#endif
         {
             Timed t(h, "prefilter", (double)(q_hi - q_lo) * h->hint_base_members);
             pa.flaglist = h->flaglist.p; pa.nflag = h->nflag.p;   // (counter reset by the CSR scan / the batch CSR kernel)
             launch_shortlist(pa, h->flags64.p, s);
         }
+        const int *fb_list = h->flaglist.p, *fb_n = h->nflag.p;   // the brute-force kernel's work list
+        if (pool_on) {
+            // second chance for the pairs whose pool threshold was too loose for a 128-entry shortlist: the exact two-sweep
+            // selection on the overflow list's work items; only what overflows again goes to the brute-force kernel
+            Timed t(h, "prefilter_retry", 0.0);
+            ShortlistArgs pb = pa;
+            pb.worklist = h->flaglist.p; pb.nwork = h->nflag.p; pb.flaglist = h->flaglist2.p; pb.nflag = h->nflag2.p;
+            launch_shortlist_worklist(pb, h->flags64.p, s);
+            fb_list = h->flaglist2.p; fb_n = h->nflag2.p;
+        }
 #ifdef CHB_DEV_KNOBS
+        if (pa.viol != nullptr) {
+            int hv[8];
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpy(hv, viol_dev, sizeof(hv), hipMemcpyDeviceToHost));
+            if (hv[0] != 0) {
+                fprintf(stderr, "[chb bounds] code %d: %d %d %d %d %d %d (workgroup %d); skip %d pool %d pp %d K %d q %d..%d\n", hv[0], hv[1], hv[2], hv[3],
+                        hv[4], hv[5], hv[6], hv[7], (int)skip_on, (int)pool_on, (int)pp_now, K, q_lo, q_hi);
+                return fail(CHB_ESTATE, "shortlist bounds check failed");
+            }
+        }
         h->dev_pa = pa; h->dev_pa_valid = true;   // (CHB_DEV_OVERLAP)
 #endif
 #ifdef CHB_DEV_KNOBS
@@ -694,7 +801,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         }
         {
             Timed t(h, "topm_fallback", 0.0);
-            launch_topm_flagged(a, h->flags64.p, h->flaglist.p, h->nflag.p, s);
+            launch_topm_flagged(a, h->flags64.p, fb_list, fb_n, s);
         }
 #ifdef CHB_DEV_KNOBS
         // CHB_SL_INJECT_SHORT=<n>: the n-th batch start of a context hands the hull kernels one truncated shortlist
@@ -709,7 +816,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
             if (verr == nullptr) HIPCHK(hipMalloc(&verr, 16 + 4 * 65536));
             HIPCHK(hipMemsetAsync(verr, 0, 16 + 4 * 65536, s));
             launch_validate_batch(h->cand.p, h->cand_cnt.p, h->B, h->Kcap, q_lo, q_hi, kCandCap, (int)h->N, h->bin_ptr.p,
-                                  h->memb_id.p, skip_on ? h->qord.p : nullptr, h->m, verr, s);
+                                  h->memb_id.p, skip_on ? qord_p : nullptr, h->m, verr, s);
             int herr[4];
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipMemcpy(herr, verr, 16, hipMemcpyDeviceToHost));
@@ -938,6 +1045,12 @@ int batch_commit_dev(chb_ctx *h, const int *final_dev)
                              h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, final_dev, h->inb.p, s);
     else
         launch_batch_close(h->labels.p, h->inb.p, h->bq_cur, final_dev, h->K, s);
+    if (h->pool_valid) {
+        // (labels and shadow rows are final: holes resolved, the batch's arrivals offered to their new bins' pools)
+        Timed t(h, "pool", (double)h->K);
+        launch_pool_commit(h->pool_view(), h->Zs.p, h->ms.p, h->qn.p, h->D, h->Dz, h->bq_cur, h->K, final_dev, h->lab_old.p,
+                           h->labels.p, h->B, h->pool_holes, s);
+    }
     HIPCHK(hipGetLastError());
     h->batch_open = false;
     h->pp_batch = false;
@@ -1047,6 +1160,7 @@ int chb_create(int device_id, chb_ctx **out)
     if (const char *ev = getenv("CHB_SEGMENTS")) h->allow_segments = atoi(ev) != 0;
     if (const char *ev = getenv("CHB_TILE_SKIP")) h->allow_skip = atoi(ev) != 0;
     if (const char *ev = getenv("CHB_PACK_INCR")) h->pp_allowed = atoi(ev) != 0;
+    if (const char *ev = getenv("CHB_POOL_TAU")) h->pool_allowed = atoi(ev) != 0;
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
     return CHB_OK;
@@ -1062,7 +1176,7 @@ int chb_destroy(chb_ctx *h)
     DevBuf<int> *ib[] = {&h->labels, &h->inb, &h->bq, &h->lab_old, &h->lab_prev, &h->lab_new,
                          &h->first_change, &h->l0i, &h->l1i, &h->l0c, &h->l1c, &h->l2i, &h->l2c, &h->cnt, &h->bin_ptr,
                          &h->cursor, &h->memb_id, &h->cnt2, &h->bin_ptr2, &h->cursor2, &h->memb2_id,
-                         &h->memb2_code, &h->perm, &h->xq, &h->xhull, &h->xcnt, &h->cand, &h->cand_cnt, &h->flags64, &h->flaglist, &h->nflag, &h->overflow};
+                         &h->memb2_code, &h->perm, &h->xq, &h->xhull, &h->xcnt, &h->cand, &h->cand_cnt, &h->flags64, &h->flaglist, &h->nflag, &h->overflow, &h->flaglist2, &h->nflag2};
     for (auto *b : ib) b->release();
     DevBuf<double> *db[] = {&h->X, &h->mind, &h->mind2, &h->dist, &h->l0d, &h->l1d, &h->l2d, &h->xdist, &h->xalpha, &h->xpts};
     for (auto *b : db) b->release();
@@ -1073,10 +1187,13 @@ int chb_destroy(chb_ctx *h)
     for (int i = 0; i < 2; ++i) { h->candu[i].release(); h->candu_cnt[i].release(); }
     h->slow.release(); h->n_slow.release(); h->tau.release(); h->short_cnt.release(); h->agree.release();
     h->xg.release(); h->xerr.release();
+    h->pool_Z.release(); h->pool_id.release(); h->pool_hole.release(); h->pool_ok.release(); h->pool_stat.release();
+    h->pool_key.release(); h->pool_sn.release(); h->pool_tsn.release();
     h->pp_start.release(); h->pp_cap.release(); h->pp_fill.release(); h->pp_live.release(); h->pp_nt.release();
     h->pp_memb.release(); h->pp_row.release(); h->pp_ctl.release(); h->pp_ovf.release(); h->pp_dest.release();
     h->seg_nseg.release(); h->seg_gflag.release(); h->seg_items.release(); h->seg_lists.release();
     h->shell_inv.release(); h->ckey.release(); h->qord.release(); h->home.release();
+    h->qord_all.release(); h->home_all.release(); h->geo_all.release();
     (void)hipStreamDestroy(h->stream);
     if (h->fc_host) (void)hipHostFree(h->fc_host);
     for (int i = 0; i < 2; ++i) if (h->fc_event[i]) (void)hipEventDestroy(h->fc_event[i]);
@@ -1113,7 +1230,7 @@ static int samples_upload(chb_ctx *h, const double *X, int64_t N, int64_t D, boo
 // everything that is a function of the resident X alone (global mean, scale, query-side shadow rows)
 static int samples_finish(chb_ctx *h)
 {
-    h->skip_off_key = -1;
+    h->skip_off_key = -1; h->pool_off_key = -1;
     const int64_t N = h->N, D = h->D;
     const int Dp = h->Dp;
     // the shortlist stage (prefilter_kernels.hip) keeps its query fragments in registers: D <= 160
@@ -1392,7 +1509,16 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     } fit_closer{h};
     const int64_t N = h->N;
     h->pp_fit = true; h->stats_pp_batches = 0; h->stats_pp_builds = 0;
-    struct PackOff { chb_ctx *h; ~PackOff() { h->pp_fit = false; h->pp_valid = false; } } pack_off{h};
+    struct PackOff {
+        chb_ctx *h;
+        ~PackOff() { h->pp_fit = false; h->pp_valid = false; h->pool_fit = false; h->pool_valid = false; h->qord_cur = nullptr; h->home_cur = nullptr; }
+    } pack_off{h};
+    // threshold pools: built from the initial labels (the CSR of the fit's start is still in place), unless an earlier fit
+    // over the same samples, bins and neighbour count found that they do not pay (overlapping bins: long shortlists)
+    h->pool_fit = true; h->stats_pool_batches = 0;
+    h->pool_state = (h->pool_off_key == skip_key(h)) ? -1 : 0;
+    h->pool_batches = 0; h->pool_cand = 0; h->pool_pairs = 0;
+    if (h->pool_state >= 0) { rc = pool_build(h); if (rc) return rc; }
     std::vector<uint64_t> seen_bits;
     // default batch: 8192 positions on one GPU, growing with sqrt(world): the batch-member
     // (update) work per rank is ~K^2/world, the per-rank grids ~K/world.  Twice that from 300k contigs to move: every
@@ -1426,9 +1552,11 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                                        (int)((hi_ >> 32) & 0x7fffffff)};
         memcpy(fa.v, eq, sizeof(eq));
         fa.v[16] = h->skip_state; fa.v[17] = h->speculate ? 1 : 0; fa.v[18] = h->allow_skip ? 1 : 0; fa.v[19] = h->pp_allowed ? 1 : 0;
+        fa.v[20] = h->pool_valid ? h->pool_state : -1;
         rc = fit_agree(h, &fa);
         if (rc) return rc;
         h->skip_state = fa.v[16]; h->speculate = fa.v[17] != 0; h->allow_skip = fa.v[18] != 0; h->pp_allowed = fa.v[19] != 0;
+        if (fa.v[20] < 0) { h->pool_state = -1; h->pool_valid = false; }
     }
 #ifdef CHB_DEV_KNOBS
     // developer builds, tests of the exchange schedule (tests/test_gpu_world2.py): CHB_DEV_HOOK_SPEC=1 lets the look-ahead run
@@ -1462,6 +1590,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
 
     int it = 0;
     bool wrote_out = false;
+    bool sweep_has_labelled = true;
     for (; it < max_iter; ++it) {
         const int64_t *perm = perms + (int64_t)it * n_move;
         HIPCHK(h->perm.ensure((size_t)std::max<int64_t>(n_move, 1)));
@@ -1471,6 +1600,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             //  sweep's final synchronisation, and the first sweep's conversion overlaps the kernels of the fit's start)
             seen_bits.assign((size_t)(N + 63) / 64, 0);
             uint64_t dup = 0;
+            int any_lab = 0;   // does this sweep visit a sample that carries a label?  (sweep 1 normally does not)
             for (int64_t i = 0; i < n_move; ++i) {
                 const int64_t v = perm[i];          // (in range: checked up front)
                 uint64_t &wd = seen_bits[(size_t)(v >> 6)];
@@ -1478,7 +1608,9 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 dup |= wd & bit;
                 wd |= bit;
                 h->pin_c.p[i] = (int)v;
+                any_lab |= prev[(size_t)v] >= 0;
             }
+            sweep_has_labelled = any_lab != 0;
             if (dup) return fail(CHB_EINVAL, "a sweep's permutation lists a sample twice");
             HIPCHK(hipMemcpyAsync(h->perm.p, h->pin_c.p, sizeof(int) * n_move, hipMemcpyHostToDevice, s));
         }
@@ -1517,6 +1649,32 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             const int q_lo = std::min(K, h->rank * C);
             return Geom{t0, K, q_lo, std::min(K, q_lo + C), C};
         };
+        // the seating order of every batch of this sweep (tile skipping / threshold pools), in one launch: the batches are a
+        // function of the sweep alone.  (Not for sweeps of thousands of tiny batches: those order theirs one by one.)
+        h->qord_cur = nullptr; h->home_cur = nullptr;
+        std::vector<int64_t> batch_t0;
+        if (h->pf_fit && h->fused && h->ckey.p != nullptr && n_move > 0 && (h->pool_valid || (h->allow_skip && h->skip_state >= 0))) {
+            std::vector<int4> geo;
+            for (int64_t t = 0; t < n_move && geo.size() <= 4096;) {
+                const Geom g = geom_at(t);
+                geo.push_back(make_int4((int)g.t0, g.q_lo, g.q_hi, g.K));
+                batch_t0.push_back(t);
+                t += g.K;
+            }
+            if (geo.size() <= 4096) {
+                HIPCHK(h->geo_all.ensure(geo.size()));
+                HIPCHK(h->qord_all.ensure((size_t)n_move));
+                HIPCHK(h->home_all.ensure(geo.size() * (size_t)h->B));
+                // (pinned staging: the previous sweep's upload from it completed before that sweep's final synchronisation)
+                HIPCHK(h->pin_geo.ensure(geo.size()));
+                memcpy(h->pin_geo.p, geo.data(), sizeof(int4) * geo.size());
+                HIPCHK(hipMemcpyAsync(h->geo_all.p, h->pin_geo.p, sizeof(int4) * geo.size(), hipMemcpyHostToDevice, s));
+                Timed t(h, "bucket", (double)n_move);
+                launch_query_order_sweep(h->ckey.p, h->perm.p, h->geo_all.p, (int)geo.size(), h->B, h->qord_all.p, h->home_all.p, s);
+            } else {
+                batch_t0.clear();
+            }
+        }
         // after a round's kernels: (multi-GPU: exchange) + first-changed position on its way to the host
         auto finish_round = [&](const Geom &g, int active, int slot) -> int {
             if (xchg) {
@@ -1536,35 +1694,53 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 launch_xchg_unpack(h->xg.p, world, g.C, g.K, tag, h->lab_new.p, h->lab_prev.p, active, h->fc_cur,
                                    first && !dev_local_verdict, h->xerr.p, s);
             }
-            HIPCHK(hipMemcpyAsync(h->fc_host + 8 * slot, h->fc_cur, 7 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(h->fc_host + kSlotInts * slot, h->fc_cur, 9 * sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(h->fc_event[slot], s));
             return CHB_OK;
         };
         auto wait_round = [&](const Geom &g, int active, int slot, int *f) -> int {
             HIPCHK(hipEventSynchronize(h->fc_event[slot]));
-            *f = h->fc_host[8 * slot];
+            *f = h->fc_host[kSlotInts * slot];
             // (bin sizes of that batch, for the segment decision of the batches still to be enqueued; and what the tile
             //  skipping of its shortlist launch achieved: a fit whose first batches skip next to nothing turns it off)
-            h->hint_max_tiles = h->fc_host[8 * slot + 1]; h->hint_total_tiles = h->fc_host[8 * slot + 2];
+            h->hint_max_tiles = h->fc_host[kSlotInts * slot + 1]; h->hint_total_tiles = h->fc_host[kSlotInts * slot + 2];
             // (the persistent pack's arena: rows handed out so far, as of that batch's start)
             {
                 int64_t mark_at = 5 * h->N + 512 * (int64_t)h->B;
 #ifdef CHB_DEV_KNOBS   // CHB_PACK_REBUILD_AT=<rows>: rebuild (compact) the pack from that fill mark on -- tests of the rebuild path
                 { static const char *e = getenv("CHB_PACK_REBUILD_AT"); if (e) mark_at = atoll(e); }
 #endif
-                if (h->pp_valid && h->fc_host[8 * slot + 6] > mark_at) h->pp_rebuild = true;
+                if (h->pp_valid && h->fc_host[kSlotInts * slot + 6] > mark_at) h->pp_rebuild = true;
             }
             // (the slot's statistics are written by the batch's one base shortlist launch: counted with the batch's first
             //  round only -- later rounds of the same batch bring the same three numbers home again)
-            if (active == 0 && h->fc_host[8 * slot + 4] > 0) {
-                h->skip_skipped += h->fc_host[8 * slot + 3]; h->skip_seen += h->fc_host[8 * slot + 4];
-                h->skip_unloaded += h->fc_host[8 * slot + 5];
+            if (active == 0 && h->fc_host[kSlotInts * slot + 4] > 0) {
+                h->skip_skipped += h->fc_host[kSlotInts * slot + 3]; h->skip_seen += h->fc_host[kSlotInts * slot + 4];
+                h->skip_unloaded += h->fc_host[kSlotInts * slot + 5];
                 if (h->skip_state == 0 && ++h->skip_batches >= 3)
                 {
                     // (it pays from a few per cent of the wave-tiles)
                     h->skip_state = ((h->skip_skipped + h->skip_unloaded) * 50 >= h->skip_seen + h->skip_unloaded) ? 1 : -1;
                     if (h->skip_state < 0) h->skip_off_key = skip_key(h);
+                    // Where tile skipping never loads a third of a bin's tiles (500k x 140 x 128: 45 %), the threshold sweep is
+                    // cheap already and the pools' price -- the looser thresholds of the contigs far out in their bins: long
+                    // shortlists, retries, label guesses that fail -- is higher than what they save (113 against 105 ms per
+                    // sweep there; 1M x 146 x 200, 19 % never loaded: 366 against 460): such a fit drops them
+                    // (checked per batch below: sweep 1's first batches stream bins of a few tiles, nothing to go by)
                 }
+            }
+            if (active == 0 && h->skip_state == 1 && h->pool_state >= 0 && h->fc_host[kSlotInts * slot + 4] > 0) {
+                const long long un = h->fc_host[kSlotInts * slot + 5], sn = h->fc_host[kSlotInts * slot + 4];
+                if (un * 10 > 3 * (sn + un)) { h->pool_state = -1; h->pool_off_key = skip_key(h); }
+            }
+            // (threshold pools: candidates per pair of that batch's base shortlist launch, as sampled; a fit whose first
+            //  batches admit far more than the exact threshold would -- overlapping bins -- goes back to the two sweeps)
+            //  -- checked for EVERY batch: the pools of sweep 1's first batches hold whole bins and say nothing yet)
+            if (active == 0 && h->pool_state >= 0 && h->fc_host[kSlotInts * slot + 8] > 0) {
+                const long long pc = h->fc_host[kSlotInts * slot + 7], pp = h->fc_host[kSlotInts * slot + 8];
+                h->pool_cand += pc; h->pool_pairs += pp;
+                if (++h->pool_batches >= 3 && h->pool_state == 0) h->pool_state = 1;
+                if (pc > (long long)(2 * h->m + 2) * pp) { h->pool_state = -1; h->pool_off_key = skip_key(h); }
             }
             (void)active; (void)g;
             return CHB_OK;
@@ -1572,12 +1748,17 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         // batch start + guess + round 0, nothing read back
         auto open_batch = [&](const Geom &g, int slot) -> int {
             h->bq_cur = h->perm.p + g.t0;   // the batch's sample indices: a window of the sweep's permutation
-            h->fc_cur = h->first_change.p + 8 * slot;
+            h->fc_cur = h->first_change.p + kSlotInts * slot;
+            if (!batch_t0.empty()) {
+                const size_t bi = (size_t)(std::lower_bound(batch_t0.begin(), batch_t0.end(), g.t0) - batch_t0.begin());
+                h->qord_cur = h->qord_all.p + g.t0 + g.q_lo; h->home_cur = h->home_all.p + bi * (size_t)h->B;
+            }
             h->hint_base_members = (double)((it == 0) ? assigned0 + g.t0 : labelled - g.K);
             h->hint_batch_entries = (double)((it == 0) ? g.K : 2 * g.K);
             h->argmin_in_place = !xchg;
             int r = batch_begin_dev(h, g.K, g.q_lo, g.q_hi, false);
             if (r) return r;
+            h->pool_holes = sweep_has_labelled;   // (an all-unlabelled batch leaves no holes for its commit to look for)
             // starting labels of the rounds: last sweep's label, or for still-unlabelled contigs
             // (sweep 1) the bin whose m-th nearest outside member is closest
             if (h->fused && !h->lists_valid) launch_guess_near(h->tau.p, h->lab_old.p, g.q_lo, g.q_hi, h->B, h->Kcap, h->lab_prev.p, s);
@@ -1593,11 +1774,11 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             return finish_round(g, 0, slot);
         };
         struct Snap {   // host-side batch state (the device side of a gated-off batch never changed)
-            int K, q_lo, q_hi, round_in_batch; bool lists_valid, batch_open, pp_batch, pp_valid; int *bq_cur, *fc_cur;
+            int K, q_lo, q_hi, round_in_batch; bool lists_valid, batch_open, pp_batch, pp_valid, pool_valid; int *bq_cur, *fc_cur;
             double hb, he; int64_t st[4]; size_t n_pending;
         };
         auto save = [&]() {
-            Snap v{h->K, h->q_lo, h->q_hi, h->round_in_batch, h->lists_valid, h->batch_open, h->pp_batch, h->pp_valid, h->bq_cur, h->fc_cur,
+            Snap v{h->K, h->q_lo, h->q_hi, h->round_in_batch, h->lists_valid, h->batch_open, h->pp_batch, h->pp_valid, h->pool_valid, h->bq_cur, h->fc_cur,
                    h->hint_base_members, h->hint_batch_entries, {0, 0, 0, 0}, h->pending.size()};
             memcpy(v.st, h->stats, sizeof(v.st));
             return v;
@@ -1605,7 +1786,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
         auto restore = [&](const Snap &v) {
             h->K = v.K; h->q_lo = v.q_lo; h->q_hi = v.q_hi; h->round_in_batch = v.round_in_batch;
             h->lists_valid = v.lists_valid; h->batch_open = v.batch_open; h->bq_cur = v.bq_cur; h->fc_cur = v.fc_cur;
-            h->pp_batch = v.pp_batch; h->pp_valid = v.pp_valid;
+            h->pp_batch = v.pp_batch; h->pp_valid = v.pp_valid; h->pool_valid = v.pool_valid;
             h->hint_base_members = v.hb; h->hint_batch_entries = v.he;
             memcpy(h->stats, v.st, sizeof(v.st));
             // the launches recorded inside the window were gated off (they returned at once): they are neither
@@ -1634,7 +1815,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             Snap snap{};
             if (spec) {
                 snap = save();
-                g_gate = Gate{h->first_change.p + 8 * slot, K};   // "this batch's round 0 changed nothing"
+                g_gate = Gate{h->first_change.p + kSlotInts * slot, K};   // "this batch's round 0 changed nothing"
                 rc = batch_commit_dev(h, h->lab_prev.p);
                 if (rc) return rc;
                 rc = open_batch(geom_at(t1), slot ^ 1);
@@ -1681,17 +1862,22 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             } else {
                 slot ^= 1;
             }
+#ifdef CHB_DEV_KNOBS
+            { static const bool tr = getenv("CHB_DEV_TRACE_BATCHES") != nullptr;
+              if (tr) fprintf(stderr, "[chb batch] sweep %d t0 %lld K %d rounds so far %lld pool %d/%d skip %d spec %d\n", it, (long long)t0, K,
+                              (long long)h->stats[1], (int)h->pool_valid, h->pool_state, h->skip_state, (int)inflight); }
+#endif
             h->stats[0] += 1;
             t0 = t1;
         }
         h->stats[3] += n_move * (int64_t)h->B;
         HIPCHK(h->pin_b.ensure((size_t)N));
         HIPCHK(hipMemcpyAsync(h->pin_b.p, h->labels.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));
-        if (h->fused && h->short_cnt.p)   // (fc_host[7]: the spare word of the first verdict slot)
-            HIPCHK(hipMemcpyAsync(h->fc_host + 7, h->short_cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        h->fc_host[15] = 0;
-        if (h->pp_ctl.p)   // (fc_host[15]: the spare word of the second slot -- the persistent pack's error flag)
-            HIPCHK(hipMemcpyAsync(h->fc_host + 15, h->pp_ctl.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (h->fused && h->short_cnt.p)   // (fc_host[12]: a spare word of the first verdict slot)
+            HIPCHK(hipMemcpyAsync(h->fc_host + 12, h->short_cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        h->fc_host[13] = 0;
+        if (h->pp_ctl.p)   // (fc_host[13]: another spare word -- the persistent pack's error flag)
+            HIPCHK(hipMemcpyAsync(h->fc_host + 13, h->pp_ctl.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
         std::vector<int> xend;
         if (xchg) {
             // every rank's "a rank was out of step" record: all ranks then leave the sweep with the same status
@@ -1710,11 +1896,11 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                                         " sent exchange " + std::to_string(e[2] >> 4) + " kind " + std::to_string(e[2] & 15) +
                                         "); labels not returned");
             }
-        if (h->fc_host[15] != 0)
+        if (h->fc_host[13] != 0)
             return fail(CHB_ESTATE, "internal error: the persistent member pack ran out of rows; labels not returned");
-        if (h->fused && h->short_cnt.p && h->fc_host[7] != 0) {
-            h->short_seen = h->fc_host[7];
-            return fail(CHB_ESTATE, "internal error: " + std::to_string(h->fc_host[7]) + " (position, bin) shortlists of this sweep came "
+        if (h->fused && h->short_cnt.p && h->fc_host[12] != 0) {
+            h->short_seen = h->fc_host[12];
+            return fail(CHB_ESTATE, "internal error: " + std::to_string(h->fc_host[12]) + " (position, bin) shortlists of this sweep came "
                         "out short of min(num_neighbors, bin size) candidates or held a wild index; labels not returned");
         }
         int64_t diff = 0;  // algorithm.py:63
@@ -2100,6 +2286,10 @@ int chb_counter(chb_ctx *h, const char *name, int64_t *out)
     if (!strcmp(name, "exchanges")) { *out = h->xseq; return CHB_OK; }
     if (!strcmp(name, "pack_incremental_batches")) { *out = h->stats_pp_batches; return CHB_OK; }
     if (!strcmp(name, "pack_builds")) { *out = h->stats_pp_builds; return CHB_OK; }
+    if (!strcmp(name, "pool_batches")) { *out = h->stats_pool_batches; return CHB_OK; }
+    if (!strcmp(name, "pool_state")) { *out = h->pool_state; return CHB_OK; }
+    if (!strcmp(name, "pool_candidates")) { *out = h->pool_cand; return CHB_OK; }
+    if (!strcmp(name, "pool_pairs")) { *out = h->pool_pairs; return CHB_OK; }
     if (!strcmp(name, "shortlist_short")) {   // pairs of the last fit that broke the shortlist stage's contract (0, or the fit failed)
         if (h->short_cnt.p) {
             int v = 0;

@@ -118,6 +118,11 @@ void launch_query_norms(const double *X, int D, int Dp, int N, int B, const doub
 void launch_query_order(const unsigned long long *ckey, const int *bq, int pos_begin, int pos_end, int B, int *qord, int *home,
                         hipStream_t s);
 
+// the same for all batches of a sweep in one launch: geo[b] = int4 {first permutation index of batch b, first / end position of
+// this rank's slice, -}; qord_all[geo[b].x + geo[b].y ..) = the slice's positions in seating order, home_all[b * B + bin]
+void launch_query_order_sweep(const unsigned long long *ckey, const int *perm, const void *geo, int nbatch, int B, int *qord_all,
+                              int *home_all, hipStream_t s);
+
 // Plan of the bins that are cut into segments for the shortlist stage (see shortlist_kernel, SEG): made on the device
 // by the CSR scan of the batch start, consumed by the three shortlist launches of the batch.
 struct SegPlan {
@@ -132,6 +137,22 @@ struct SegPlan {
 constexpr int kSegMinTiles = 256;   // a bin is segmented if it has more tiles than this AND more than 4x the average
 constexpr int kSegLenTiles = 128;   // shortest segment (a bin has at most 16)
 
+// ---- threshold POOLS of the shortlist stage (prefilter_kernels.hip, "threshold pools"; round 5).  For every ordered pair
+// (bin c, home bin h) the kPoolRows base members of c nearest to the CENTRE of h, kept as one 32-row tile of shadow rows.
+// A query whose nearest centre is h takes tau(j, c) = the m-th smallest upper bound over the tile (c, h) -- any m base
+// members of c bound the m-th nearest distance from above -- and the base shortlist launch then streams the bin ONCE
+// (the admission sweep) instead of twice (threshold sweep + admission sweep).
+constexpr int kPoolRows = 32;
+constexpr int kPoolMaxHomes = 8;   // a workgroup whose queries span more home bins than this keeps the two-sweep form
+struct PoolState {
+    unsigned short *Z;   // [B * B * 32][Dz] tile (c, h) at rows (c * B + h) * 32; empty slots / holes: first bias piece -inf
+    int *id;             // [B * B * 32] sample of each slot (-1: empty)
+    float *key;          // [B * B * 32] ||(x_p - mu_h) S||^2 (rounded up) of the slot's sample (+inf: empty)
+    float *sn;           // [B * B * 32] ||zh_p|| (rounded up; 0: empty)
+    int *hole;           // [B * B * 32] 1: the slot's sample is in the open batch (not a base member right now)
+    float *tsn;          // [B * B + 64] largest ||zh|| of the tile's slots (the tile's query-rounding term)
+    int *ok;             // [B * B] usable rows of the tile while the current batch is open (written by every batch open)
+};
 struct ShortlistArgs {
     const unsigned short *Gs;  // [N][Dz] query-side rows
     const float2 *gq;          // [N]
@@ -163,6 +184,15 @@ struct ShortlistArgs {
     int *flaglist;   // work items (query tile of 64, bin) whose shortlist overflowed, for launch_topm_flagged ...
     int *nflag;      // ... and their number (zeroed by the caller before the launch)
     SegPlan seg;         // base mode: segmented bins (seg.gflag == nullptr: none)
+    // base mode, optional: threshold pools (a non-null pool.Z selects the one-sweep builds; needs qord / ckey)
+    PoolState pool{};
+    const unsigned long long *ckey = nullptr;   // [N] {norm bits, nearest bin centre} of every sample (launch_query_norms)
+    int *pool_stat = nullptr;   // optional [2]: candidates admitted / (query, bin) pairs, reported by about 64 workgroups
+    const int *worklist = nullptr;   // work-list form (launch_shortlist_worklist): the items (bin * ceil(nq / 64) + query tile of 64)
+    const int *nwork = nullptr;      // ... and their number, both on the device
+    int *viol = nullptr;        // developer builds (CHB_SL_BOUNDS=1): [8] first out-of-range access of the launch {code, ...} -- the
+                                // access is then skipped instead of faulting
+    long long viol_rows = 0, viol_pool_rows = 0, viol_members = 0;   // ... and the limits: pack rows, pool rows, CSR entries
     float gamma;         // accumulation error factor g (set by launch_shortlist)
     int tile_best_min;   // bins with at least this many tiles learn tau from per-tile bests (ditto)
     int tile_k2;         // ... or, where the top m crowd into tile halves (4 tiles < m^2), from the tile_k2 best per tile half
@@ -199,9 +229,28 @@ void launch_pack_state_commit(const PackState &ps, const MemberPack &P, const do
                               int *labels, int B, const double *centers, const double *mu_g, double S, unsigned short *Zs,
                               int Dz, void *ms, const int *new_lab, const int *lab_old, int *inb, hipStream_t s);
 
+// ---- threshold pools: maintenance (PoolState above ShortlistArgs)
+// all pools from the CSR of the labelled samples (fit start)
+void launch_pool_build(const PoolState &ps, const unsigned short *Zs, const void *ms, const void *qn, int D, int Dz,
+                       const int *memb_id, const int *bin_ptr, int B, hipStream_t s);
+// batch open (behind the kernel that marks the batch's samples in inb): the slots of batch members become holes,
+// ok[c * B + h] = usable rows
+// (zero_me, optional: one int reset here -- the second-chance launch's overflow counter)
+void launch_pool_open(const PoolState &ps, const int *inb, int D, int Dz, int B, int *zero_me, hipStream_t s);
+// batch commit (behind the kernel that writes the final labels and refreshes the samples' shadow rows): holes whose sample
+// stayed in the bin are usable again, the others are emptied; the batch's ARRIVALS of every bin (final label c, label at
+// the batch's start another one) compete for the pools (c, *), replacing the slot with the largest key
+// (holes: the batch may have held labelled samples -- false in a fit's first sweep, whose batches are all unlabelled)
+void launch_pool_commit(const PoolState &ps, const unsigned short *Zs, const void *ms, const void *qn, int D, int Dz,
+                        const int *ids, int n, const int *new_lab, const int *lab_old, const int *labels, int B, bool holes,
+                        hipStream_t s);
+
 // flags64[bin][ceil(nq/64)] (pre-zeroed): set for (query tile of 64, bin) pairs whose shortlist overflowed
 // (and listed once in a.flaglist)
 void launch_shortlist(const ShortlistArgs &a, int *flags64, hipStream_t s);
+// the exact two-sweep selection for the listed work items only (a.worklist / a.nwork = the overflow list of a launch that
+// took its thresholds from the pools); what overflows here as well goes on a.flaglist / a.nflag for the brute-force kernel
+void launch_shortlist_worklist(const ShortlistArgs &a, int *flags64, hipStream_t s);
 
 struct RescoreArgs {
     const double *X;

@@ -565,10 +565,9 @@ __device__ __forceinline__ void query_norms_tile(const QnArgs &q, int tile_x, in
 // home[b] = the query tile (of kPfQ seats) where the positions nearest to bin b start: the shortlist launch runs the
 // query tiles of a bin from there on, wrapping round -- the long work items of a bin (its own neighbourhood) first, the
 // short ones (far queries, most of their tiles skipped) last, so that the launch does not end on long ones.
-__global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long long *ckey, const int *bq, int pos_begin,
-                                                           int nq, int B, int *qord, int *home, Gate gate)
+__device__ __forceinline__ void query_order_body(const unsigned long long *ckey, const int *bq, int pos_begin, int nq, int B,
+                                                 int *qord, int *home)
 {
-    CHB_GATE(gate);
     extern __shared__ int sh[];   // [B + 1] counts -> cursors, [1024] scan partials
     int *cnt = sh, *part = sh + B + 1;
     const int tid = threadIdx.x;
@@ -616,6 +615,24 @@ __global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long l
         const unsigned c = (unsigned)(k & 0xffffffffu);
         qord[atomicAdd(&cnt[(k != ~0ull && c < (unsigned)B) ? (int)c : B], 1)] = pos_begin + i;
     }
+}
+
+__global__ __launch_bounds__(1024) void query_order_kernel(const unsigned long long *ckey, const int *bq, int pos_begin,
+                                                           int nq, int B, int *qord, int *home, Gate gate)
+{
+    CHB_GATE(gate);
+    query_order_body(ckey, bq, pos_begin, nq, B, qord, home);
+}
+
+// the same for EVERY batch of a sweep in one launch (the fit loop knows the sweep's batches when it uploads the
+// permutation): block b orders the positions [geo[b].y, geo[b].z) of the batch that starts at perm + geo[b].x;
+// qord_all[geo[b].x + position index], home_all[b * B + bin]
+__global__ __launch_bounds__(1024) void query_order_sweep_kernel(const unsigned long long *ckey, const int *perm, const int4 *geo,
+                                                                 int B, int *qord_all, int *home_all)
+{
+    const int4 g = geo[blockIdx.x];
+    if (g.z > g.y)
+        query_order_body(ckey, perm + g.x, g.y, g.z - g.y, B, qord_all + g.x + g.y, home_all + (size_t)blockIdx.x * B);
 }
 
 __global__ __launch_bounds__(256) void query_norms_kernel(QnArgs q, int nqx)
@@ -780,7 +797,7 @@ __global__ __launch_bounds__(256) void pack_state_start_kernel(PackState ps, Mem
         __syncthreads();
         if (threadIdx.x == 0) {
             if (seg.gflag != nullptr && seg.nseg != nullptr) *seg.nseg = s_ni;
-            if (stats != nullptr) { stats[0] = s_max; stats[1] = s_tot; stats[2] = 0; stats[3] = 0; stats[4] = 0; stats[5] = ps.ctl[0]; }
+            if (stats != nullptr) { stats[0] = s_max; stats[1] = s_tot; stats[2] = 0; stats[3] = 0; stats[4] = 0; stats[5] = ps.ctl[0]; stats[6] = 0; stats[7] = 0; }
         }
         return;
     }
@@ -998,6 +1015,169 @@ __global__ __launch_bounds__(256) void pack_state_fix_kernel(PackState ps, Membe
 }
 
 // ---------------------------------------------------------------------------------------------
+// threshold pools (round 5)
+//
+// The base shortlist launch used to stream every bin TWICE per query tile: a threshold sweep that learns tau(j, c) (the m-th
+// smallest upper bound over the bin's members) and the admission sweep.  But ANY m base members of c bound the m-th nearest
+// distance from above, and which members are near a query is mostly decided by where the query's own bin lies: with
+// x_j = mu_h + e_j and x_p = mu_c + e_p the part of d^2(j, p) that varies over p is dominated by -2 <mu_h - mu_c, e_p>
+// (86 % of its variance on the benchmark generator, tools/pool_tau_probe.py).  So for every ordered pair (bin c, home bin
+// h) the 32 base members of c NEAREST TO THE CENTRE OF h are kept as one tile of shadow rows; a query whose nearest centre
+// is h learns tau(j, c) from that one tile (5.0-5.1 candidates per pair where the exact threshold gives 5.0; benchmark
+// configs[2] / [3] / [4]), and the bin itself is streamed once.  The query's own bin (h == c) keeps the two sweeps: a
+// bin's members nearest to its own centre say little about one particular member's neighbourhood.
+//   * key of a member p for home h: ||(x_p - mu_h) S||^2 from the fit's table qn; a pool holds the 32 smallest keys among
+//     the members it has been offered (build: all labelled samples; later: every batch's ARRIVALS -- a member that
+//     arrives replaces the slot with the largest key if its own is smaller);
+//   * validity needs only that a usable slot is a base member of c NOW: the slots of the open batch's members are holes
+//     while the batch is open (pool_open_kernel), and a commit makes a hole usable again if the sample stayed in c, else
+//     empties the slot (pool_update_kernel<false>); ok[c * B + h] = usable rows, and a (query tile, bin) whose pools hold
+//     fewer than m of them falls back to the two sweeps;
+//   * a tile's rows are copies of the samples' own shadow rows Zs (bias pieces included), empty slots and holes carry the
+//     padding rows' -inf bias piece.
+// One wavefront per pool: lanes 0 .. 31 hold the slots.
+constexpr int kPoolWin = 4096;   // candidates staged per pass of pool_update_kernel
+
+// the slot with the largest key (lowest lane among equals), on every lane
+__device__ __forceinline__ void pool_worst(float key, int lane, float &wkey, int &wlane)
+{
+    float k = lane < kPoolRows ? key : -INFINITY;
+    int l = lane;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        const float ok = __shfl_xor(k, off, 64);
+        const int ol = __shfl_xor(l, off, 64);
+        if (ok > k || (ok == k && ol < l)) { k = ok; l = ol; }
+    }
+    wkey = __shfl(k, 0, 64); wlane = __shfl(l, 0, 64);
+}
+
+// BUILD: candidates = all members of bin c (CSR), pools start empty.  Otherwise (commit): holes are resolved first (`holes`:
+// the batch may have held labelled samples), the candidates are the batch's arrivals of bin c.
+// Block (c, y): homes h = y * hb + w, w + 4, ... < min(B, (y + 1) * hb); one wavefront per pool, lanes 0 .. 31 = its slots.
+// (Tried in round 5: one block per bin with one HOME per lane, so that a candidate's keys are one coalesced load of its qn
+//  row -- 64 .. 200 blocks of long serial loops instead of B x B short wavefronts: 11.9 against 0.58 ms per sweep at
+//  100k x 136 x 64.  The parallel form stays.)
+template <bool BUILD>
+__global__ __launch_bounds__(256) void pool_update_kernel(PoolState ps, const unsigned short *Zs, const float4 *ms,
+                                                          const float2 *qn, int D, int Dz, int B, int hb,
+                                                          const int *memb_id, const int *bin_ptr,   // BUILD
+                                                          const int *ids, int n, const int *new_lab, const int *lab_old,
+                                                          const int *labels, int holes, Gate gate)
+{
+    CHB_GATE(gate);
+    __shared__ int s_ids[kPoolWin];
+    __shared__ int s_n;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int h_begin = blockIdx.y * hb, h_end = min(B, h_begin + hb);
+    const int cpr = Dz >> 3;
+    const int src_n = BUILD ? bin_ptr[c + 1] - bin_ptr[c] : n;
+    const int nwin = max(1, (src_n + kPoolWin - 1) / kPoolWin);
+    for (int win = 0; win < nwin; ++win) {
+        __syncthreads();
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        const int w0 = win * kPoolWin, w1 = min(src_n, w0 + kPoolWin);
+        if (BUILD) {
+            for (int i = w0 + tid; i < w1; i += 256) s_ids[i - w0] = memb_id[bin_ptr[c] + i];
+            if (tid == 0) s_n = w1 - w0;
+        } else {
+            // (four positions per load: the scan of the batch's labels is every block's first ~K / 256 dependent loads)
+            for (int i = w0 + 4 * tid; i < w1; i += 1024) {
+                if (i + 4 <= w1) {
+                    const int4 nl = *reinterpret_cast<const int4 *>(new_lab + i), lo = *reinterpret_cast<const int4 *>(lab_old + i);
+                    if (nl.x == c && lo.x != c) s_ids[atomicAdd(&s_n, 1)] = ids[i];
+                    if (nl.y == c && lo.y != c) s_ids[atomicAdd(&s_n, 1)] = ids[i + 1];
+                    if (nl.z == c && lo.z != c) s_ids[atomicAdd(&s_n, 1)] = ids[i + 2];
+                    if (nl.w == c && lo.w != c) s_ids[atomicAdd(&s_n, 1)] = ids[i + 3];
+                } else {
+                    for (int k = i; k < w1; ++k)
+                        if (new_lab[k] == c && lab_old[k] != c) s_ids[atomicAdd(&s_n, 1)] = ids[k];
+                }
+            }
+        }
+        __syncthreads();
+        const int ncand = s_n;
+        if (!BUILD && ncand == 0 && !(win == 0 && holes)) continue;   // (nothing arrives in this bin, no hole to look for)
+        for (int h = h_begin + w; h < h_end; h += 4) {
+            const size_t slot = ((size_t)c * B + h) * kPoolRows + (size_t)(lane & 31);
+            float key = INFINITY, sn = 0.f;
+            int id = -1, hole = 0, changed = 0;
+            if (BUILD && win == 0) {
+                // empty pool: every row a padding row (finite features, first bias piece -inf)
+                for (int r = lane >> 4; r < kPoolRows; r += 4)
+                    pack_padding_row(ps.Z + (((size_t)c * B + h) * kPoolRows + r) * Dz, D, Dz, lane & 15);
+            } else if (lane < kPoolRows) {
+                key = ps.key[slot]; id = ps.id[slot]; sn = ps.sn[slot];
+                if (holes) hole = ps.hole[slot];
+            }
+            if (!BUILD && win == 0 && lane < kPoolRows && hole) {
+                if (id >= 0 && labels[id] == c) {
+                    ps.Z[slot * Dz + D] = Zs[(size_t)id * Dz + D];   // usable again (the row itself never changed)
+                } else {
+                    id = -1; key = INFINITY; sn = 0.f;               // left the bin: the slot is empty (its row stays -inf)
+                }
+                hole = 0; changed |= 2;
+            }
+            float wkey; int wlane;
+            pool_worst(key, lane, wkey, wlane);
+            for (int base = 0; base < ncand; base += 64) {
+                const int cid = base + lane < ncand ? s_ids[base + lane] : -1;
+                const float ck = cid >= 0 ? qn[(size_t)cid * B + h].x : INFINITY;
+                unsigned long long mask = __ballot(cid >= 0 && ck < wkey);
+                while (mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const float bk = __shfl(ck, b, 64);
+                    const int bid = __shfl(cid, b, 64);
+                    if (bk < wkey) {   // (the bar may have dropped since the ballot)
+                        if (lane == wlane) { key = bk; id = bid; changed |= 1; }
+                        pool_worst(key, lane, wkey, wlane);
+                    }
+                }
+            }
+            // the rows of the slots that changed hands
+            const unsigned long long chm = __ballot((changed & 1) != 0 && lane < kPoolRows);
+            if (changed & 1) sn = sqrtf(ms[id].z) * (1.0f + 2e-6f);
+            for (unsigned long long mm = chm; mm; mm &= mm - 1) {
+                const int r = __ffsll((long long)mm) - 1;
+                const int rid = __shfl(id, r, 64);
+                if (lane < cpr)
+                    *reinterpret_cast<uint4 *>(ps.Z + (((size_t)c * B + h) * kPoolRows + r) * Dz + lane * 8) =
+                        *reinterpret_cast<const uint4 *>(Zs + (size_t)rid * Dz + lane * 8);
+            }
+            const bool wr = BUILD || __ballot(changed != 0) != 0ull;   // (a pool nothing happened to is not written back)
+            if (wr) {
+                float tn = lane < kPoolRows ? sn : 0.f;
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) tn = fmaxf(tn, __shfl_xor(tn, off, 64));
+                if (lane < kPoolRows) { ps.key[slot] = key; ps.id[slot] = id; ps.sn[slot] = sn; ps.hole[slot] = hole; }
+                if (lane == 0) ps.tsn[(size_t)c * B + h] = tn;
+            }
+        }
+    }
+}
+
+// batch open: one thread per slot
+__global__ __launch_bounds__(256) void pool_open_kernel(PoolState ps, const int *inb, int D, int Dz, long long nslot, int *zero_me,
+                                                        Gate gate)
+{
+    CHB_GATE(gate);
+    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (slot == 0 && zero_me != nullptr) *zero_me = 0;   // (the counter of the second-chance launch's overflow list)
+    bool usable = false;
+    if (slot < nslot) {
+        const int id = ps.id[slot];
+        const bool inbatch = id >= 0 && inb[id] >= 0;
+        if (inbatch) { ps.hole[slot] = 1; ps.Z[(size_t)slot * Dz + D] = kF16NegInf; }
+        usable = id >= 0 && !inbatch;
+    }
+    const unsigned long long bal = __ballot(usable);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 31) == 0 && slot < nslot) ps.ok[slot >> 5] = __popc((unsigned)(bal >> (lane & 32)));
+}
+
+// ---------------------------------------------------------------------------------------------
 // the shortlist kernel
 //
 // Workgroup = 128 batch positions (32 per wavefront: members are the A operand, queries the B
@@ -1113,12 +1293,27 @@ __device__ __noinline__ void shortlist_flush_call(const unsigned *pool, int npar
     }
 }
 
-template <int ML, bool UPD, int KS, int SEG = 0, bool SKIP = false>
+// POOL (base mode, SEG = 0; launched when a.pool.Z is set) -- threshold pools, see "threshold pools" above.  The queries
+// are seated by their nearest bin centre (a.qord); a workgroup's seats then span the home bins h_lo .. h_lo + n_home - 1
+// (usually one to three).  For a bin c outside that range whose pools (c, h_lo ..) all hold at least m usable rows the
+// threshold sweep streams those n_home POOL TILES instead of the bin's tiles -- a lane takes part only in the tile of its
+// own home bin, a wavefront only computes the tiles of its own lanes' homes -- and the admission sweep streams the bin as
+// before: ntile + n_home tiles instead of 2 ntile.  Every other (workgroup, bin) keeps the two sweeps.
+//
+// WORK (base mode, the plain two-sweep build) -- the second chance of the pool launches.  A threshold that comes from a pool
+// tile is an upper bound of the m-th nearest distance, but for a few (query, bin) pairs a loose one (a query far out in its
+// bin: 0.05 % of the pairs at 500k x 140 x 128 admit more than the 128 candidates a shortlist holds).  Those pairs' work
+// items (64 positions x a bin) are on the overflow list; before the fp64 brute-force kernel gets them, this launch runs the
+// exact two-sweep selection for them alone: one workgroup per listed item (a.worklist / a.nwork, read on the device; items
+// beyond the grid go straight on to the brute-force list), seats 0 .. 63 = the item's positions.
+template <int ML, bool UPD, int KS, int SEG = 0, bool SKIP = false, bool POOL = false, bool WORK = false>
 __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 2))) ? 4 : 3) void shortlist_kernel(ShortlistArgs a, int nqt, int nchunk,
                                                                          int bpw, int *flags64, int nqt64, Gate gate)
 {
     CHB_GATE(gate);
+    static_assert(!WORK || (!UPD && SEG == 0 && !SKIP && !POOL), "the work-list form is the plain base build");
     static_assert(SEG == 0 || !UPD, "segments exist for base members only");
+    static_assert(!POOL || (!UPD && SEG == 0), "threshold pools serve the ordinary base launch");
 #ifdef CHB_DEV_KNOBS
     const unsigned long long dbg_t0 = wall_clock64();
     int dbg_tiles = 0;
@@ -1148,11 +1343,20 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     const int nitem = SEG == 0 ? nchunk : min(*a.seg.nseg, a.seg.cap);
     const int total = nqt * nitem;
     const int per = (total + 7) >> 3;
-    if ((int)(blockIdx.x >> 3) >= per) return;
-    const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (W >= total) return;
-    const int chunk = W / nqt;
-    int qt = W - chunk * nqt;
+    int witem = -1;
+    if (WORK) {
+        const int nw = *a.nwork;
+        if (blockIdx.x == 0)   // (more items than workgroups: the rest keeps its flag and goes to the brute-force kernel)
+            for (int i = (int)gridDim.x + (int)threadIdx.x; i < nw; i += (int)blockDim.x) a.flaglist[atomicAdd(a.nflag, 1)] = a.worklist[i];
+        if ((int)blockIdx.x >= nw) return;
+        witem = a.worklist[blockIdx.x];
+        if (threadIdx.x == 0) flags64[witem] = 0;   // (set again below if the exact selection overflows as well)
+        __syncthreads();
+    } else if ((int)(blockIdx.x >> 3) >= per) return;
+    const int W = WORK ? 0 : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (!WORK && W >= total) return;
+    const int chunk = WORK ? witem / nqt64 : W / nqt;
+    int qt = WORK ? 0 : W - chunk * nqt;
     // (tile skipping, one bin per workgroup: the bin's query tiles start at its own neighbourhood's -- long items first)
     if (SKIP && a.home != nullptr && bpw == 1) { qt += a.home[chunk]; qt = qt >= nqt ? qt - nqt : qt; }
     int c0 = chunk * bpw, c1 = min(a.B, c0 + bpw);
@@ -1169,16 +1373,16 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     const unsigned smem_base = lds_addr(smem);
     const unsigned pool_base = lds_addr(sPool) + (unsigned)(w * kPoolW * 4);
     const int col = lane & 31, h = lane >> 5;
-    const int pos0 = a.pos_begin + qt * kPfQ;
+    const int pos0 = WORK ? a.pos_begin + (witem - chunk * nqt64) * kQTile : a.pos_begin + qt * kPfQ;
     const int m = a.m;
 
     // my query: lane (col, h) owns B[k = 16 s + 8 h + j][col] of its global-centred row
     // (seated by position, or -- a.qord -- in the order of their nearest bin centre)
     const int qseat = pos0 + 32 * w + col;
-    const bool qvalid = qseat < a.pos_end;
+    const bool qvalid = qseat < a.pos_end && (!WORK || 32 * w + col < kQTile);
     // (kSeated: only the tile-skipping launches -- and the segment launches that may accompany them -- seat their queries
     //  out of position order; the other builds keep seat == position and need no table)
-    constexpr bool kSeated = SKIP || SEG != 0;
+    constexpr bool kSeated = SKIP || SEG != 0 || POOL;
     const int qpos = (kSeated && a.qord != nullptr && qvalid) ? a.qord[qseat - a.pos_begin] : qseat;
     int *sQpos = reinterpret_cast<int *>(kFour ? sGb : sGb + kPfQ);   // [kPfQ] position of every seat of the workgroup (for the flush)
     // [4] tile skipping: "somebody in the workgroup needs tile t" for t = 0 .. 3 (mod 4); accessed by LDS address only
@@ -1196,6 +1400,46 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     }
     const float snq = sqrtf(nq) * (1.0f + kSlack);
     const float qposf = (float)qpos;
+    // threshold pools: my query's home bin (its nearest centre), the workgroup's range of home bins and this wavefront's
+    int hq = -1, h_lo = 0, n_home = 0x3fffffff, hw_lo = 0, hw_hi = -1;
+    if (POOL) {
+        if (qvalid) {
+            const unsigned long long k = a.ckey[sidx];
+            hq = (k != ~0ull && (unsigned)(k & 0xffffffffu) < (unsigned)a.B) ? (int)(k & 0xffffffffu) : -1;
+        }
+        int lo = qvalid ? (hq < 0 ? -0x40000000 : hq) : 0x7fffffff, hi = qvalid ? (hq < 0 ? 0x40000000 : hq) : -0x7fffffff;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+        hw_lo = __builtin_amdgcn_readfirstlane(lo); hw_hi = __builtin_amdgcn_readfirstlane(hi);
+        int *sHome = sQpos + kPfQ + 4;   // [2 kPfW] behind the tile-skipping flags
+        if (lane == 0) { sHome[2 * w] = hw_lo; sHome[2 * w + 1] = hw_hi; }
+        __syncthreads();
+        int glo = 0x7fffffff, ghi = -0x7fffffff;
+#pragma unroll
+        for (int ww = 0; ww < kPfW; ++ww) { glo = min(glo, sHome[2 * ww]); ghi = max(ghi, sHome[2 * ww + 1]); }
+        // (a query without a key, or seats spanning many homes: no pool for this workgroup)
+        if (ghi >= glo && glo >= 0 && ghi - glo < kPoolMaxHomes && ghi < a.B) { h_lo = glo; n_home = ghi - glo + 1; }
+        h_lo = __builtin_amdgcn_readfirstlane(h_lo); n_home = __builtin_amdgcn_readfirstlane(n_home);
+    }
+    // does this workgroup take bin c's threshold from the pools (c, h_lo ..)?  (wave-uniform; the issue side and the
+    // consumers of the tile stream ask at different times and must get the same answer: a.pool.ok is constant here)
+    // (decided ONCE per workgroup, for all its bins, and kept as a bit mask: the issue side and the consumers then test a bit.
+    //  With the decision as a function that loops over the pools' counters at every use, hipcc 7.2 mis-scheduled the
+    //  assignments behind the loop in two of its inlined copies -- a dropped base pointer (GPU memory fault), then, in the
+    //  copy inside the tile loop, short shortlists for the second bin of a workgroup: experiments 12 and 32 of round 5)
+    unsigned long long pool_bins = 0ull;
+    if (POOL && n_home <= kPoolMaxHomes && c1 - c0 <= 64) {
+        for (int c = c0; c < c1; ++c) {
+            int bad = (c >= h_lo && c < h_lo + n_home) ? 1 : 0;
+            for (int t = 0; t < n_home; ++t) bad |= a.pool.ok[(size_t)c * a.B + h_lo + t] < a.m ? 1 : 0;
+            pool_bins |= (unsigned long long)(bad ^ 1) << (c - c0);
+        }
+    }
+    {
+        const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)pool_bins), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(pool_bins >> 32));
+        pool_bins = ((unsigned long long)hi32 << 32) | lo32;
+    }
+    auto pool_mode_of = [&](int c) -> bool { return POOL && ((pool_bins >> (c - c0)) & 1ull) != 0ull; };
 
     // DMA roles: wavefront w moves the 1-KiB pieces w, w+4, w+8 of a tile (lane l of piece i fills
     // LDS chunk 64 i + l from the global chunk the swizzle maps there: chunk cs of row r sits at
@@ -1221,6 +1465,15 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     int ic = c0, it = 0, isw = (UPD || SEG == 2) ? 1 : 0, ibuf = 0;
     int irow0 = 0, int_ = 0;   // first padded row and tile count of bin ic
     bool ivalid = false;
+    // (POOL: the current run's source and extent -- the pool tiles (ic, h_lo ..) in the threshold sweep of a pool-mode bin,
+    //  else the bin's own tiles, whose first row and count are kept in brow0 / bnt.  The pool tiles live in a buffer of their
+    //  own; the run's source is kept as ONE 64-bit byte offset from the pack's base -- with a second base pointer selected
+    //  per run, hipcc 7.2 dropped the assignment of the pool's base on the path behind pool_mode_of's loop (found in the
+    //  ISA after a GPU memory fault: the pool tile's row offset was applied to the pack))
+    const long long pool_delta = (long long)reinterpret_cast<unsigned long long>(a.pool.Z) -
+                                 (long long)reinterpret_cast<unsigned long long>(a.P.Z);
+    long long ioff = 0;   // byte offset of the current run's first tile from zall
+    int brow0 = 0, bnt = 0;
     // move to the first / next non-empty bin
 #define CHB_SL_ISSUE_SEEK()                                                                        \
     {                                                                                              \
@@ -1233,12 +1486,35 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
             if (int_ > 0) { ivalid = true; break; }                                                \
             ++ic;                                                                                  \
         }                                                                                          \
+        if (POOL && ivalid) {                                                                      \
+            brow0 = irow0; bnt = int_;                                                             \
+            const bool pm_ = pool_mode_of(ic);                                                     \
+            ioff = pm_ ? pool_delta + (long long)((ic * a.B + h_lo) * kPoolRows) * ROWB : (long long)irow0 * ROWB; \
+            int_ = pm_ ? n_home : int_;                                                            \
+        }                                                                                          \
     }
+#ifdef CHB_DEV_KNOBS
+#define CHB_SL_BOUNDS_DMA()                                                                        \
+        if (a.viol != nullptr) {                                                                   \
+            const long long bo_ = POOL ? ioff + (long long)it * kPfP * ROWB : (long long)row_ * ROWB; \
+            const bool in_pack_ = bo_ >= 0 && bo_ + (long long)kPfP * ROWB <= a.viol_rows * ROWB;  \
+            const bool in_pool_ = POOL && bo_ >= pool_delta && bo_ + (long long)kPfP * ROWB <= pool_delta + a.viol_pool_rows * ROWB; \
+            if (!in_pack_ && !in_pool_) {                                                          \
+                if (tid == 0 && atomicCAS(&a.viol[0], 0, 1) == 0) {                                \
+                    a.viol[1] = ic; a.viol[2] = it; a.viol[3] = (int)(bo_ / ROWB); a.viol[4] = isw; a.viol[5] = int_; a.viol[6] = (int)(pool_delta >> 8); a.viol[7] = (int)blockIdx.x; \
+                }                                                                                  \
+                src_ = zall;                                                                       \
+            }                                                                                      \
+        }
+#else
+#define CHB_SL_BOUNDS_DMA()
+#endif
 #define CHB_SL_ISSUE()                                                                             \
     {                                                                                              \
         unsigned char *dst_ = smem + ibuf * BUFB;                                                  \
         const size_t row_ = (size_t)irow0 + (size_t)it * kPfP;                                     \
-        const unsigned char *src_ = zall + row_ * ROWB;                                            \
+        const unsigned char *src_ = POOL ? zall + (ioff + (long long)it * (kPfP * ROWB)) : zall + row_ * ROWB; \
+        CHB_SL_BOUNDS_DMA()                                                                        \
         _Pragma("unroll") for (int rep_ = 0; rep_ < CHB_SL_DMAREP; ++rep_)                         \
         _Pragma("unroll") for (int j = 0; j < 3; ++j)                                              \
             if (w + kPfW * j < KS)                                                                 \
@@ -1260,7 +1536,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
 #define CHB_SL_ISSUE_NEXTRUN()                                                                     \
     {                                                                                              \
         it = 0;                                                                                    \
-        if (!UPD && SEG == 0 && isw == 0) isw = 1;                                                 \
+        if (!UPD && SEG == 0 && isw == 0) { isw = 1; if (POOL) { ioff = (long long)brow0 * ROWB; irow0 = brow0; int_ = bnt; } } \
         else { isw = (UPD || SEG == 2) ? 1 : 0; ++ic; CHB_SL_ISSUE_SEEK() }                        \
     }
     int n_issued = 0, n_consumed = 0;
@@ -1285,6 +1561,15 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     // bin); the per-query counters keep running, so the pool can be emptied in the middle of a bin
     // (SEG = 2: the shortlist is shared with the bin's other segments -- the parked entries are counted per query
     //  first, one global atomic per query reserves their places, then they are written behind that base)
+#ifdef CHB_DEV_KNOBS
+#define CHB_SL_BOUNDS_FLUSH()                                                                      \
+            if (a.viol != nullptr && ((long long)mb_ + e >= a.viol_members || e < 0)) {            \
+                if (atomicCAS(&a.viol[0], 0, 2) == 0) { a.viol[1] = c; a.viol[2] = e; a.viol[3] = mb_; a.viol[4] = qc; a.viol[7] = (int)blockIdx.x; } \
+                continue;                                                                          \
+            }
+#else
+#define CHB_SL_BOUNDS_FLUSH()
+#endif
 #define CHB_SL_FLUSH()                                                                             \
     {                                                                                              \
         const int mb_ = a.bin_ptr[c];                                                              \
@@ -1308,6 +1593,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
             const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));                     \
             int off = atomicAdd(&sCnt[32 * w + qc], 1);                                            \
             if (SEG == 2) off += sGb[32 * w + qc];                                                 \
+            CHB_SL_BOUNDS_FLUSH()                                                                  \
             if (off < a.cand_cap)                                                                  \
                 a.cand[(kSeated ? (size_t)c * a.Kcap + sQpos[32 * w + qc] : (size_t)c * a.Kcap + pos0 + 32 * w + qc) * a.cand_cap + off] = a.memb_id[mb_ + e]; \
         }                                                                                          \
@@ -1318,6 +1604,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     }
     int cbuf = 0;
     int wt_seen = 0, wt_skipped = 0, wt_unloaded = 0;   // tiles this wavefront met / skipped / found not loaded (statistics)
+    int pool_cand = 0, pool_pairs = 0;                  // POOL: candidates admitted for / pairs of this lane's query (statistics)
     for (int c = c0; c < c1; ++c) {
         const int row0 = a.P.pad_ptr[c];
         int ntile = a.P.nt != nullptr ? a.P.nt[c] : (a.P.pad_ptr[c + 1] - row0) / kPfP;
@@ -1380,6 +1667,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
         //  25-49 tiles the per-tile-best tau is so loose that the hull kernel gathers 17 instead of ~15.5 rows per pair:
         //  39.5 against 43.5 ms per sweep with every value competing, 39.1 with the three best per tile half (kmax below);
         //  at m <= 8 the cheaper sweep 0 wins, at m = 12 it is a tie)
+        const bool pmode = POOL && pool_mode_of(c);   // this bin's threshold comes from the pool tiles (c, h_lo ..)
         const bool tile_best = !SKIP && (SEG != 0 || (ntile >= a.tile_best_min && 4 * ntile >= m * m)) && !(!UPD && a.skip != 0);
         // (in between: a bin with enough tiles for the shortcut but crowded tile halves lets its tile_k2 best values per tile
         //  half compete -- a bounded loop)
@@ -1396,13 +1684,19 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
 
         for (int sweep = (UPD || SEG == 2) ? 1 : 0; sweep < (SEG == 1 ? 1 : 2); ++sweep) {
             const float rgs = (sweep ? rg : -rg) * (1.0f + kSlack);
+            // POOL: the threshold sweep of a pool-mode bin runs over the n_home pool tiles; their norms are a.pool.tsn's
+            const bool psweep = POOL && pmode && sweep == 0;
+            const float *tsn_run = psweep ? a.pool.tsn + (size_t)c * a.B + h_lo : tsn_c;
             // tile skipping: the tiles' norm bounds of this run, 64 of them across the lanes of a VGPR (an ordinary load,
             // once per sweep and then every 61 tiles: its wait drains the tile DMA queue, which at that rate costs nothing;
             // the table has slack behind); a bound is then one v_readlane
             float v_tsn = 0.f;
             int tbase = 0;
-            if (SKIP && ntile > 0) {
-                v_tsn = tsn_c[lane];
+            // (the pool sweep of a tile-skipping build skips nothing: it takes the plain builds' path through the tile loop --
+            //  no bounds table, no flags, the tile's norm by a scalar load)
+            const bool skp = can_skip && !psweep;
+            if (SKIP && !psweep && ntile > 0) {
+                v_tsn = tsn_run[lane];
                 asm volatile("" : "+v"(v_tsn));   // (waited for here, not at a use inside the tile loop)
                 // (the "somebody needs tile t" flags of this sweep; nobody reads the previous sweep's any more: its last
                 //  tiles' successors in the stream were this sweep's first tiles, which are always loaded)
@@ -1443,7 +1737,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
             // posts "one of my queries needs tile ct + 3" (LDS flags, made visible by the next barrier); when the flag of
             // the tile about to be requested (two ahead) is down, nobody needs it or any later tile: the run ends two
             // tiles from here, for the issue side (on to the next sweep / bin at once) and for the consumers alike.
-            int nt_run = ntile;
+            int nt_run = psweep ? n_home : ntile;
             // Everything this (bin, sweep) has loaded so far -- bounds, thresholds, spilled values -- is waited for HERE, by a
             // wait the compiler knows (the builtin, not asm): otherwise its own waitcnt pass finds those loads still pending
             // on the path into the loop and puts `s_waitcnt vmcnt(0)` in front of their first use INSIDE the tile loop, on
@@ -1467,7 +1761,8 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                     float mx = acc[0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-                    if (tile_best) {
+                    if (POOL && psweep && hq != h_lo + ctp) mx = -INFINITY;   // (another home bin's pool tile)
+                    if (tile_best && !psweep) {
                         // Large bins: only the BEST of the 16 values enters the list.  The m-th best
                         // of per-(tile, lane half) bests is the m-th best of m distinct members, i.e.
                         // still a valid tau; it is the exact m-th unless two of the top m share a tile
@@ -1481,7 +1776,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                     } else
                     // (the counted form only in the builds for m > 8, the only ones that can reach kmax: in the 128-register
                     //  builds the counter costs the shortlist kernel 1.5 %)
-                    for (int left = ML > 8 ? kmax : 1; left > 0 && mx - dlt > thr_s; left -= ML > 8 ? 1 : 0) {
+                    for (int left = ML > 8 ? (psweep ? 0x7fffffff : kmax) : 1; left > 0 && mx - dlt > thr_s; left -= ML > 8 ? 1 : 0) {
                         list_insert_desc<ML>(lb, mx - dlt);
                         thr_s = lb[ML - 1];
                         if (can_skip && thr_s > -INFINITY)
@@ -1499,7 +1794,9 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                     // shortlists are long, and in the tile-skipping builds, whose workgroups hold queries of ONE
                     // neighbourhood (in their own bin all of them park candidates); in the 128-VGPR builds the extra
                     // code pushes query fragments into scratch inside this loop
-                    if (SKIP && ML <= 8) {
+                    // (and in the pool builds: a query whose nearest centre says little about where it lies -- a bin made of
+                    //  several clusters -- gets a loose threshold from the pool tile and parks many candidates)
+                    if ((SKIP || POOL) && ML <= 8) {
 #ifdef CHB_DEV_KNOBS
                         if (wcnt >= kPoolW / 2 && wcnt <= kPoolW && !kNoMidFlush) {
 #else
@@ -1534,9 +1831,9 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
             };
             for (int ct = 0; ct < nt_run; ++ct) {
                 wait_vmcnt(n_issued - n_consumed > 1 ? n_w : 0);   // my pieces of this tile have landed
-                if (can_skip) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (and my flag writes)
+                if (skp) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (and my flag writes)
                 __builtin_amdgcn_s_barrier();   // everybody's have; the buffer two tiles ahead is free again
-                if (can_skip && ct + 2 < nt_run && ct + 2 >= 3) {
+                if (skp && ct + 2 < nt_run && ct + 2 >= 3) {
                     // (the issue side stands at tile ct + 2 of this very run)
                     // (asm read: the compiler would order an ordinary LDS read behind the tile DMA -- vmcnt(0))
                     int nd;
@@ -1551,19 +1848,19 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                     }
                 }
                 if (ivalid) CHB_SL_ISSUE()
-                if (can_skip && tid == 0) lds_write_u32(need_base + 4u * (unsigned)((ct + 1) & 3), 0u);   // (read one tile ago; next written in two)
+                if (skp && tid == 0) lds_write_u32(need_base + 4u * (unsigned)((ct + 1) & 3), 0u);   // (read one tile ago; next written in two)
 
                 const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
                 // rows held by this lane: (r & 3) + 8 (r >> 2) + 4 h
                 const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
                 float tsn_t = 0.f, tsn_3 = 0.f;   // largest member norm of this tile (and of the rest of the bin) / three tiles on
-                if (SKIP) {
-                    if (ct + 3 - tbase >= 64) { tbase = ct; v_tsn = tsn_c[ct + lane]; asm volatile("" : "+v"(v_tsn)); }   // (waited for here, not at a use)
+                if (SKIP && !psweep) {
+                    if (ct + 3 - tbase >= 64) { tbase = ct; v_tsn = tsn_run[ct + lane]; asm volatile("" : "+v"(v_tsn)); }   // (waited for here, not at a use)
                     tsn_t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_tsn), ct - tbase));
                     tsn_3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v_tsn), ct + 3 - tbase));
                 }
                 bool do_tile = true;
-                if (can_skip) {
+                if (skp) {
                     const float thr_now = sweep == 0 ? tau_run : hi_s1;
                     // does anybody of this wavefront need tile ct + 3?  (with the threshold as it stands: it only tightens)
                     if (ct + 3 < nt_run) {
@@ -1580,6 +1877,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                     if (__ballot(need0) == 0ull) { do_tile = false; ++wt_skipped; }
 #endif
                 }
+                if (POOL && psweep && (h_lo + ct < hw_lo || h_lo + ct > hw_hi)) do_tile = false;   // none of my lanes' home
                 if (!do_tile) {
                     if (kDefer && pend) { epilogue(dlt_p, ct_p); pend = false; }
                     ++n_consumed;
@@ -1620,8 +1918,8 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                 // base mode (builds without tile skipping): the tile's largest member norm, a SCALAR load (an ordinary vector
                 // load here would make the compiler drain the tile DMA queue); it is complete behind the fragment reads'
                 // lgkmcnt(0) below
-                if (!UPD && !SKIP) {
-                    const unsigned long long ta = reinterpret_cast<unsigned long long>(tsn_c + ct);
+                if (!UPD && (!SKIP || psweep)) {
+                    const unsigned long long ta = reinterpret_cast<unsigned long long>(tsn_run + ct);
                     const unsigned ta_lo = __builtin_amdgcn_readfirstlane((unsigned)ta);
                     const unsigned ta_hi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
                     const unsigned long long ta_s = ((unsigned long long)ta_hi << 32) | ta_lo;
@@ -1633,7 +1931,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                     f16x8 h0 = lds_read_frag<0>(fa0), h1 = lds_read_frag<0>(fa1), h2 = lds_read_frag<64>(fa0),
                           h3 = lds_read_frag<64>(fa1), h4 = lds_read_frag<128>(fa0);
                     if (kDefer && pend) epilogue(dlt_p, ct_p);   // (the previous tile's, under this tile's LDS reads)
-                    if (SKIP)
+                    if (SKIP && !POOL)
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : : "memory");
                     else
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+s"(tsn_t) : : "memory");
@@ -1660,7 +1958,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                     f16x8 h0 = lds_read_frag<0>(fa0), h1 = lds_read_frag<32>(fa0), h2 = lds_read_frag<64>(fa0),
                           h3 = lds_read_frag<96>(fa0), h4 = lds_read_frag<128>(fa0);
                     if (pend) epilogue(dlt_p, ct_p);   // (the previous tile's, under this tile's LDS reads)
-                    if (SKIP)
+                    if (SKIP && !POOL)
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4) : : "memory");
                     else
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+s"(tsn_t) : : "memory");
@@ -1691,7 +1989,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                     }
                 }
                 if (kDefer && pend) epilogue(dlt_p, ct_p);   // (the previous tile's, under this tile's LDS reads)
-                if (SKIP)
+                if (SKIP && !POOL)
                     asm volatile("s_waitcnt lgkmcnt(0)"
                                  : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
                                    "+v"(af[6]), "+v"(af[7]), "+v"(af[8])
@@ -1722,7 +2020,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
                 if (++cbuf == NBUF) cbuf = 0;
             }
             if (kDefer && pend) { epilogue(dlt_p, ct_p); pend = false; }   // the run's last tile
-            if (can_skip) wt_unloaded += ntile - nt_run;
+            if (skp) wt_unloaded += ntile - nt_run;
         }
 
         if (SEG == 1) {
@@ -1748,6 +2046,7 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
         CHB_SL_FLUSH()
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
+        if (POOL) { pool_cand += ccount; pool_pairs += (qvalid && h == 0) ? 1 : 0; }
         if (qvalid && h == 0) {
             // (SEG = 2: the bin's counter is the sum of its segments' reservations; the last one past the capacity
             //  flags the pair, and the brute-force fallback then rewrites list and count)
@@ -1771,12 +2070,19 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
     // (statistics: about 64 workgroups spread evenly over the work items -- the first ones of a launch are the bins' own
     //  neighbourhoods since the query tiles are rotated, where least can be skipped)
     //  (an ODD stride: the work items are (bin, query tile) with the tile running fastest, usually over a power of two)
+    if (POOL && a.pool_stat != nullptr && W % (max(1, total >> 6) | 1) == 0) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { pool_cand += __shfl_xor(pool_cand, off, 64); pool_pairs += __shfl_xor(pool_pairs, off, 64); }
+        if (lane == 0) { atomicAdd(&a.pool_stat[0], pool_cand); atomicAdd(&a.pool_stat[1], pool_pairs); }
+    }
     if (SKIP && a.skip_stat != nullptr && W % (max(1, total >> 6) | 1) == 0 && lane == 0) {
         atomicAdd(&a.skip_stat[0], wt_skipped);
         atomicAdd(&a.skip_stat[1], wt_seen);
         atomicAdd(&a.skip_stat[2], wt_unloaded);
     }
 #undef CHB_SL_FLUSH
+#undef CHB_SL_BOUNDS_DMA
+#undef CHB_SL_BOUNDS_FLUSH
 #undef CHB_SL_ISSUE
 #undef CHB_SL_ISSUE_NEXTRUN
 #undef CHB_SL_ISSUE_SEEK
@@ -1785,8 +2091,8 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
 // (four: the layout of the kFour builds -- no bias / norm column slots, the seat table in the segment bases' place)
 static size_t shortlist_lds_bytes(int ks, int ml, bool four = false)
 {
-    if (four) return (size_t)3 * (kPfP * 32 * ks) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 3 * kPfQ * 4 + 16;
-    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 4 * kPfQ * 4 + 16;
+    if (four) return (size_t)3 * (kPfP * 32 * ks) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 3 * kPfQ * 4 + 16 + 8 * kPfW;
+    return (size_t)3 * (kPfP * 32 * ks + 512) + (size_t)kPfW * shortlist_pool_entries(ml) * 4 + 4 * kPfQ * 4 + 16 + 8 * kPfW;
 }
 
 template <int ML, bool UPD>
@@ -1807,11 +2113,38 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
     if (env_bpw == -2) { const char *e = getenv("CHB_SL_BPW"); env_bpw = e ? atoi(e) : 0; }
     if (env_bpw > 0) bpw = env_bpw;
 #endif
+    bool pool_build = false;
+    if constexpr (!UPD) pool_build = a.pool.Z != nullptr && a.qord != nullptr && a.ckey != nullptr;
+    // (a pool-mode bin is ntile + a few tiles instead of 2 ntile: twice the bins per workgroup keep the streams as long)
+    if (pool_build && !skip_build) bpw = (int)std::max<long long>(1, units / 1024);
+#ifdef CHB_DEV_KNOBS
+    if (env_bpw > 0) bpw = env_bpw;
+#endif
+    // (the tile-skipping builds are one bin per workgroup by construction -- their early run ends and, with the pools, the
+    //  order of a bin's runs have only ever been exercised that way; the developer knob above does not reach them:
+    //  experiment 29 of round 5 saw short shortlists from the skipping pool build with two and more bins per workgroup)
+    if (skip_build) bpw = 1;
     bpw = std::min(bpw, a.B);
     const int nchunk = (a.B + bpw - 1) / bpw;
     const int total = nqt * nchunk;
     const int grid = ((total + 7) / 8) * 8;
-    if (skip_build) {
+    if (pool_build) {
+        if constexpr (!UPD) {
+            if (skip_build) {
+                if (a.Dz == 144)
+                    hipLaunchKernelGGL((shortlist_kernel<ML, false, 9, 0, true, true>), dim3(grid), dim3(64 * kPfW),
+                                       shortlist_lds_bytes(9, ML), s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+                else
+                    hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 0, true, true>), dim3(grid), dim3(64 * kPfW),
+                                       shortlist_lds_bytes(10, ML, ML <= 5), s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+            } else if (a.Dz == 144)
+                hipLaunchKernelGGL((shortlist_kernel<ML, false, 9, 0, false, true>), dim3(grid), dim3(64 * kPfW),
+                                   shortlist_lds_bytes(9, ML), s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+            else
+                hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 0, false, true>), dim3(grid), dim3(64 * kPfW),
+                                   shortlist_lds_bytes(10, ML, ML <= 5), s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+        }
+    } else if (skip_build) {
         if constexpr (!UPD) {
             if (a.Dz == 144)
                 hipLaunchKernelGGL((shortlist_kernel<ML, false, 9, 0, true>), dim3(grid), dim3(64 * kPfW),
@@ -1844,6 +2177,19 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
             }
         }
     }
+}
+
+template <int ML>
+static void launch_sl_work(const ShortlistArgs &a, int *flags64, int grid, hipStream_t s)
+{
+    const int nq = a.pos_end - a.pos_begin;
+    const int nqt = (nq + kPfQ - 1) / kPfQ, nqt64 = (nq + kQTile - 1) / kQTile;
+    if (a.Dz == 144)
+        hipLaunchKernelGGL((shortlist_kernel<ML, false, 9, 0, false, false, true>), dim3(grid), dim3(64 * kPfW),
+                           shortlist_lds_bytes(9, ML), s, a, nqt, a.B, 1, flags64, nqt64, g_gate);
+    else
+        hipLaunchKernelGGL((shortlist_kernel<ML, false, 10, 0, false, false, true>), dim3(grid), dim3(64 * kPfW),
+                           shortlist_lds_bytes(10, ML, ML <= 5), s, a, nqt, a.B, 1, flags64, nqt64, g_gate);
 }
 
 }  // namespace
@@ -1914,6 +2260,14 @@ void launch_query_order(const unsigned long long *ckey, const int *bq, int pos_b
                            pos_begin, pos_end - pos_begin, B, qord, home, g_gate);
 }
 
+void launch_query_order_sweep(const unsigned long long *ckey, const int *perm, const void *geo, int nbatch, int B, int *qord_all,
+                              int *home_all, hipStream_t s)
+{
+    if (nbatch > 0)
+        hipLaunchKernelGGL(query_order_sweep_kernel, dim3(nbatch), dim3(1024), sizeof(int) * ((size_t)B + 1 + 1024), s, ckey, perm,
+                           reinterpret_cast<const int4 *>(geo), B, qord_all, home_all);
+}
+
 void launch_query_norms(const double *X, int D, int Dp, int N, int B, const double *centers, double S, void *qn,
                         unsigned long long *ckey, hipStream_t s)
 {
@@ -1967,6 +2321,61 @@ void launch_pack_state_commit(const PackState &ps, const MemberPack &P, const do
                        centers, mu_g, S, Zs, Dz, reinterpret_cast<float4 *>(ms), new_lab, ps.dest, inb, g_gate);
     hipLaunchKernelGGL(pack_state_fix_kernel, dim3(B), dim3(256), 0, s, ps, P, Zs, reinterpret_cast<const float4 *>(ms), D, Dz,
                        ids, new_lab, g_gate);
+}
+
+static int pool_home_blocks(int B, int *hb)
+{
+    int hy = std::max(1, std::min(2048 / std::max(B, 1), (B + 3) / 4));
+    *hb = (B + hy - 1) / hy;
+    return (B + *hb - 1) / *hb;
+}
+
+void launch_pool_build(const PoolState &ps, const unsigned short *Zs, const void *ms, const void *qn, int D, int Dz,
+                       const int *memb_id, const int *bin_ptr, int B, hipStream_t s)
+{
+    if (B <= 0) return;
+    int hb = 1;
+    const int hy = pool_home_blocks(B, &hb);
+    hipLaunchKernelGGL((pool_update_kernel<true>), dim3(B, hy), dim3(256), 0, s, ps, Zs, reinterpret_cast<const float4 *>(ms),
+                       reinterpret_cast<const float2 *>(qn), D, Dz, B, hb, memb_id, bin_ptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                       g_gate);
+}
+
+void launch_pool_open(const PoolState &ps, const int *inb, int D, int Dz, int B, int *zero_me, hipStream_t s)
+{
+    const long long nslot = (long long)B * B * kPoolRows;
+    if (nslot > 0)
+        hipLaunchKernelGGL(pool_open_kernel, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, s, ps, inb, D, Dz, nslot, zero_me,
+                           g_gate);
+}
+
+void launch_pool_commit(const PoolState &ps, const unsigned short *Zs, const void *ms, const void *qn, int D, int Dz,
+                        const int *ids, int n, const int *new_lab, const int *lab_old, const int *labels, int B, bool holes,
+                        hipStream_t s)
+{
+    if (B <= 0 || n <= 0) return;
+    int hb = 1;
+    const int hy = pool_home_blocks(B, &hb);
+    hipLaunchKernelGGL((pool_update_kernel<false>), dim3(B, hy), dim3(256), 0, s, ps, Zs, reinterpret_cast<const float4 *>(ms),
+                       reinterpret_cast<const float2 *>(qn), D, Dz, B, hb, nullptr, nullptr, ids, n, new_lab, lab_old, labels,
+                       holes ? 1 : 0, g_gate);
+}
+
+void launch_shortlist_worklist(const ShortlistArgs &a_, int *flags64, hipStream_t s)
+{
+    ShortlistArgs a = a_;
+    a.gamma = kGamma; a.tile_best_min = 16; a.tile_k2 = 3;
+    // (a.skip stays as it is: the plain build skips nothing, but the flag also says that the pack is in SHELL order, where the
+    //  per-tile-best shortcut of the threshold sweep must not be taken -- the m nearest crowd into a few tiles)
+    a.pool = PoolState{}; a.qord = nullptr; a.home = nullptr; a.skip_stat = nullptr; a.pool_stat = nullptr;
+    a.seg = SegPlan{};   // (a segmented bin's pairs were never on the pool launch's list)
+    const int nq = a.pos_end - a.pos_begin;
+    if (nq <= 0 || a.B <= 0 || a.update || a.worklist == nullptr) return;
+    const long long items = (long long)((nq + kQTile - 1) / kQTile) * a.B;
+    const int grid = (int)std::min<long long>(items, 2048);
+    if (a.m <= 5) launch_sl_work<5>(a, flags64, grid, s);
+    else if (a.m <= 8) launch_sl_work<8>(a, flags64, grid, s);
+    else launch_sl_work<16>(a, flags64, grid, s);
 }
 
 void launch_shortlist(const ShortlistArgs &a_, int *flags64, hipStream_t s)

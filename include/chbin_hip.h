@@ -29,6 +29,8 @@
  *       CHB_FUSED_STRIPE=0  position-major work order in the fused kernels (default: striped over the XCDs by bin)
  *       CHB_PACK_INCR=0     CSR and member pack of the shortlist stage rebuilt from the labels at every batch start (default:
  *                           kept across the batches of a fit and updated by each commit, where tiles are not skipped)
+ *       CHB_POOL_TAU=0      the base shortlist launch always streams a bin twice (threshold sweep + admission sweep); default:
+ *                           the threshold comes from a per-(bin, home bin) pool tile where one exists, and the bin is streamed once
  *       CHB_TILE_SKIP=0     the shortlist stage never skips member tiles (default: on for fits whose first batches
  *                           show that tiles can be skipped -- data with several coverage columns)
  */
@@ -204,6 +206,8 @@ int chb_profile_reset(chb_ctx *h);
 /* kernel: "prefilter" | "prefilter_update" | "rescore" | "rescore_update" | "query_norms" (once per fit) |
  * "fit_start" (bin centres + every labelled sample's shadow row, once per fit) |
  * "topm_fallback" | "topm_base" | "topm_update" | "hull_qp" | "slow_path" | "argmin" | "bucket" |
+ * "pool" (upkeep of the shortlist stage's threshold pools: build once per fit, open + commit per batch) |
+ * "prefilter_retry" (the exact two-sweep selection for the work items a pool batch's launch left on its overflow list) |
  * "pairwise" | "kmer_count".  For m <= 16 "hull_qp" is the fused selection + hull-distance kernel and
  * "slow_path" the exact path for what it leaves over; "rescore*" then only appear for m > 16 or CHB_FUSED=0. */
 int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *launches,
@@ -224,7 +228,9 @@ int chb_fit_stats(chb_ctx *h, int64_t *out4);
  * CHB_ESTATE at the end of that sweep -- the product build checks the shortlist stage's contract in every fused hull
  * launch), "lookahead_batches" (batches of the last fit whose successor was enqueued ahead of their convergence verdict
  * and kept: on one GPU and, since round 4, under the RCCL exchange), "lookahead_failed" (... and discarded because the
- * batch needed further rounds), "exchanges" (framed all-gathers of the last fit under an exchange: one per batch for the
+ * batch needed further rounds), "pool_batches" (batches of the last fit whose base shortlist launch took its thresholds
+ * from the pools), "pool_state" (0 undecided = on, 1 kept on, -1 turned off because the shortlists came out long),
+ * "pool_candidates" / "pool_pairs" (sampled shortlist lengths behind that decision), "exchanges" (framed all-gathers of the last fit under an exchange: one per batch for the
  * label guess, one per round) */
 int chb_counter(chb_ctx *h, const char *name, int64_t *out);
 

@@ -973,6 +973,7 @@ def test_segmented_giant_bin(O, m):
         assert a.counter("pack_incremental_batches") == a.fit_stats()["batches"]
         seg_batches = a.counter("segment_batches")
         overflow = a.counter("prefilter_overflow")
+        pool_state, pool_batches = a.counter("pool_state"), a.counter("pool_batches")
         assert a.counter("shortlist_short") == 0   # the product build's check of the shortlist stage's contract
         rng = np.random.default_rng(2)
         q = rng.choice(np.flatnonzero(initial < 0), 300, replace=False)
@@ -981,6 +982,7 @@ def test_segmented_giant_bin(O, m):
     finally:
         a.close()
     assert seg_batches > 0, "the giant bin was never segmented"
+    assert pool_state == -1 and 0 < pool_batches < 8, (pool_state, pool_batches)   # (pools tried, found wanting, dropped)
     assert (got == true).mean() > 0.95
     b = _ctx_env({"CHB_SEGMENTS": "0"})
     try:
@@ -990,7 +992,11 @@ def test_segmented_giant_bin(O, m):
     finally:
         b.close()
     assert its == its_w and np.array_equal(changed, changed_w) and np.array_equal(got, want)
-    assert overflow <= (1e-3 if m <= 5 else 2e-2) * its * perms.shape[1] * B   # (m = 15 overflows ~0.4 % of its pairs on any data)
+    # (m = 15 overflows ~0.4 % of its pairs on any data.  Round 5: the giant bin is 18 clusters under one label, so most
+    #  contigs' nearest bin centre says nothing about where they lie and the threshold pools give them loose thresholds;
+    #  the fit notices -- candidates per pair of a batch above 2 m + 2 -- and goes back to the two-sweep launch, one batch
+    #  late under the look-ahead: the long shortlists of those two or three early batches are what the bound allows for)
+    assert overflow <= (1e-3 if m <= 5 else 4e-2) * its * perms.shape[1] * B
     c = _brute_ctx()
     try:
         c.set_samples(X)
