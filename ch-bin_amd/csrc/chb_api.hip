@@ -258,6 +258,7 @@ struct chb_ctx {
     // the persistent base pack (prefilter_kernels.hip): the member pack kept across the batches of a fit
     DevBuf<int> pp_start, pp_cap, pp_fill, pp_live, pp_nt, pp_memb, pp_row, pp_ctl, pp_ovf, pp_dest;
     int pp_arena_rows = 0;
+    int64_t pp_mark = 0;       // rows handed out from which on the host asks for a rebuild (pack_state_build)
     bool pp_allowed = true;    // CHB_PACK_INCR=0: every batch start rebuilds CSR and pack (the form up to round 3; A/B tests)
     bool pp_fit = false;       // inside chb_fit_cluster (the stepwise entry points and chb_topm_per_bin always rebuild)
     bool pp_valid = false;     // the pack on the device matches the labels
@@ -533,9 +534,17 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m, bool sy
             launch_sample_shadow(h->X.p, h->D, h->Dp, nullptr, (int)h->N, h->labels.p, h->B, h->centers.p,
                                  h->mu_g.p, h->shadow_scale, h->Zs.p, h->Dz, h->ms.p, nullptr, nullptr, h->stream);
         }
-        // every sample's exact norm against every (fixed) centre, and its nearest centre: once per fit, not per batch
-        HIPCHK(h->qn.ensure((size_t)h->N * (size_t)B * 2));
-        HIPCHK(h->ckey.ensure((size_t)h->N));
+        // every sample's exact norm against every (fixed) centre, and its nearest centre: once per fit, not per batch.
+        // N x B x 8 bytes (51 MB at 100k x 64, 1.6 GB at 1M x 200, 65 GB at 1M x 8192): a table that does not fit the
+        // device sends the fit to the brute-force selection (as a feature width beyond the shortlist stage's does) instead
+        // of failing it
+        if (h->qn.ensure((size_t)h->N * (size_t)B * 2) != hipSuccess || h->ckey.ensure((size_t)h->N) != hipSuccess) {
+            (void)hipGetLastError();
+            h->qn.release(); h->ckey.release();
+            h->pf_fit = false; h->fused = false;
+        }
+    }
+    if (h->pf_fit) {
         {
             Timed t(h, "query_norms", (double)h->N * (double)B);
             launch_query_norms(h->X.p, h->D, h->Dp, (int)h->N, h->B, h->centers.p, h->shadow_scale, h->qn.p, h->ckey.p, h->stream);
@@ -566,9 +575,25 @@ int pack_state_build(chb_ctx *h)
     const size_t B = h->B;
     // (layout: at most 2 N + 1.5 N + 128 B rows; 2 * row + 1 must fit an int)
     const int arena = (int)std::min<int64_t>(12 * h->N + 1024 * (int64_t)B, 0x3fffff00);
+    // The host asks for a rebuild (compaction) once `mark` rows are handed out; the request is honoured up to three commits
+    // later (it rides home with a verdict, lags a batch under the look-ahead and waits for a batch start outside a window).
+    // What three commits can take: ONE mass move -- every bin's region tripling at once, 3 (N + K) + 96 B rows, after which
+    // the regions hold three times their members and cannot move again at once -- plus the appends of the other two (K rows
+    // each): 3 N + 5 K + 128 B.  The mark leaves that much room; it always lies above a fresh layout (3.5 N + 128 B) since a
+    // batch never holds more than N samples.
+    {
+        const int64_t K = std::max(h->Kcap, 1);
+        h->pp_mark = std::min<int64_t>(5 * h->N + 512 * (int64_t)B, (int64_t)arena - (3 * h->N + 5 * K + 128 * (int64_t)B));
+        if (h->pp_mark < 7 * h->N / 2 + 128 * (int64_t)B) { h->pp_valid = false; h->pp_fit = false; return CHB_OK; }   // (capped arena)
+    }
     if (h->pp_arena_rows < arena || !h->pp_memb.p) {
-        HIPCHK(h->pk.ensure((size_t)arena, B, (size_t)h->Dz));
-        HIPCHK(h->pp_memb.ensure((size_t)arena + 64));
+        if (h->pk.ensure((size_t)arena, B, (size_t)h->Dz) != hipSuccess || h->pp_memb.ensure((size_t)arena + 64) != hipSuccess) {
+            (void)hipGetLastError();   // (no room for the arena: this fit rebuilds its pack per batch)
+            h->pp_memb.release();
+            HIPCHK(h->pk.ensure((size_t)h->N + 32 * B, B, (size_t)h->Dz));
+            h->pp_arena_rows = 0; h->pp_valid = false; h->pp_fit = false;
+            return CHB_OK;
+        }
         h->pp_arena_rows = arena;
     }
     HIPCHK(h->pp_row.ensure((size_t)h->N));
@@ -603,10 +628,13 @@ int pool_build(chb_ctx *h)
     if (!h->pool_allowed || !h->fused || !h->pf_fit || !h->pf_base || h->ckey.p == nullptr || B < 2 ||
         slots * (size_t)h->Dz * sizeof(unsigned short) > kPoolMaxBytes)
         return CHB_OK;
-    HIPCHK(h->pool_Z.ensure(slots * (size_t)h->Dz));
-    HIPCHK(h->pool_id.ensure(slots)); HIPCHK(h->pool_hole.ensure(slots));
-    HIPCHK(h->pool_key.ensure(slots)); HIPCHK(h->pool_sn.ensure(slots));
-    HIPCHK(h->pool_tsn.ensure(B * B + 64)); HIPCHK(h->pool_ok.ensure(B * B));
+    if (h->pool_Z.ensure(slots * (size_t)h->Dz) != hipSuccess || h->pool_id.ensure(slots) != hipSuccess ||
+        h->pool_hole.ensure(slots) != hipSuccess || h->pool_key.ensure(slots) != hipSuccess || h->pool_sn.ensure(slots) != hipSuccess ||
+        h->pool_tsn.ensure(B * B + 64) != hipSuccess || h->pool_ok.ensure(B * B) != hipSuccess) {
+        (void)hipGetLastError();   // (no room: the fit keeps the two-sweep launch)
+        h->pool_Z.release(); h->pool_id.release(); h->pool_hole.release(); h->pool_key.release(); h->pool_sn.release();
+        return CHB_OK;
+    }
     {
         Timed t(h, "pool", (double)h->N);
         launch_pool_build(h->pool_view(), h->Zs.p, h->ms.p, h->qn.p, h->D, h->Dz, h->memb_id.p, h->bin_ptr.p, h->B, h->stream);
@@ -1706,7 +1734,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             h->hint_max_tiles = h->fc_host[kSlotInts * slot + 1]; h->hint_total_tiles = h->fc_host[kSlotInts * slot + 2];
             // (the persistent pack's arena: rows handed out so far, as of that batch's start)
             {
-                int64_t mark_at = 5 * h->N + 512 * (int64_t)h->B;
+                int64_t mark_at = h->pp_mark;
 #ifdef CHB_DEV_KNOBS   // CHB_PACK_REBUILD_AT=<rows>: rebuild (compact) the pack from that fill mark on -- tests of the rebuild path
                 { static const char *e = getenv("CHB_PACK_REBUILD_AT"); if (e) mark_at = atoll(e); }
 #endif
@@ -1809,7 +1837,7 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
             const int64_t t1 = t0 + K;
             // (a batch start that has to build or rebuild the persistent pack stays outside the look-ahead window)
             const bool skip_would = h->allow_skip && h->nsh > 1 && h->skip_state >= 0 && h->ckey.p != nullptr;
-            const bool pack_sync = h->pp_allowed && h->fused && h->pf_base && h->cand.p && !skip_would &&
+            const bool pack_sync = h->pp_fit && h->pp_allowed && h->fused && h->pf_base && h->cand.p && !skip_would &&
                                    (!h->pp_valid || h->pp_rebuild);
             const bool spec = spec_ok && t1 < n_move && !pack_sync;
             Snap snap{};

@@ -711,6 +711,7 @@ __global__ __launch_bounds__(256) void pack_state_layout_kernel(PackState ps, co
         for (int t = 0; t < 256; ++t) { const int v = part[t]; part[t] = run; run += v; }
         part[256] = run;
         ps.ctl[0] = run; ps.ctl[1] = 0;
+        if (run > ps.arena_rows) ps.ctl[2] = 1;   // (cannot happen by the host's sizes; fails the fit rather than writing past the arena)
     }
     __syncthreads();
     int run = part[threadIdx.x];
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(256) void pack_state_build_kernel(PackState ps, Mem
         for (int t = t0 + (int)threadIdx.x; t < t1; t += 256) P.tsn[t] = 0.f;
         return;
     }
-    const int total = ps.ctl[0];
+    const int total = min(ps.ctl[0], ps.arena_rows);   // (a layout past the arena has raised ctl[2]: the fit fails, nothing is written beyond)
     const int cpr = Dz >> 3, l16 = threadIdx.x & 15;
     for (int r = b * 16 + (int)(threadIdx.x >> 4); r < total; r += ngather * 16) {
         const int c = bin_of_row(ps.start, B, r);   // (start ascending; the last region ends at `total`)

@@ -1177,6 +1177,59 @@ def test_persistent_pack_equals_rebuild(O, N, D, B, m, iters, sigma, mix, n_seed
         assert ch_o[1] > 0    # the case really moves contigs after the first sweep
 
 
+@pytest.mark.parametrize("N,D,B,m,iters,sigma,mix,n_seed,batch,expect", [
+    (24000, 136, 24, 5, 3, 1.5e-3, 0.0, None, 2048, "kept"),       # the benchmark generator: pools serve every batch
+    (24000, 136, 24, 5, 4, 4.5e-3, 0.3, None, 2048, "any"),        # overlapping bins: labels change in later sweeps (holes, departures)
+    (20000, 146, 20, 5, 3, 2e-3, 0.2, None, 4096, "any"),          # ten coverage columns: the tile-skipping pool build
+    (5000, 136, 8, 8, 3, 2e-3, 0.2, None, 512, "any"),             # m = 8 builds
+    (4000, 140, 8, 15, 3, 2e-3, 0.2, None, 512, "any"),            # m = 15 builds (16-entry lists), five coverage columns
+    (6000, 136, 8, 5, 4, 6e-3, 0.6, 12, 512, "any"),               # heavy overlap: long shortlists, the fit drops the pools
+])
+def test_threshold_pools_equal_two_sweeps(O, N, D, B, m, iters, sigma, mix, n_seed, batch, expect):
+    """Round 5: the base shortlist launch takes tau(j, c) from a POOL -- the 32 members of c nearest to the centre of j's home
+    bin, one tile per (bin, home bin), kept up by every commit -- and streams the bin once, instead of learning tau in a
+    sweep of its own (prefilter_kernels.hip, "threshold pools").  Any m base members bound the m-th nearest distance from
+    above, so the selection of distance_matrix.py:47-62 is unchanged: whole fits with the pools must equal a context
+    without them (CHB_POOL_TAU=0) and the oracle -- labels, sweep counts, change counts, winning distances -- over several
+    sweeps (holes for the open batch's members, departures, arrivals), with and without the look-ahead."""
+    X, initial, _ = _synth(N, D, B, S=1 if D <= 136 else (5 if D == 140 else 10), seed=N + B, sigma=sigma, mix=mix, n_seed=n_seed)
+    perms = _perms(initial, iters)
+    want, its_o, ch_o = O.fit_cluster(X, B, initial, perms, m, iters) if N <= 12000 else (None, None, None)
+    from chbin_amd import _lib
+    a = _lib.Context(0)
+    try:
+        a.set_samples(X)
+        got, its, ch, mind = a.fit_cluster(B, initial, perms, m, iters, batch=batch, want_min_dist=True)
+        pool_batches, pool_state = a.counter("pool_batches"), a.counter("pool_state")
+        assert a.counter("shortlist_short") == 0
+        got_t, its_t, ch_t = a.fit_cluster(B, initial, perms, m, iters, batch=batch)     # the look-ahead path
+    finally:
+        a.close()
+    assert pool_batches > 0                                            # the pools really served batches
+    if expect == "kept":
+        assert pool_state == 1 and pool_batches >= 0.8 * its * (len(perms[0]) / batch)
+    b = _ctx_env({"CHB_POOL_TAU": "0"})
+    try:
+        b.set_samples(X)
+        ref, its_r, ch_r, mind_r = b.fit_cluster(B, initial, perms, m, iters, batch=batch, want_min_dist=True)
+        assert b.counter("pool_batches") == 0
+    finally:
+        b.close()
+    assert its == its_r and np.array_equal(ch, ch_r) and np.array_equal(got, ref)
+    assert its_t == its_r and np.array_equal(ch_t, ch_r) and np.array_equal(got_t, ref)
+    mv = initial < 0
+    assert np.allclose(mind[mv], mind_r[mv], rtol=0, atol=QP_TOL)
+    if want is not None:
+        assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
+    else:
+        # the oracle on the converged labels / on a sample of the last sweep's visits (frozen evaluation)
+        rng = np.random.default_rng(3)
+        if ch[its - 1] == 0:
+            sample = rng.choice(np.flatnonzero(initial < 0), 128, replace=False)
+            bb, _ = O.eval_frozen_mt(X, B, got, sample, m, 8)
+            assert np.array_equal(bb, got[sample])
+
+
 def test_persistent_pack_rebuilds_under_pressure(tmp_path):
     """The persistent base pack is rebuilt from the labels (holes squeezed out, regions re-sized) when much of its row arena
     has been handed out -- a path ordinary data never reaches (the arena holds 12 N + 1024 B rows).  The developer library
