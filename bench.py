@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_PEAK_GBS = 6290.0     # the measured-copy peak BASELINE.md 3 also quotes the path figure against
 F16_PEAK_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak
-TRAFFIC_FILE = "r04_traffic.json"   # rocprofv3 --pmc passes of this round (tools/traffic_from_pmc.py); m > 5: r04_m15_traffic.json
+TRAFFIC_FILE = "r05_traffic.json"   # rocprofv3 --pmc passes of this round (tools/traffic_from_pmc.py); m > 5: r05_m15_traffic.json;
+                                    # BASELINE configs[3] / [4]: r05_cfg3_traffic.json / r05_cfg4_traffic.json
 # MI355X_MICROARCH.md: indexed rows out of an L2-resident table gather at 16.8-18.8 TB/s chip-wide (mid-point); L2 aggregate 34.5
 L2_GATHER_PEAK_GBS = 17800.0
 L2_AGGREGATE_GBS = 34500.0
@@ -416,24 +417,31 @@ def main():
         traffic_note = None
         try:
             default_tf = TRAFFIC_FILE if m <= 5 else TRAFFIC_FILE.replace("_traffic", "_m15_traffic")
+            cfg_idx = next((i for i, shp in BASELINE_CONFIGS.items() if shp == (N, D, B)), None)
+            if cfg_idx in (3, 4) and m <= 5:
+                default_tf = TRAFFIC_FILE.replace("_traffic", f"_cfg{cfg_idx}_traffic")
             tj = json.load(open(args.traffic_file or os.path.join(ROOT, "profiles", default_tf)))
             tf_label = (f"{args.traffic_file} (this run's own rocprofv3 --pmc passes; committed as profiles/{default_tf})"
                         if args.traffic_file else f"profiles/{default_tf}")
             tr = tj["kernels"]
             # (kernel names as rocprofv3 prints them: the shortlist kernel's template list has grown over the rounds)
             ml = 5 if m <= 5 else (8 if m <= 8 else 16)
-            tmap = {"prefilter": [f"shortlist_kernel<{ml}, false, 9, 0, false, true>", f"shortlist_kernel<{ml}, false, 9, 0, false, false>",
-                                  f"shortlist_kernel<{ml}, false, 9, 0, false>", f"shortlist_kernel<{ml}, false, 9, 0>",
-                                  f"shortlist_kernel<{ml}, false, 9>"],
+            # (the base shortlist launch of this configuration: the instantiation with the most launches in the table among
+            #  the ordinary base builds -- tile skipping and threshold pools are chosen per fit)
+            base_sl = sorted((k for k in tr if k.startswith(f"shortlist_kernel<{ml}, false, ") and ", 0, " in k and not k.endswith("true>")),
+                             key=lambda k: -tr[k].get("launches", 0))
+            tmap = {"prefilter": base_sl + [f"shortlist_kernel<{ml}, false, 9, 0, false>", f"shortlist_kernel<{ml}, false, 9, 0>",
+                                            f"shortlist_kernel<{ml}, false, 9>"],
                     "hull_qp": ["hull_select_qp_kernel<5, 7, 4, true>"] if m <= 5 else ["hull_select_qp16_kernel<4>"],
-                    "prefilter_update": [f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false, false>",
+                    "prefilter_update": [f"shortlist_kernel<{1 if m <= 8 else 2}, true, {9 if D <= 141 else 10}, 0, false, false, false>",
+                                         f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false, false>",
                                          f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false>",
                                          "shortlist_kernel<1, true, 9, 0>", "shortlist_kernel<1, true, 9>"]}
             stamp = kernel_source_stamp()
             if tj.get("kernel_source_stamp") != stamp:
                 traffic_note = (f"{tf_label} was measured on kernel sources {tj.get('kernel_source_stamp')}, "
                                 f"this build is {stamp}: not quoted")
-            elif (N, D, B) == (100_000, 136, 64) and m in (5, 15) and (args.batch or 8192) == 8192 and not use_dist and fused:
+            elif (((N, D, B) == (100_000, 136, 64) and m in (5, 15)) or (cfg_idx in (3, 4) and m == 5)) and not args.batch and not use_dist and fused:
                 for name, names in tmap.items():
                     src = next((k for k in names if k in tr), None)
                     if src is not None:

@@ -4,7 +4,7 @@
 #   kernel stats (rocprofv3 --kernel-trace --stats) + the bench line of the same run, HBM-side counters (separate --pmc
 #   passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes), the default bench line, and the other configs.
 set -o pipefail
-tag=${1:-r03prof}; quick=$2
+tag=${1:-r05prof}; quick=$2
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -34,5 +34,19 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_m15 -o t -- $B 
 echo "[6] configs[1]"; $B --contigs 10000 --bins 32 --steps 5 --warmup 2 --cpu-sample 200 --no-extra > $O/cfg1_bench.json 2> $O/err_cfg1.txt || exit 1
 echo "[7] configs[3]"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg3 -o t -- $B --contigs 500000 --dim 140 --bins 128 --steps 2 --warmup 1 --cpu-sample 0 --no-extra > $O/cfg3_bench_under_rocprof.json 2> $O/err_cfg3.txt || exit 1
 echo "[8] configs[4]"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -o t -- $B --contigs 1000000 --dim 146 --bins 200 --steps 2 --warmup 1 --cpu-sample 0 --no-extra > $O/cfg4_bench_under_rocprof.json 2> $O/err_cfg4.txt || exit 1
+# counters of the kernels that dominate the multi-GPU configurations (their own tables: bench.py quotes
+# r05_cfg3_traffic.json / r05_cfg4_traffic.json for --contigs 500000 ... / 1000000 ...)
+for c in cfg3:"--contigs 500000 --dim 140 --bins 128" cfg4:"--contigs 1000000 --dim 146 --bins 200"; do
+  name=${c%%:*}; cargs=${c#*:}
+  echo "[9] pmc $name"
+  for p in tcp:"TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" tcc:"TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" sq:"SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES" fetch:FETCH_SIZE write:WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc ${p#*:} --output-format csv -d $O/$name/pmc_${p%%:*} -o t -- $B $cargs $PB > $O/${name}_bench_pmc_${p%%:*}.json 2> $O/${name}_err_pmc_${p%%:*}.txt || exit 1
+    find $O/$name -name "*kernel_trace.csv" -delete
+  done
+  python3 $R/tools/traffic_from_pmc.py $O/$name $O/this_$name > $O/traffic_${name}_log.txt 2>&1 || exit 1
+  $B $cargs --steps 2 --warmup 1 --cpu-sample 0 --no-extra --traffic-file $O/this_${name}_traffic.json > $O/${name}_bench.json 2> $O/err_${name}_bench.txt || exit 1
+done
+# VERDICT r4 item 8, "first, the numbers": a feature width beyond the shortlist stage's 157 columns (k = 5: 512 k-mer columns)
+echo "[10] wide features"; $B --dim 528 --steps 2 --warmup 1 --cpu-sample 0 --no-extra --no-e2e > $O/wide528_bench.json 2> $O/err_wide528.txt || exit 1
 find $O -name "*kernel_trace.csv" -size +8M -delete
 echo done

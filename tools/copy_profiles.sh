@@ -11,3 +11,9 @@ cp $P/stats_m15/t_kernel_stats.csv ${R}_m15_kernel_stats_bench_steps2.csv
 cp $P/cfg1_bench.json ${R}_cfg1_bench.json
 cp $P/cfg3_bench_under_rocprof.json ${R}_cfg3_bench_under_rocprof.json; cp $P/stats_cfg3/t_kernel_stats.csv ${R}_cfg3_kernel_stats_bench_steps2.csv
 cp $P/cfg4_bench_under_rocprof.json ${R}_cfg4_bench_under_rocprof.json; cp $P/stats_cfg4/t_kernel_stats.csv ${R}_cfg4_kernel_stats_bench_steps2.csv
+# round 5: the counter tables of BASELINE configs[3] / [4], their bench lines with roofline.limiter, the wide-feature run
+for c in cfg3 cfg4; do
+  [ -f $P/this_${c}_traffic.json ] && cp $P/this_${c}_traffic.json ${R}_${c}_traffic.json && cp $P/this_${c}_pmc_hbm_counters.csv ${R}_${c}_pmc_hbm_counters.csv
+  [ -f $P/${c}_bench.json ] && cp $P/${c}_bench.json ${R}_${c}_bench.json
+done
+[ -f $P/wide528_bench.json ] && cp $P/wide528_bench.json ${R}_wide528_bench.json
