@@ -625,7 +625,10 @@ int pool_build(chb_ctx *h)
 {
     h->pool_valid = false;
     const size_t B = h->B, slots = B * B * (size_t)kPoolRows;
-    if (!h->pool_allowed || !h->fused || !h->pf_fit || !h->pf_base || h->ckey.p == nullptr || B < 2 ||
+    // (m > 8: the 16-lane hull kernel pays for every candidate beyond 16 with extra rows and second tiles -- with the pools'
+    //  17.4 instead of 16.8 candidates per pair at m = 15 it ran 34.4 instead of 28.8 ms per sweep, more than the shortlist
+    //  kernel saved (5.1 instead of 5.9): those fits keep the two sweeps)
+    if (!h->pool_allowed || !h->fused || !h->pf_fit || !h->pf_base || h->ckey.p == nullptr || B < 2 || h->m > 8 ||
         slots * (size_t)h->Dz * sizeof(unsigned short) > kPoolMaxBytes)
         return CHB_OK;
     if (h->pool_Z.ensure(slots * (size_t)h->Dz) != hipSuccess || h->pool_id.ensure(slots) != hipSuccess ||
@@ -1768,7 +1771,9 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
                 const long long pc = h->fc_host[kSlotInts * slot + 7], pp = h->fc_host[kSlotInts * slot + 8];
                 h->pool_cand += pc; h->pool_pairs += pp;
                 if (++h->pool_batches >= 3 && h->pool_state == 0) h->pool_state = 1;
-                if (pc > (long long)(2 * h->m + 2) * pp) { h->pool_state = -1; h->pool_off_key = skip_key(h); }
+                // (the benchmark configurations admit m + 0.1 .. m + 0.4 per pair; from m + 3 on the loose thresholds cost the
+                //  update stage and the hull kernel more than the threshold sweep did)
+                if (pc > (long long)(h->m + 3) * pp) { h->pool_state = -1; h->pool_off_key = skip_key(h); }
             }
             (void)active; (void)g;
             return CHB_OK;
