@@ -151,6 +151,47 @@ def test_hull_distance_points_vs_oracle_and_enumerator(ctx, O, mmax, D):
         assert abs(np.linalg.norm(alpha @ P - x) - d) <= QP_TOL + 1e-7 * scale * (d < 1e-6 * scale)
 
 
+@pytest.mark.parametrize("D", [3, 7, 40, 136])
+def test_hull_distance_16_lane_solver_both_starts(ctx, O, D):
+    """The 16-lane solver (5 < m <= 16) starts Wolfe's method from the FULL vertex set when most vertices improve on the
+    nearest one (round 5; a query inside its neighbours' cloud) and from the nearest vertex alone otherwise (a query far
+    from a tight bin).  Both regimes, affinely dependent sets (m > D + 1: the full-set start has to leave vertices out),
+    duplicates and queries inside the hull, m = 6 .. 16, against the oracle's Goldfarb-Idnani and the enumerator."""
+    rng = np.random.default_rng(500 + D)
+    worst = 0.0
+    for t in range(132):
+        m = 6 + t % 11
+        kind = (t // 11) % 6
+        P = rng.standard_normal((m, D))
+        if kind == 0:
+            x = 0.3 * rng.standard_normal(D)                      # in the cloud: every vertex improves (full-set start)
+        elif kind == 1:
+            x = 40.0 * np.ones(D) + rng.standard_normal(D)        # far away: support of a few vertices (grown corral)
+        elif kind == 2:
+            x = rng.dirichlet(np.ones(m)) @ P                     # inside the hull
+        elif kind == 3:
+            P[m - 1] = P[0]; P[m - 2] = P[1]                      # duplicates in a cloud
+            x = 0.3 * rng.standard_normal(D)
+        elif kind == 4:
+            P[3:] = rng.dirichlet(np.ones(3), size=m - 3) @ P[:3] + 1e-3 * rng.standard_normal((m - 3, D))
+            x = P.mean(0) + 0.5 * rng.standard_normal(D)          # nearly coplanar vertices
+        else:
+            P *= 1e-6; x = 1e-6 * 0.3 * rng.standard_normal(D) + 5.0   # tiny cloud on a large offset
+            P += 5.0
+        d, alpha = ctx.hull_distance_points(x, P, want_alpha=True)
+        scale = max(np.linalg.norm(P - x, axis=1).max(), 1e-300)
+        d_or = O.convex_hull_distance(x, P)
+        tol = QP_TOL * max(scale, 1.0) + 1e-7 * scale * (d_or < 1e-6 * scale)
+        assert abs(d - d_or) <= tol, (D, m, kind, d, d_or)
+        if m <= 12:
+            d_en = O.enum_hull_distance(x, P)
+            assert abs(d - d_en) <= QP_TOL * max(scale, 1.0) + 1e-7 * scale * (d_en < 1e-6 * scale), (D, m, kind, d, d_en)
+        assert np.all(alpha >= 0) and abs(alpha.sum() - 1) < 1e-12
+        assert abs(np.linalg.norm(alpha @ P - x) - d) <= tol
+        worst = max(worst, abs(d - d_or) / max(scale, 1e-300))
+    assert worst < 1e-9, worst
+
+
 def test_hull_distance_golden_qp_problems(ctx, O, golden_dir):
     from chbin_amd import clustering
     g = np.load(os.path.join(golden_dir, "qp_args.npz"))
