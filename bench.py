@@ -341,7 +341,8 @@ def main():
 
     out = None
     if rank == 0:
-        Dz = 144 if D <= 144 else 160
+        # shadow row width of the shortlist stage: 144 / 160 columns, or two to four 144-column slices (wide rows, D <= 573)
+        Dz = 144 if D + 3 <= 144 else (160 if D + 3 <= 160 else 144 * ((D + 3 + 143) // 144))
         fused = ctx.counter("fused_enabled") == 1
         bytes_qp = 8.0 * (m * D + D / B + 1)      # no-reuse gather model per hull distance
         x_mb = N * ((D + 15) // 16 * 16) * 8 / 1e6      # (rows of the resident matrix are padded to whole 128-byte lines)

@@ -494,7 +494,8 @@ int fit_begin_impl(chb_ctx *h, int64_t B, const int64_t *initial, int m, bool sy
     h->pf_fit = h->use_prefilter && h->shadow_ok && m <= kMaxM;
     // (a fit that found nothing to skip settles it for later fits over the same samples with the same bin count,
     //  neighbour count and metric -- the verdict depends on all three)
-    h->skip_state = (h->skip_off_key == skip_key(h)) ? -1 : 0;
+    // (wide rows, Dz > 160: the plain two-sweep builds only -- no tile skipping, pools or segments)
+    h->skip_state = (h->skip_off_key == skip_key(h) || h->Dz > 160) ? -1 : 0;
     h->skip_batches = 0; h->skip_skipped = 0; h->skip_seen = 0; h->skip_unloaded = 0;
     h->fused = h->allow_fused && h->pf_fit && h->pf_base && h->pf_update && fused_supported(m, h->Dp);
     HIPCHK(h->pin_a.ensure((size_t)h->N));
@@ -628,7 +629,7 @@ int pool_build(chb_ctx *h)
     // (m > 8: the 16-lane hull kernel pays for every candidate beyond 16 with extra rows and second tiles -- with the pools'
     //  17.4 instead of 16.8 candidates per pair at m = 15 it ran 34.4 instead of 28.8 ms per sweep, more than the shortlist
     //  kernel saved (5.1 instead of 5.9): those fits keep the two sweeps)
-    if (!h->pool_allowed || !h->fused || !h->pf_fit || !h->pf_base || h->ckey.p == nullptr || B < 2 || h->m > 8 ||
+    if (!h->pool_allowed || !h->fused || !h->pf_fit || !h->pf_base || h->ckey.p == nullptr || B < 2 || h->m > 8 || h->Dz > 160 ||
         slots * (size_t)h->Dz * sizeof(unsigned short) > kPoolMaxBytes)
         return CHB_OK;
     if (h->pool_Z.ensure(slots * (size_t)h->Dz) != hipSuccess || h->pool_id.ensure(slots) != hipSuccess ||
@@ -667,7 +668,7 @@ int batch_begin_dev(chb_ctx *h, int K, int q_lo, int q_hi, bool need_lists)
         sp.nseg = h->seg_nseg.p; sp.items = h->seg_items.p; sp.gflag = h->seg_gflag.p; sp.lists = h->seg_lists.p;
         sp.cap = 16 * h->seg_gcap; sp.gcap = h->seg_gcap;
         const long long est = (long long)h->hint_max_tiles * 3 / 2 + 8;
-        sp.launch = h->allow_segments && est > kSegMinTiles && est * h->B > 3LL * std::max(1, h->hint_total_tiles);
+        sp.launch = h->allow_segments && h->Dz <= 160 && est > kSegMinTiles && est * h->B > 3LL * std::max(1, h->hint_total_tiles);
         if (sp.launch) {
             HIPCHK(h->seg_lists.ensure((size_t)h->seg_gcap * 16 * (size_t)h->Kcap * (size_t)shortlist_list_len(h->m)));
             sp.lists = h->seg_lists.p;
@@ -1264,7 +1265,8 @@ static int samples_finish(chb_ctx *h)
     h->skip_off_key = -1; h->pool_off_key = -1;
     const int64_t N = h->N, D = h->D;
     const int Dp = h->Dp;
-    // the shortlist stage (prefilter_kernels.hip) keeps its query fragments in registers: D <= 160
+    // the shortlist stage (prefilter_kernels.hip) keeps its query fragments in registers: D <= 157 in the narrow builds,
+    // D <= 573 as two to four 144-column slices in the wide ones (shadow_row_elems)
     h->shadow_ok = false;
     const int Dz = shadow_row_elems((int)D);
     if (h->use_prefilter && Dz > 0) {
@@ -1291,6 +1293,7 @@ static int samples_finish(chb_ctx *h)
             (void)std::frexp((double)R, &e);   // R < 2^e
             S = std::ldexp(1.0, 10 - e);       // |x - mu_c| S <= 2 R S < 2^11: every member's -bias / 2 then fits the three
                                                // fp16 bias columns of its shadow row (prefilter_kernels.hip, kBiasExp)
+            if (Dz > 160) S *= 0.5;            // wide rows (D <= 573): |x - mu_c| S < 2^10, -bias / 2 <= D 2^21 / 2 < 2^29.2
         }
         h->shadow_scale = S;
         launch_global_shadow(h->X.p, (int)N, (int)D, Dp, h->mu_g.p, S, h->Gs.p, Dz, h->gq.p, h->stream);

@@ -80,6 +80,7 @@ constexpr float kSlack = 1e-6f;
 constexpr int kPfW = CHB_SL_WAVES;
 constexpr int kPfQ = 32 * kPfW;  // batch positions per workgroup (32 per wavefront)
 constexpr int kPfP = 32;   // members per tile
+constexpr int kWideMaxSlices = 4;   // wide rows: at most this many 144-column slices (shortlist_wide_kernel)
 
 __device__ __forceinline__ float round_up_f32(double v)
 {
@@ -2089,6 +2090,332 @@ __global__ __launch_bounds__(64 * kPfW, (ML <= 5 && (KS == 9 || (!UPD && SEG != 
 #undef CHB_SL_ISSUE_SEEK
 }
 
+// ---------------------------------------------------------------------------------------------
+// WIDE rows (round 5): 157 < D <= 573 -- e.g. the 512 canonical 5-mers of KmerK = 5 plus coverage columns
+// (ch_bin/core/features/kmer_count.py:110-125, config/default.ini:10 takes any k).  Up to round 4 such a fit fell back to
+// brute-force fp64 selection (tile_kernel: 3 D flops per (query, member) pair).  Here a shadow row is NS = 2 .. 4 SLICES of 144
+// columns (Dz = 144 NS; the bias pieces sit in the last slice, columns D .. D + 2, as in the narrow builds), a wavefront holds
+// the 9 NS query fragments of its 32 queries in registers (36 NS VGPRs: these builds run at 2 wavefronts per SIMD), and the
+// member tiles stream through LDS one slice at a time: the unit of the DMA pipeline is (tile, slice) = 32 rows x 288 bytes,
+// laid out in LDS exactly like a tile of the 144-column builds; the accumulator is carried over the NS units of a tile and
+// the selection code runs once per tile.  Bounds and thresholds are those of the narrow builds with the accumulation-error
+// factor scaled by NS (n <= 577 fp32 terms: (n - 1) 2^-23 <= 6.9e-5 <= 4 x 2.5e-5) and the fit's scale S one binade lower
+// (chb_api.hip: |x - mu_c| S < 2^10, so that -bias / 2 <= D 2^20 still fits the three fp16 pieces).  No tile skipping, pools,
+// segments or work-list form: the plain two-sweep selection (and the one-sweep update mode for the batch's own entries).
+template <int ML, bool UPD, int NS>
+__global__ __launch_bounds__(64 * kPfW, 2) void shortlist_wide_kernel(ShortlistArgs a, int nqt, int nchunk, int bpw, int *flags64,
+                                                                      int nqt64, Gate gate)
+{
+    CHB_GATE(gate);
+    constexpr int KS = 9;                    // matrix-core steps per slice
+    constexpr int CPR = 2 * KS;              // 16-byte chunks per slice of a row
+    constexpr int SLB = 32 * KS;             // bytes per slice of a row (= the row stride of a unit in LDS)
+    constexpr int ROWB = SLB * NS;           // bytes per shadow row in memory
+    constexpr int TILEB = kPfP * SLB;        // one unit (tile, slice) in LDS
+    constexpr int METAB = 512;               // update mode: floats [0,32) bias | [32,64) s | [64,96) b | [96,128) ||zh||
+    constexpr int BUFB = TILEB + METAB;
+    constexpr int NBUF = 3;
+    constexpr int kPoolW = shortlist_pool_entries(ML);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *sPool = reinterpret_cast<unsigned *>(smem + NBUF * BUFB);   // [kPfW][kPoolW]
+    int *sCnt = reinterpret_cast<int *>(sPool + kPfW * kPoolW);           // [kPfQ]
+    float *sTau = reinterpret_cast<float *>(sCnt + kPfQ);                 // [kPfQ]
+
+    // work items as in shortlist_kernel: a contiguous range of (bin run, query tile) items per XCD
+    const int total = nqt * nchunk;
+    const int per = (total + 7) >> 3;
+    if ((int)(blockIdx.x >> 3) >= per) return;
+    const int W = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (W >= total) return;
+    const int chunk = W / nqt, qt = W - chunk * nqt;
+    const int c0 = chunk * bpw, c1 = min(a.B, c0 + bpw);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smem_base = lds_addr(smem);
+    const unsigned pool_base = lds_addr(sPool) + (unsigned)(w * kPoolW * 4);
+    const int col = lane & 31, h = lane >> 5;
+    const int pos0 = a.pos_begin + qt * kPfQ;
+    const int m = a.m;
+
+    const int qpos = pos0 + 32 * w + col;
+    const bool qvalid = qpos < a.pos_end;
+    f16x8 qreg[KS * NS];
+    float nq, rg;
+    const int sidx = a.bq[qvalid ? qpos : a.pos_end - 1];
+    {
+        const unsigned short *zq = a.Gs + (size_t)sidx * (KS * NS * 16) + h * 8;
+#pragma unroll
+        for (int sx = 0; sx < KS * NS; ++sx) qreg[sx] = *reinterpret_cast<const f16x8 *>(zq + sx * 16);
+        const float2 g2 = a.gq[sidx];
+        nq = g2.x; rg = g2.y;
+    }
+    const float snq = sqrtf(nq) * (1.0f + kSlack);
+    const float qposf = (float)qpos;
+
+    // DMA roles: wavefront w moves the 1-KiB pieces w, w + 4, w + 8 of a unit; chunk cs of row r lands at cs ^ f(r),
+    // f = (r >> 4) & 1 (conflict-free ds_read_b128 fragment reads); update mode: wavefront 3 also moves bias + s, 2 b + ||zh||
+    int src_off[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int pch = (w + kPfW * j) * 64 + lane;
+        const int r = pch / CPR, cs = pch - r * CPR;
+        const int f = (r >> 4) & 1;
+        src_off[j] = r * ROWB + (cs ^ f) * 16;
+    }
+    int n_w = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) n_w += (w + kPfW * j < KS) ? 1 : 0;
+    n_w += (UPD && w == 3) ? 1 : 0;
+    n_w += (UPD && w == 2) ? 1 : 0;
+    const unsigned char *zall = reinterpret_cast<const unsigned char *>(a.P.Z);
+
+    // ---- issue side of the unit stream: (bin ic, sweep isw, tile it, slice is), two units ahead of the consumer
+    int ic = c0, it = 0, is = 0, isw = UPD ? 1 : 0, ibuf = 0;
+    int irow0 = 0, int_ = 0;
+    bool ivalid = false;
+    int n_issued = 0, n_consumed = 0;
+    auto issue_seek = [&]() __attribute__((always_inline)) {
+        ivalid = false;
+        while (ic < c1) {
+            irow0 = a.P.pad_ptr[ic];
+            int_ = a.P.nt != nullptr ? a.P.nt[ic] : (a.P.pad_ptr[ic + 1] - irow0) / kPfP;
+            if (int_ > 0) { ivalid = true; break; }
+            ++ic;
+        }
+    };
+    auto issue = [&]() __attribute__((always_inline)) {
+        unsigned char *dst_ = smem + ibuf * BUFB;
+        const size_t row_ = (size_t)irow0 + (size_t)it * kPfP;
+        const unsigned char *src_ = zall + row_ * ROWB + is * SLB;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (w + kPfW * j < KS)
+                __builtin_amdgcn_global_load_lds(src_ + src_off[j],
+                    (__attribute__((address_space(3))) void *)(dst_ + (w + kPfW * j) * 1024), 16, 0, 0);
+        if (UPD && w == 3) {   // (the member columns ride with every slice of the tile: a fixed DMA count per unit)
+            const float *p_ = (h ? a.P.cs : a.P.bias) + row_ + col;
+            __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB), 4, 0, 0);
+        }
+        if (UPD && w == 2) {
+            const float *p_ = (h ? a.P.sn : a.P.cb) + row_ + col;
+            __builtin_amdgcn_global_load_lds(p_, (__attribute__((address_space(3))) void *)(dst_ + TILEB + 256), 4, 0, 0);
+        }
+        if (++ibuf == NBUF) ibuf = 0;
+        ++n_issued;
+        if (++is == NS) {
+            is = 0;
+            if (++it == int_) {
+                it = 0;
+                if (!UPD && isw == 0) isw = 1;
+                else { isw = UPD ? 1 : 0; ++ic; issue_seek(); }
+            }
+        }
+    };
+    issue_seek();
+    if (ivalid) issue();
+    if (ivalid) issue();
+
+    // fragment addressing: chunk (2 sx + h) of row `col` of the unit, XOR-swizzled as the DMA laid it out
+    const int fbase0 = col * SLB + ((h ^ ((col >> 4) & 1)) << 4);
+    const unsigned ent0 = ((unsigned)col << 27) | (unsigned)(4 * h);
+
+    int cbuf = 0;
+    for (int c = c0; c < c1; ++c) {
+        const int row0 = a.P.pad_ptr[c];
+        const int ntile = a.P.nt != nullptr ? a.P.nt[c] : (a.P.pad_ptr[c + 1] - row0) / kPfP;
+        const size_t slot = (size_t)c * a.Kcap + (qvalid ? qpos : a.pos_end - 1);
+        // ---- per-(query, bin) bounds (as in shortlist_kernel)
+        float4 bb = a.P.bb[c];                            // {rho_bin, snb, Bmax, bias residual}
+        if (UPD) bb.y = sqrtf(bb.y) * (1.0f + 1e-6f);
+        const float2 qn2 = a.qn[(size_t)sidx * a.B + c];  // N_jc {up, down}
+        const float E = ((UPD ? 1.2e-7f * bb.z : 2.0f * bb.w) + a.gamma * (1.001f * bb.z + 2.0f * snq * bb.y)) *
+                        (1.0f + 4.0f * kSlack);
+        const float rgq = rg * (1.0f + 4.0f * kSlack);
+        const float *tsn_c = UPD ? nullptr : a.P.tsn + (row0 >> 5);
+        const float nj_hi = (qn2.x + E) * (1.0f + kSlack);
+        const float nj_lo = (qn2.y - E) * (qn2.y > E ? (1.0f - kSlack) : (1.0f + kSlack));
+        const float rsum = bb.x * (1.0f + kSlack);
+        float lb[ML];
+#pragma unroll
+        for (int i = 0; i < ML; ++i) lb[i] = i < ML - m ? INFINITY : -INFINITY;
+        float thr_s = -INFINITY;
+        float thr2 = qvalid ? -FLT_MAX : INFINITY;
+        if (UPD && qvalid) {
+            float tau = INFINITY;
+            if (a.tau_in != nullptr) tau = a.tau_in[slot];
+            else if (a.seed.cnt[slot] >= m) tau = round_up_f32(a.seed.d[slot * m + m - 1] * a.S) * (1.0f + kSlack);
+            if (tau < INFINITY) {
+                const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+                thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
+            }
+        }
+        if (h == 0) sCnt[32 * w + col] = 0;
+        // (per-tile bests: only where the m nearest are unlikely to share a tile half, and never on a shell-ordered pack)
+        const bool tile_best = ntile >= a.tile_best_min && 4 * ntile >= m * m && !(!UPD && a.skip != 0);
+        const int kmax = (ML > 8 && !tile_best && ntile >= a.tile_best_min && !(!UPD && a.skip != 0)) ? a.tile_k2 : 0x7fffffff;
+        int wcnt = 0;   // entries parked by this wavefront and not yet written out (wave-uniform)
+        auto flush = [&]() __attribute__((always_inline)) {
+            const int mb_ = a.bin_ptr[c];
+            const int npark_ = wcnt < kPoolW ? wcnt : kPoolW;
+            for (int i = lane; i < npark_; i += 64) {
+                const unsigned en = sPool[w * kPoolW + i];
+                const int qc = (int)(en >> 27), e = (int)(en & ((1u << 27) - 1u));
+                const int off = atomicAdd(&sCnt[32 * w + qc], 1);
+                if (off < a.cand_cap)
+                    a.cand[((size_t)c * a.Kcap + pos0 + 32 * w + qc) * a.cand_cap + off] = a.memb_id[mb_ + e];
+            }
+        };
+
+        for (int sweep = UPD ? 1 : 0; sweep < 2; ++sweep) {
+            const float rgs = (sweep ? rg : -rg) * (1.0f + kSlack);
+            if (!UPD && sweep == 1) {
+                // end of sweep 0: m-th smallest t over BOTH lane halves -> tau -> thr2
+                float mg[ML];
+#pragma unroll
+                for (int i = 0; i < ML; ++i) mg[i] = lb[i];
+#pragma unroll
+                for (int i = 0; i < ML; ++i) {
+                    const float o = __shfl_xor(lb[i], 32, 64);
+                    list_insert_desc<ML>(mg, i >= ML - m ? o : -INFINITY);
+                }
+                const float ms = mg[ML - 1];
+                float tau = INFINITY;
+                if (qvalid && ms > -INFINITY) {
+                    const float thr = -2.0f * ms;
+                    tau = sqrtf(fmaxf(thr + nj_hi, 0.f)) * (1.0f + 4.0f * kSlack) + rsum;
+                    const float hi = tau * (1.0f + 4.0f * kSlack) + rsum;
+                    thr2 = -0.5f * (hi * hi * (1.0f + 4.0f * kSlack) - nj_lo);
+                }
+                if (h == 0) sTau[32 * w + col] = tau;
+            }
+            // (everything loaded so far is waited for here, by a wait the compiler knows: see shortlist_kernel)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            for (int ct = 0; ct < ntile; ++ct) {
+                f32x16 acc;
+                float tsn_t = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    wait_vmcnt(n_issued - n_consumed > 1 ? n_w : 0);   // my pieces of this unit have landed
+                    __builtin_amdgcn_s_barrier();   // everybody's have; the buffer two units ahead is free again
+                    if (ivalid) issue();
+                    const unsigned tb = smem_base + (unsigned)(cbuf * BUFB);
+                    if (sl == 0) {
+                        if (UPD) {
+                            const unsigned ma = tb + (unsigned)(TILEB + 16 * h);
+                            f32x4 nv[4], nn[4], sv[4], bv[4];
+#define CHB_SL_META(G)                                                                             \
+                            nv[G] = lds_read_f4<32 * (G)>(ma);                                     \
+                            nn[G] = lds_read_f4<384 + 32 * (G)>(ma);                               \
+                            sv[G] = lds_read_f4<128 + 32 * (G)>(ma); bv[G] = lds_read_f4<256 + 32 * (G)>(ma);
+                            CHB_SL_META(0) CHB_SL_META(1) CHB_SL_META(2) CHB_SL_META(3)
+#undef CHB_SL_META
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "+v"(nn[0]), "+v"(nn[1]), "+v"(nn[2]),
+                                           "+v"(nn[3])
+                                         :
+                                         : "memory");
+                            asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(bv[0]), "+v"(bv[1]),
+                                              "+v"(bv[2]), "+v"(bv[3]) : : "memory");
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    acc[4 * g + k] = fmaf(rgs, nn[g][k], -0.5f * nv[g][k]);
+                                    if (fmaf(sv[g][k], qposf, bv[g][k]) < 0.f) acc[4 * g + k] = -INFINITY;
+                                }
+                            }
+                        } else {
+                            // the tile's largest member norm: a SCALAR load (complete behind the fragment reads' wait below)
+                            const unsigned long long ta = reinterpret_cast<unsigned long long>(tsn_c + ct);
+                            const unsigned ta_lo = __builtin_amdgcn_readfirstlane((unsigned)ta);
+                            const unsigned ta_hi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
+                            const unsigned long long ta_s = ((unsigned long long)ta_hi << 32) | ta_lo;
+                            asm volatile("s_load_dword %0, %1, 0x0" : "=s"(tsn_t) : "s"(ta_s) : "memory");
+                            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        }
+                    }
+                    f16x8 af[KS];
+                    {
+                        const unsigned fa0 = tb + (unsigned)fbase0;
+                        af[0] = lds_read_frag<0>(fa0);   af[1] = lds_read_frag<32>(fa0);  af[2] = lds_read_frag<64>(fa0);
+                        af[3] = lds_read_frag<96>(fa0);  af[4] = lds_read_frag<128>(fa0); af[5] = lds_read_frag<160>(fa0);
+                        af[6] = lds_read_frag<192>(fa0); af[7] = lds_read_frag<224>(fa0); af[8] = lds_read_frag<256>(fa0);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]),
+                                   "+v"(af[6]), "+v"(af[7]), "+v"(af[8]), "+s"(tsn_t)
+                                 :
+                                 : "memory");
+#pragma unroll
+                    for (int sx = 0; sx < KS; ++sx)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[sx], qreg[sl * KS + sx], acc, 0, 0, 0);
+                    ++n_consumed;
+                    if (++cbuf == NBUF) cbuf = 0;
+                }
+                // ---- the tile's selection code
+                const float dlt = UPD ? 0.f : rgq * tsn_t;
+                if (!UPD && sweep == 0) {
+                    float mx = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                    if (tile_best) {
+                        if (mx - dlt > thr_s) {
+                            list_insert_desc<ML>(lb, mx - dlt);
+                            thr_s = lb[ML - 1];
+                        }
+                    } else
+                    for (int left = ML > 8 ? kmax : 1; left > 0 && mx - dlt > thr_s; left -= ML > 8 ? 1 : 0) {
+                        list_insert_desc<ML>(lb, mx - dlt);
+                        thr_s = lb[ML - 1];
+                        float nx = -INFINITY;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            acc[r] = acc[r] == mx ? -INFINITY : acc[r];
+                            nx = fmaxf(nx, acc[r]);
+                        }
+                        mx = nx;
+                    }
+                } else {
+                    if ((ML > 8 || (UPD && ML > 1)) && wcnt >= kPoolW / 2 && wcnt <= kPoolW) {
+                        flush();
+                        wcnt = 0;
+                    }
+                    const unsigned ebase = ent0 + (unsigned)(ct * kPfP);
+                    const float thr_t = thr2 - dlt;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool hit = acc[r] >= thr_t;
+                        const unsigned long long bal = __ballot(hit);
+                        if (bal) {
+                            const int before = __builtin_amdgcn_mbcnt_hi(
+                                (unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                            const int pos = wcnt + before;
+                            if (hit && pos < kPoolW)
+                                lds_write_u32(pool_base + 4u * (unsigned)pos, ebase + (unsigned)((r & 3) + 8 * (r >> 2)));
+                            wcnt += __popcll(bal);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- end of the bin: write the parked entries out
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (my asm pool writes, before the ordinary reads of the flush)
+        flush();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int ccount = (qvalid && h == 0) ? sCnt[32 * w + col] : 0;
+        if (qvalid && h == 0) {
+            a.cand_cnt[slot] = ccount < a.cand_cap ? ccount : a.cand_cap;
+            if (!UPD && a.tau_out != nullptr) a.tau_out[slot] = sTau[32 * w + col];
+            if (ccount > a.cand_cap || wcnt > kPoolW) {
+                atomicAdd(a.overflow, 1);
+                const int fi = c * nqt64 + (qpos - a.pos_begin) / kQTile;
+                if (atomicExch(&flags64[fi], 1) == 0) a.flaglist[atomicAdd(a.nflag, 1)] = fi;
+            }
+        }
+    }
+}
+
 // (four: the layout of the kFour builds -- no bias / norm column slots, the seat table in the segment bases' place)
 static size_t shortlist_lds_bytes(int ks, int ml, bool four = false)
 {
@@ -2180,6 +2507,33 @@ static void launch_sl(const ShortlistArgs &a, int *flags64, hipStream_t s)
     }
 }
 
+// the wide-row builds (Dz = 144 NS, NS = 2 .. 4): plain two-sweep base launch / one-sweep update launch
+template <int ML, bool UPD>
+static void launch_sl_wide(const ShortlistArgs &a, int *flags64, hipStream_t s)
+{
+    const int nq = a.pos_end - a.pos_begin;
+    const int nqt = (nq + kPfQ - 1) / kPfQ;
+    const int nqt64 = (nq + kQTile - 1) / kQTile;
+    const long long units = (long long)nqt * a.B;
+    int bpw = (int)std::max<long long>(1, units / (UPD ? 1024 : 2048));
+    bpw = std::min(bpw, a.B);
+    const int nchunk = (a.B + bpw - 1) / bpw;
+    const int total = nqt * nchunk;
+    const int grid = ((total + 7) / 8) * 8;
+    const size_t lds = shortlist_lds_bytes(9, ML);
+    switch (a.Dz / 144) {
+    case 2:
+        hipLaunchKernelGGL((shortlist_wide_kernel<ML, UPD, 2>), dim3(grid), dim3(64 * kPfW), lds, s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+        break;
+    case 3:
+        hipLaunchKernelGGL((shortlist_wide_kernel<ML, UPD, 3>), dim3(grid), dim3(64 * kPfW), lds, s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+        break;
+    default:
+        hipLaunchKernelGGL((shortlist_wide_kernel<ML, UPD, 4>), dim3(grid), dim3(64 * kPfW), lds, s, a, nqt, nchunk, bpw, flags64, nqt64, g_gate);
+        break;
+    }
+}
+
 template <int ML>
 static void launch_sl_work(const ShortlistArgs &a, int *flags64, int grid, hipStream_t s)
 {
@@ -2197,7 +2551,14 @@ static void launch_sl_work(const ShortlistArgs &a, int *flags64, int grid, hipSt
 
 int shortlist_list_len(int m) { return m <= 5 ? 5 : (m <= 8 ? 8 : 16); }
 
-int shadow_row_elems(int D) { return D + kBiasCols <= 144 ? 144 : (D + kBiasCols <= 160 ? 160 : 0); }
+// 144 or 160 columns (the narrow builds), else 2 .. 4 slices of 144 (the wide builds, D <= 573), else 0 (no shortlist stage)
+int shadow_row_elems(int D)
+{
+    if (D + kBiasCols <= 144) return 144;
+    if (D + kBiasCols <= 160) return 160;
+    const int ns = (D + kBiasCols + 143) / 144;
+    return ns <= kWideMaxSlices ? 144 * ns : 0;
+}
 
 void launch_global_center(const double *X, int N, int D, int Dp, double *part, int part_blocks, double *mu_g,
                           unsigned int *rmax, hipStream_t s)
@@ -2371,7 +2732,7 @@ void launch_shortlist_worklist(const ShortlistArgs &a_, int *flags64, hipStream_
     a.pool = PoolState{}; a.qord = nullptr; a.home = nullptr; a.skip_stat = nullptr; a.pool_stat = nullptr;
     a.seg = SegPlan{};   // (a segmented bin's pairs were never on the pool launch's list)
     const int nq = a.pos_end - a.pos_begin;
-    if (nq <= 0 || a.B <= 0 || a.update || a.worklist == nullptr) return;
+    if (nq <= 0 || a.B <= 0 || a.update || a.worklist == nullptr || a.Dz > 160) return;   // (wide rows: no pools, no second chance)
     const long long items = (long long)((nq + kQTile - 1) / kQTile) * a.B;
     const int grid = (int)std::min<long long>(items, 2048);
     if (a.m <= 5) launch_sl_work<5>(a, flags64, grid, s);
@@ -2396,6 +2757,17 @@ void launch_shortlist(const ShortlistArgs &a_, int *flags64, hipStream_t s)
 #endif
     const int nq = a.pos_end - a.pos_begin;
     if (nq <= 0 || a.B <= 0) return;
+    if (a.Dz > 160) {
+        // wide rows: NS slices of 144 columns, up to 144 NS + 1 fp32 terms per accumulator
+        a.gamma *= (float)(a.Dz / 144);
+        if (a.update) {
+            if (a.m <= 8) launch_sl_wide<1, true>(a, flags64, s);
+            else launch_sl_wide<2, true>(a, flags64, s);
+        } else if (a.m <= 5) launch_sl_wide<5, false>(a, flags64, s);
+        else if (a.m <= 8) launch_sl_wide<8, false>(a, flags64, s);
+        else launch_sl_wide<16, false>(a, flags64, s);
+        return;
+    }
     if (a.update) {
         if (a.m <= 8) launch_sl<1, true>(a, flags64, s);
         else launch_sl<2, true>(a, flags64, s);   // (ML is unused in update mode: 2 marks the m > 8 build)

@@ -1980,7 +1980,8 @@ void launch_hull_qp(const QpArgs &a, hipStream_t s)
     dispatch<false>(a, nprob, a.m, nullptr, nullptr, nullptr, nullptr, nullptr, s);
 }
 
-bool fused_supported(int m, int Dp) { return m >= 1 && m <= 16 && Dp <= kFusedMaxDp; }
+// (m <= 5: the vector-Gram kernel sweeps rows of any width; 5 < m <= 16: the 16-lane kernel stages the query row in LDS)
+bool fused_supported(int m, int Dp) { return m >= 1 && m <= 16 && (m <= 5 || Dp <= kFusedMaxDp); }
 
 void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
 {

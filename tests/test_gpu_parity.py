@@ -289,6 +289,11 @@ CASES = [
     (1200, 140, 5, 5, 10, 9e-3, 0.9, 4, 4096),    # heavy overlap: many movers, many rounds
     (700, 24, 9, 3, 5, 4e-3, 0.0, 2, 128),        # bins start smaller than m
     (2000, 136, 8, 5, 3, 1.5e-3, 0.0, None, 0),   # SURVEY 8(d) generator as-is
+    # wide rows (round 5: shadow rows of two to four 144-column slices): k = 5 width on the fused kernel with overlapping
+    # bins (update-mode shortlist, repeated rounds), the default neighbour count on the list-based kernels
+    (900, 528, 8, 5, 5, 3e-3, 0.6, 8, 257),
+    (800, 300, 6, 15, 3, 3e-3, 0.6, 20, 300),
+    (1500, 200, 5, 5, 6, 5e-3, 0.9, 4, 2048),
 ]
 
 
@@ -462,7 +467,8 @@ def _brute_ctx():
     return c
 
 
-@pytest.mark.parametrize("kind", ["offset", "tiny", "dups", "wide", "onehot", "bigbins", "d141", "d157", "spread"])
+@pytest.mark.parametrize("kind", ["offset", "tiny", "dups", "wide", "onehot", "bigbins", "d141", "d157", "spread",
+                                  "d158", "d300", "d528", "d573", "d528offset", "d300dups", "d285bigbins", "d573spread"])
 def test_shortlist_stage_equals_brute_force(ctx, O, kind):
     """The fp16 shortlist + exact rescoring must give bit-identical lists to the brute-force
     kernel on data built to stress the error bounds and the overflow fallback."""
@@ -474,19 +480,31 @@ def test_shortlist_stage_equals_brute_force(ctx, O, kind):
         D = 141                 # the widest rows of the 144-column build: exactly three spare (bias) columns
     if kind == "d157":
         D = 157                 # ... of the 160-column build
+    # wide rows (round 5): two to four 144-column slices per shadow row -- the narrowest (158 = two slices), k = 5 (512
+    # k-mer columns + 16), the widest (573 = 4 x 144 - 3), with the stress kinds of the narrow builds on top
+    if kind.startswith("d158"):
+        D = 158
+    if kind.startswith("d300"):
+        D = 300
+    if kind.startswith("d528"):
+        D = 528
+    if kind.startswith("d573"):
+        D = 573
+    if kind == "d285bigbins":
+        D, N, B = 285, 9000, 4  # exactly two slices; > 512 members per bin (per-tile bests)
     X, _, true = _synth(N, D, B, seed=4, sigma=3e-3, mix=0.5)
-    if kind == "offset":
+    if kind in ("offset", "d528offset"):
         X = X + 1000.0                                   # huge common offset: centring must cope
     elif kind == "tiny":
         X = X * 1e-150
-    elif kind == "dups":
+    elif kind in ("dups", "d300dups"):
         X[100:400] = X[100]                              # 300 identical members: shortlist overflow
         true[100:400] = 1
     elif kind == "wide":
         X = X * rng.lognormal(0, 3, size=(1, D))         # wildly different column scales
     elif kind == "onehot":
         X = np.zeros((N, D)); X[np.arange(N), rng.integers(0, D, N)] = 1.0   # massive exact ties
-    elif kind == "spread":
+    elif kind in ("spread", "d573spread"):
         # bins 2^17 times further apart than they are wide: the members' bias (carried as three fp16 pieces in the
         # shadow rows) is huge against the distances that decide the selection
         X = X + 1e3 * true[:, None] * rng.random((1, D))
@@ -506,7 +524,7 @@ def test_shortlist_stage_equals_brute_force(ctx, O, kind):
         b.close()
     for g, w_ in zip(got, want):
         assert np.array_equal(g, w_)
-    if kind in ("dups", "onehot"):
+    if kind in ("dups", "onehot", "d300dups"):
         assert overflow > 0                              # the fallback really ran
     # and against the oracle for a few queries
     for qi in range(0, 700, 97):
@@ -518,15 +536,17 @@ def test_shortlist_stage_equals_brute_force(ctx, O, kind):
             assert np.array_equal(got[0][qi, c, :len(want_idx)], want_idx)
 
 
-@pytest.mark.parametrize("N,D,B,m", [(20000, 136, 500, 5), (12000, 140, 64, 15), (9000, 146, 3, 8), (12000, 136, 12, 15)])
+@pytest.mark.parametrize("N,D,B,m", [(20000, 136, 500, 5), (12000, 140, 64, 15), (9000, 146, 3, 8), (12000, 136, 12, 15),
+                                     (16000, 528, 12, 5), (9000, 300, 6, 15), (9000, 573, 5, 8)])
 def test_fit_two_stage_equals_brute_force_selection(O, N, D, B, m):
     """Whole fits with the two-stage selection against the same fits with CHB_PREFILTER=0 (brute-force
     selection kernel) at sizes the oracle cannot replay: many small bins, long lists (m = 15, where
     the shortlist pool is emptied mid-bin and overflow fallbacks occur), few huge bins, and (round 4) m = 15 on bins
     of ~1000 members = 31 tiles: >= 16 tiles but 4 x tiles < m^2, where sweep 0 lets the three best values per tile
-    half compete."""
+    half compete; (round 5) wide rows -- k = 5 (528 columns, four slices) with the persistent pack and the fused m <= 5
+    kernel, three slices with m = 15 on the list-based kernels, the widest rows (573) with m = 8."""
     from chbin_amd import _lib
-    S = 1 if D <= 136 else (5 if D == 140 else 10)
+    S = 1 if (D <= 136 or D > 160) else (5 if D == 140 else 10)
     X, initial, _ = _synth(N, D, B, S=S, seed=3, sigma=3e-3, mix=0.3, n_seed=3)
     perms = _perms(initial, 3)
     a = _lib.Context(0)
@@ -639,17 +659,23 @@ def test_native_comm_exchange_path_world1(O):
         c.close()
 
 
-@pytest.mark.parametrize("N,D,B,m", [(400, 300, 3, 5), (300, 8, 1, 4), (900, 146, 40, 5), (64, 16, 2, 16)])
+@pytest.mark.parametrize("N,D,B,m", [(400, 300, 3, 5), (300, 8, 1, 4), (900, 146, 40, 5), (64, 16, 2, 16),
+                                     (700, 200, 4, 15), (500, 528, 3, 5), (300, 573, 2, 8), (300, 574, 2, 5)])
 def test_fit_cluster_odd_shapes(ctx, O, N, D, B, m):
-    """D > 160 (no fp16 shadow: brute-force selection), a single bin, many bins with few members
+    """157 < D <= 573 (the wide shortlist builds, round 5: with the fused kernel for m <= 5, the list-based hull kernels
+    beyond), D = 574 (no fp16 shadow: brute-force selection), a single bin, many bins with few members
     each, D = 146 (10 coverage columns: 10 MFMA k-steps), m = 16 with bins smaller than m."""
     S = 10 if D == 146 else 1
     X, initial, _ = _synth(N, D, B, S=S, seed=D + B, sigma=6e-3, mix=0.5, n_seed=3)
     perms = _perms(initial, 4)
     want, its_o, ch_o = O.fit_cluster(X, B, initial, perms, m, 4)
     ctx.set_samples(X)
+    assert ctx.counter("prefilter_enabled") == (1 if D <= 573 else 0)
     got, its, ch = ctx.fit_cluster(B, initial, perms, m, 4, batch=150)
     assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
+    if D > 160:
+        # (the fused m <= 5 kernel sweeps rows of any width; the 16-lane one stages its query row in LDS: 288 doubles)
+        assert ctx.counter("fused_enabled") == (1 if (D <= 573 and (m <= 5 or (D + 15) // 16 * 16 <= 288)) else 0)
 
 
 def test_hull_distance_kkt_properties(ctx, O):
