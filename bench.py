@@ -433,7 +433,8 @@ def main():
                              key=lambda k: -tr[k].get("launches", 0))
             tmap = {"prefilter": base_sl + [f"shortlist_kernel<{ml}, false, 9, 0, false>", f"shortlist_kernel<{ml}, false, 9, 0>",
                                             f"shortlist_kernel<{ml}, false, 9>"],
-                    "hull_qp": ["hull_select_qp_kernel<5, 7, 4, true>"] if m <= 5 else ["hull_select_qp16_kernel<4>"],
+                    "hull_qp": ["hull_select_qp_kernel<5, 7, 4, true>"] if m <= 5 else
+                               ["hull_select_qp16_kernel<4, false>", "hull_select_qp16_kernel<4>"],
                     "prefilter_update": [f"shortlist_kernel<{1 if m <= 8 else 2}, true, {9 if D <= 141 else 10}, 0, false, false, false>",
                                          f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false, false>",
                                          f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false>",

@@ -1271,23 +1271,28 @@ __device__ __forceinline__ void gram_sweep16_chunk(const double *vptr, const dou
         }
     }
 }
+// (rows wider than the LDS tile that stages the query row -- round 5 -- are swept in WINDOWS of up to kFusedMaxDp columns:
+//  c0 = first column of the window, Dk = its width, xs = the query row's columns c0 .. c0 + Dk; `first` clears the extra-row
+//  sums, `last` reduces them.  The one-window call of the narrow rows is the defaults.)
 template <int NE, int CH>
 __device__ __forceinline__ void gram_sweep16(const double *X, int Dp, int Dk, int q, int idv, const int (&ide)[kExtraMax], int kq,
                                              const double *xs, f64x4 &acc, double (&ae)[kExtraMax],
-                                             double (&ee)[kExtraNP])
+                                             double (&ee)[kExtraNP], int c0 = 0, bool first = true, bool last = true)
 {
-    const double *vptr = X + (size_t)(idv >= 0 ? idv : q) * Dp + 4 * kq;   // a missing vertex reads the query row: y = 0
+    const double *vptr = X + (size_t)(idv >= 0 ? idv : q) * Dp + 4 * kq + c0;   // a missing vertex reads the query row: y = 0
     const double *eptr[kExtraMax];
 #pragma unroll
-    for (int b = 0; b < kExtraMax; ++b) eptr[b] = X + (size_t)(b < NE ? ide[b] : q) * Dp + 4 * kq;
+    for (int b = 0; b < kExtraMax; ++b) eptr[b] = X + (size_t)(b < NE ? ide[b] : q) * Dp + 4 * kq + c0;
+    if (first) {
 #pragma unroll
-    for (int b = 0; b < kExtraMax; ++b) ae[b] = 0.0;
+        for (int b = 0; b < kExtraMax; ++b) ae[b] = 0.0;
 #pragma unroll
-    for (int e = 0; e < kExtraNP; ++e) ee[e] = 0.0;
+        for (int e = 0; e < kExtraNP; ++e) ee[e] = 0.0;
+    }
     int k0 = 0;
     for (; k0 + CH <= Dk; k0 += CH) gram_sweep16_chunk<NE, CH, true>(vptr, eptr, xs, k0, kq, Dk, acc, ae, ee);
     if (k0 < Dk) gram_sweep16_chunk<NE, CH, false>(vptr, eptr, xs, k0, kq, Dk, acc, ae, ee);
-    if (NE > 0) {
+    if (NE > 0 && last) {
         // sum over the four feature slices
 #pragma unroll
         for (int b = 0; b < NE; ++b) {
@@ -1382,7 +1387,9 @@ __global__ __launch_bounds__(256, CHB_QP16_OCC) void hull_qp16_kernel(QpArgs a, 
 // The diagonal = the squared distances ranks the candidates; the entries between the m nearest become the hull's
 // Gram tile (vertex slot = rank).  For n <= 18 that happens after the sweeps, the four pairs of the wavefront
 // side by side (16 lanes each: lane i owns candidate i's row of the raw tile and moves it to its slot).
-template <int WAVES>
+// WIDEROW: the instantiation for rows wider than kFusedMaxDp columns (its window loop would cost the ordinary one 24 spilled
+// registers).
+template <int WAVES, bool WIDEROW>
 __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_kernel(FusedArgs a, int nprob, Gate gate)
 {
     CHB_GATE(gate);
@@ -1399,6 +1406,9 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
     const int grp = lane >> 4, l16 = lane & 15;
     const int m = a.m;
     const int Dk = (a.D + 7) & ~7;   // columns swept (the rows are padded to whole 128-byte lines beyond)
+    // rows wider than the tile that stages a pair's query row (kFusedMaxDp = 288 doubles; wide feature vectors, round 5):
+    // the sweep of a pair then runs in windows of 288 columns, all 64 lanes staging each window's piece of the query row
+    constexpr bool widerow = WIDEROW;   // (the launcher: Dk > kFusedMaxDp)
     // the two-tile form works on one pair at a time inside the sweep loop and borrows the wavefront's group arrays
     // (32 of the 80 entries each), which the groups only use after the loop
     double *sDw = &sGD[w][0][0];
@@ -1456,11 +1466,13 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
             if ((unsigned)idm >= (unsigned)a.n_samples) idm = -1;
             if ((unsigned)idx >= (unsigned)a.n_samples) idx = -1;
         }
-        double *xq = &sQ[w][grp][0][0];
-        const int Dp16 = (Dk + 15) & ~15;
-        for (int e = 2 * l16; e < Dp16; e += 32)
-            *reinterpret_cast<double2 *>(xq + e) =
-                e < Dk ? *reinterpret_cast<const double2 *>(a.X + (size_t)qid * a.Dp + e) : double2{0.0, 0.0};
+        if (!widerow) {
+            double *xq = &sQ[w][grp][0][0];
+            const int Dp16 = (Dk + 15) & ~15;
+            for (int e = 2 * l16; e < Dp16; e += 32)
+                *reinterpret_cast<double2 *>(xq + e) =
+                    e < Dk ? *reinterpret_cast<const double2 *>(a.X + (size_t)qid * a.Dp + e) : double2{0.0, 0.0};
+        }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -1488,9 +1500,25 @@ __global__ __launch_bounds__(64 * WAVES, CHB_QP16_OCC) void hull_select_qp16_ker
             double ae[kExtraMax], ee[kExtraNP];
             QP16_CLK(tp1);
             QP16_CLK_ACC(c_ids, tp1 - tp0);
-            if (ne == 0) gram_sweep16<0, CHB_SW0>(a.X, a.Dp, Dk, q, idA, ide, kq, Qp, aa, ae, ee);
-            else if (ne == 1) gram_sweep16<1, CHB_SW1>(a.X, a.Dp, Dk, q, idA, ide, kq, Qp, aa, ae, ee);
-            else gram_sweep16<2, CHB_SW2>(a.X, a.Dp, Dk, q, idA, ide, kq, Qp, aa, ae, ee);
+            if (!widerow) {
+                if (ne == 0) gram_sweep16<0, CHB_SW0>(a.X, a.Dp, Dk, q, idA, ide, kq, Qp, aa, ae, ee);
+                else if (ne == 1) gram_sweep16<1, CHB_SW1>(a.X, a.Dp, Dk, q, idA, ide, kq, Qp, aa, ae, ee);
+                else gram_sweep16<2, CHB_SW2>(a.X, a.Dp, Dk, q, idA, ide, kq, Qp, aa, ae, ee);
+            } else {
+#pragma unroll 1
+                for (int c0 = 0; c0 < Dk; c0 += kFusedMaxDp) {
+                    const int cw = min(kFusedMaxDp, Dk - c0), cw16 = (cw + 15) & ~15;
+                    __builtin_amdgcn_wave_barrier();   // (the previous window's reads of the tile are issued: LDS keeps a wavefront's order)
+                    for (int e = 2 * lane; e < cw16; e += 128)
+                        *reinterpret_cast<double2 *>(Qp + e) =
+                            e < cw ? *reinterpret_cast<const double2 *>(a.X + (size_t)q * a.Dp + c0 + e) : double2{0.0, 0.0};
+                    __builtin_amdgcn_wave_barrier();
+                    const bool fst = c0 == 0, lst = c0 + kFusedMaxDp >= Dk;
+                    if (ne == 0) gram_sweep16<0, CHB_SW1>(a.X, a.Dp, cw, q, idA, ide, kq, Qp, aa, ae, ee, c0, fst, lst);
+                    else if (ne == 1) gram_sweep16<1, CHB_SW1>(a.X, a.Dp, cw, q, idA, ide, kq, Qp, aa, ae, ee, c0, fst, lst);
+                    else gram_sweep16<2, CHB_SW2>(a.X, a.Dp, cw, q, idA, ide, kq, Qp, aa, ae, ee, c0, fst, lst);
+                }
+            }
             if (ne > 0) {
                 if (kq == 0) {
 #pragma unroll
@@ -1980,8 +2008,9 @@ void launch_hull_qp(const QpArgs &a, hipStream_t s)
     dispatch<false>(a, nprob, a.m, nullptr, nullptr, nullptr, nullptr, nullptr, s);
 }
 
-// (m <= 5: the vector-Gram kernel sweeps rows of any width; 5 < m <= 16: the 16-lane kernel stages the query row in LDS)
-bool fused_supported(int m, int Dp) { return m >= 1 && m <= 16 && (m <= 5 || Dp <= kFusedMaxDp); }
+// (rows of any width: the m <= 5 kernel sweeps them from registers, the 16-lane kernel stages the query row in LDS in
+//  windows of kFusedMaxDp columns)
+bool fused_supported(int m, int Dp) { (void)Dp; return m >= 1 && m <= 16; }
 
 void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
 {
@@ -1997,7 +2026,10 @@ void launch_hull_select_qp(const FusedArgs &a, hipStream_t s)
             np16 = (a.pos_end - a.pos_begin) * ((a.B + 7) / 8);
             grid16 = 8 * ((np16 + 4 * WV - 1) / (4 * WV));
         }
-        hipLaunchKernelGGL((hull_select_qp16_kernel<WV>), dim3(grid16), dim3(64 * WV), 0, s, as, np16, g_gate);
+        if (((a.D + 7) & ~7) > kFusedMaxDp)
+            hipLaunchKernelGGL((hull_select_qp16_kernel<WV, true>), dim3(grid16), dim3(64 * WV), 0, s, as, np16, g_gate);
+        else
+            hipLaunchKernelGGL((hull_select_qp16_kernel<WV, false>), dim3(grid16), dim3(64 * WV), 0, s, as, np16, g_gate);
         return;
     }
     int np5 = nprob, grid = (nprob + 64 * WV - 1) / (64 * WV);

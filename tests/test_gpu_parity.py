@@ -662,8 +662,8 @@ def test_native_comm_exchange_path_world1(O):
 @pytest.mark.parametrize("N,D,B,m", [(400, 300, 3, 5), (300, 8, 1, 4), (900, 146, 40, 5), (64, 16, 2, 16),
                                      (700, 200, 4, 15), (500, 528, 3, 5), (300, 573, 2, 8), (300, 574, 2, 5)])
 def test_fit_cluster_odd_shapes(ctx, O, N, D, B, m):
-    """157 < D <= 573 (the wide shortlist builds, round 5: with the fused kernel for m <= 5, the list-based hull kernels
-    beyond), D = 574 (no fp16 shadow: brute-force selection), a single bin, many bins with few members
+    """157 < D <= 573 (the wide shortlist builds, round 5; the fused 16-lane kernel sweeps rows beyond 288 columns in
+    windows), D = 574 (no fp16 shadow: brute-force selection), a single bin, many bins with few members
     each, D = 146 (10 coverage columns: 10 MFMA k-steps), m = 16 with bins smaller than m."""
     S = 10 if D == 146 else 1
     X, initial, _ = _synth(N, D, B, S=S, seed=D + B, sigma=6e-3, mix=0.5, n_seed=3)
@@ -674,8 +674,8 @@ def test_fit_cluster_odd_shapes(ctx, O, N, D, B, m):
     got, its, ch = ctx.fit_cluster(B, initial, perms, m, 4, batch=150)
     assert its == its_o and np.array_equal(ch, ch_o) and np.array_equal(got, want)
     if D > 160:
-        # (the fused m <= 5 kernel sweeps rows of any width; the 16-lane one stages its query row in LDS: 288 doubles)
-        assert ctx.counter("fused_enabled") == (1 if (D <= 573 and (m <= 5 or (D + 15) // 16 * 16 <= 288)) else 0)
+        # (both fused kernels take rows of any width: the 16-lane one stages its query row in LDS in windows of 288 columns)
+        assert ctx.counter("fused_enabled") == (1 if D <= 573 else 0)
 
 
 def test_hull_distance_kkt_properties(ctx, O):
@@ -909,6 +909,13 @@ F16_CASES = [
     (1200, 40, 4, 12, 3, 800, False),      # few seeds, large batches: most candidates are batch entries (two tiles, exact path)
     (800, 157, 3, 15, 20, 0, False),       # the longest rows the shortlist stage takes (157 + 3 bias columns = 160)
     (1000, 64, 4, 15, 20, 0, True),        # duplicated members: exact ties at the selection boundary -> exact path
+    # rows wider than the 288-column tile that stages the query row (round 5): the WIDEROW instantiation's windows --
+    # two windows with a short second one, k = 5 width (two windows), the widest rows (576 = exactly two), many batch entries
+    (900, 300, 4, 15, 20, 0, False),
+    (900, 528, 4, 15, 20, 0, False),
+    (700, 573, 3, 16, 20, 0, False),
+    (900, 300, 4, 12, 3, 600, False),
+    (800, 528, 4, 15, 20, 0, True),
 ]
 
 
