@@ -275,6 +275,7 @@ struct chb_ctx {
     DevBuf<unsigned short> pool_Z;
     DevBuf<int> pool_id, pool_hole, pool_ok, pool_stat;
     DevBuf<float> pool_key, pool_sn, pool_tsn;
+    bool pool_force = false;    // CHB_POOL_TAU=2: pools whatever the size of the fit (A/B tests)
     bool pool_allowed = true;   // CHB_POOL_TAU=0: the base shortlist launch always streams a bin twice (the form up to round 4; A/B tests)
     bool pool_fit = false;      // inside chb_fit_cluster (the stepwise entry points and chb_topm_per_bin never use pools)
     bool pool_valid = false;    // the pools on the device match the labels
@@ -632,6 +633,10 @@ int pool_build(chb_ctx *h)
     if (!h->pool_allowed || !h->fused || !h->pf_fit || !h->pf_base || h->ckey.p == nullptr || B < 2 || h->m > 8 || h->Dz > 160 ||
         slots * (size_t)h->Dz * sizeof(unsigned short) > kPoolMaxBytes)
         return CHB_OK;
+    // (small fits: a bin of a few tiles has no threshold sweep worth replacing, while the pools' build and upkeep are per
+    //  fit and per batch -- BASELINE configs[1], 10k x 32 = 10 tiles per bin, went from 1.45 to 1.85 ms per sweep with them.
+    //  From 16 tiles per bin on average; CHB_POOL_TAU=2 keeps them whatever the size)
+    if (!h->pool_force && (size_t)h->N < 512 * B) return CHB_OK;
     if (h->pool_Z.ensure(slots * (size_t)h->Dz) != hipSuccess || h->pool_id.ensure(slots) != hipSuccess ||
         h->pool_hole.ensure(slots) != hipSuccess || h->pool_key.ensure(slots) != hipSuccess || h->pool_sn.ensure(slots) != hipSuccess ||
         h->pool_tsn.ensure(B * B + 64) != hipSuccess || h->pool_ok.ensure(B * B) != hipSuccess) {
@@ -1192,7 +1197,7 @@ int chb_create(int device_id, chb_ctx **out)
     if (const char *ev = getenv("CHB_SEGMENTS")) h->allow_segments = atoi(ev) != 0;
     if (const char *ev = getenv("CHB_TILE_SKIP")) h->allow_skip = atoi(ev) != 0;
     if (const char *ev = getenv("CHB_PACK_INCR")) h->pp_allowed = atoi(ev) != 0;
-    if (const char *ev = getenv("CHB_POOL_TAU")) h->pool_allowed = atoi(ev) != 0;
+    if (const char *ev = getenv("CHB_POOL_TAU")) { h->pool_allowed = atoi(ev) != 0; h->pool_force = atoi(ev) == 2; }
     if (e != hipSuccess) { delete h; return fail(CHB_EHIP, hipGetErrorString(e)); }
     *out = h;
     return CHB_OK;

@@ -31,6 +31,8 @@
  *                           kept across the batches of a fit and updated by each commit, where tiles are not skipped)
  *       CHB_POOL_TAU=0      the base shortlist launch always streams a bin twice (threshold sweep + admission sweep); default:
  *                           the threshold comes from a per-(bin, home bin) pool tile where one exists, and the bin is streamed once
+ *                           (fits of m <= 8 neighbours, rows of up to 157 columns and at least 512 contigs per bin on average;
+ *                           CHB_POOL_TAU=2: whatever the fit's size)
  *       CHB_TILE_SKIP=0     the shortlist stage never skips member tiles (default: on for fits whose first batches
  *                           show that tiles can be skipped -- data with several coverage columns)
  */
@@ -215,8 +217,9 @@ int chb_profile_get(chb_ctx *h, const char *kernel, double *total_ms, int64_t *l
 /* counters of the last chb_fit_cluster call: [0]=batches [1]=rounds [2]=hull distances evaluated
  * (incl. speculative re-evaluation) [3]=hull distances the sequential loop needs (sweeps*n_move*B) */
 int chb_fit_stats(chb_ctx *h, int64_t *out4);
-/* diagnostic counters: "prefilter_enabled" (1 when the fp16 shortlist stage is active; the
- * environment variable CHB_PREFILTER=0 selects the brute-force selection kernel instead),
+/* diagnostic counters: "prefilter_enabled" (1 when the fp16 shortlist stage is active: feature vectors of up to 573
+ * columns -- 157 on the narrow builds, two to four 144-column slices beyond, which covers KmerK = 5; wider samples, or the
+ * environment variable CHB_PREFILTER=0, select the brute-force selection kernel instead),
  * "prefilter_overflow" (shortlists that overflowed and were recomputed by brute force since the
  * last chb_fit_begin), "fused_enabled" (1 when the fused selection + hull kernels serve the fit), "segment_batches"
  * (batches of the last fit that cut a giant bin into segments), "batch_size" (speculative batch size of the last fit),
