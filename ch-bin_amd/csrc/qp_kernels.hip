@@ -959,7 +959,11 @@ constexpr int kQ16Ld = 18;   // row stride of the 16 x 16 Gram tile in LDS (16-b
 // vertex v enters: false (and no change) when it is affinely dependent on the support.
 // Qt = the group's LIFTED Gram tile in LDS (Q + s, row stride kQ16Ld), sv = its 16-double exchange row.
 // Rows and columns of H outside the support are zero, so the products below need no support mask.
-__device__ __forceinline__ bool inv16_insert(Inv16 &I, const double *Qt, double *sv, unsigned &S, int v, int l16)
+// small (out): the accepted pivot was below kSmallPivot x the vertex's own lifted norm -- the support is ill-conditioned
+// (cond ~ 1 / that ratio), see solve16's rebuild.  reject: the pivot below which the vertex counts as dependent.
+constexpr double kSmallPivot = 1e-4;
+__device__ __forceinline__ bool inv16_insert(Inv16 &I, const double *Qt, double *sv, unsigned &S, int v, int l16, bool &small,
+                                             double reject = 1e-13)
 {
     // a = lifted row v (a broadcast read); u = H a
     double u = 0.0;
@@ -993,7 +997,8 @@ __device__ __forceinline__ bool inv16_insert(Inv16 &I, const double *Qt, double 
         u += du;
         delta = avv - group_sum16(a_own * u);
     }
-    if (!(delta > 1e-13 * avv)) return false;
+    small = !(delta > kSmallPivot * avv);
+    if (!(delta > reject * avv)) return false;
     const double inv = fast_rcp(delta);
     // bordering: H' = H + w w^T / delta with w = (u on the support, -1 at v, 0 elsewhere)
     const double w = l16 == v ? -1.0 : u;
@@ -1003,6 +1008,12 @@ __device__ __forceinline__ bool inv16_insert(Inv16 &I, const double *Qt, double 
     for (int j = 0; j < 16; ++j) I.H[j] = fma(f, ug[j], I.H[j]);
     S |= 1u << v;
     return true;
+}
+
+__device__ __forceinline__ bool inv16_insert(Inv16 &I, const double *Qt, double *sv, unsigned &S, int v, int l16)
+{
+    bool small;
+    return inv16_insert(I, Qt, sv, S, v, l16, small);
 }
 
 // vertex r (in S) leaves
@@ -1078,6 +1089,41 @@ __device__ __forceinline__ double solve16(double *Qt, double *sv, int n, int met
         for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
         (void)inv16_insert(I, Qt, sv, S, i0, l16);   // a single vertex is always independent
         alpha = l16 == i0 ? 1.0 : 0.0;
+        // Round 5: the explicit inverse is only as good as the supports it has been through.  A vertex that enters with a
+        // pivot of 1e-7 of its norm (four nearly coplanar points in three dimensions: a near-duplicate contig among the
+        // neighbours) leaves H with entries of 1e7 and a relative error of eps * cond; the Schur update that takes a vertex
+        // out again cancels all but 1 / cond of that magnitude, so H -- and with it every later weight vector -- is off by
+        // eps * cond^2 (6e-2 in the case tools/solve16_cases.py found: a distance 1.2 % too large, a corral of eight
+        // "independent" vertices in three dimensions).  Hence: once a small pivot has been accepted (`dirty`), every removal
+        // REBUILDS H from the tile's rows for the vertices that remain -- |S| borderings, error eps * cond of the CURRENT
+        // support, no history.  Well-conditioned problems (every benchmark configuration) never take that path.
+        bool dirty = false;
+        // H for the vertices in S from scratch; a vertex whose pivot comes out non-positive now (it was accepted on a
+        // corrupted H) is dropped and its weight shared out.  false: nothing usable was left, the solver has been set back
+        // to the nearest vertex alone (the caller leaves its minor cycle).
+        auto rebuild = [&]() __attribute__((always_inline)) -> bool {
+            const unsigned S2 = S;
+            unsigned lost = 0u;
+            S = 0u; dirty = false;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
+            for (int v = 0; v < 16; ++v) {
+                if (!((S2 >> v) & 1u)) continue;
+                bool sm;
+                if (inv16_insert(I, Qt, sv, S, v, l16, sm, 0.0)) dirty = dirty || sm;
+                else lost |= 1u << v;
+            }
+            if (lost == 0u) return true;
+            alpha = ((lost >> l16) & 1u) ? 0.0 : alpha;
+            const double s1 = group_sum16(alpha);
+            if (S != 0u && s1 > 0.0) { alpha *= fast_rcp(s1); return true; }
+            S = 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) I.H[j] = 0.0;
+            (void)inv16_insert(I, Qt, sv, S, i0, l16);
+            alpha = l16 == i0 ? 1.0 : 0.0;
+            return false;
+        };
         const double tol = 1.4210854715202004e-14 * scale;  // 64 eps * scale
         QP16_STAT(0, 1);
         for (int it = 0; it < 3 * 16 + 8; ++it) {
@@ -1091,14 +1137,21 @@ __device__ __forceinline__ double solve16(double *Qt, double *sv, int n, int met
             int jb;
             group_argmin16((mine && !(((S | banned) >> l16) & 1u)) ? gi : kInf, lane, gmin, jb);
             if (jb < 0 || !(gmin < val - tol)) break;
-            if (!inv16_insert(I, Qt, sv, S, jb, l16)) {
-                banned |= 1u << jb;
-                continue;
+            {
+                bool sm;
+                if (!inv16_insert(I, Qt, sv, S, jb, l16, sm)) {
+                    banned |= 1u << jb;
+                    continue;
+                }
+                dirty = dirty || sm;
             }
             for (int mi = 0; mi <= 16; ++mi) {
                 double beta;
                 if (!inv16_beta(I, beta)) {   // (degenerate weights: give the vertex up)
-                    if ((S >> jb) & 1u) inv16_remove(I, sv, S, jb, l16);
+                    if ((S >> jb) & 1u) {
+                        inv16_remove(I, sv, S, jb, l16);
+                        if (dirty) (void)rebuild();
+                    }
                     banned |= 1u << jb;
                     break;
                 }
@@ -1117,6 +1170,7 @@ __device__ __forceinline__ double solve16(double *Qt, double *sv, int n, int met
                 alpha = (in && l16 != kr) ? vnew : 0.0;
                 inv16_remove(I, sv, S, kr, l16);
                 if (kr == jb) banned |= 1u << jb;
+                if (dirty && !rebuild()) break;
             }
         }
         QP16_STAT(3, __popc(S));
@@ -1752,7 +1806,9 @@ __device__ __forceinline__ void gen_sync()
 }
 
 // vertex v enters the support: false (and no change) when it is affinely dependent on it
-__device__ __forceinline__ bool gen_insert(GenLds &L, int n, double s, unsigned long long &S, int v, int lane)
+// (small / reject: as inv16_insert)
+__device__ __forceinline__ bool gen_insert(GenLds &L, int n, double s, unsigned long long &S, int v, int lane, bool &small,
+                                           double reject = 1e-13)
 {
     const bool in = (S >> lane) & 1ull;
     const double a_own = (lane < n) ? L.Q[v][lane] + s : 0.0;
@@ -1781,7 +1837,8 @@ __device__ __forceinline__ bool gen_insert(GenLds &L, int n, double s, unsigned 
         delta = avv - wave_sum64(in ? a_own * u : 0.0);
         gen_sync();
     }
-    if (!(delta > 1e-13 * avv)) return false;
+    small = !(delta > kSmallPivot * avv);
+    if (!(delta > reject * avv)) return false;
     const double inv = 1.0 / delta;
     L.vu[lane] = in ? u : 0.0;
     gen_sync();
@@ -1798,6 +1855,12 @@ __device__ __forceinline__ bool gen_insert(GenLds &L, int n, double s, unsigned 
     S |= 1ull << v;
     gen_sync();
     return true;
+}
+
+__device__ __forceinline__ bool gen_insert(GenLds &L, int n, double s, unsigned long long &S, int v, int lane)
+{
+    bool small;
+    return gen_insert(L, n, s, S, v, lane, small);
 }
 
 // vertex r (in the support) leaves
@@ -1888,6 +1951,31 @@ __global__ __launch_bounds__(64) void hull_generic_kernel(QpArgs a, int nprob, c
             wave_argmin64(mine ? diag : kInf, lane, best, i0);
             (void)gen_insert(L, n, scale, S, i0, lane);   // a single vertex is always independent
             alpha = lane == i0 ? 1.0 : 0.0;
+            // (as solve16: once a small pivot has been accepted, every removal rebuilds the inverse for what remains)
+            bool dirty = false;
+            auto rebuild = [&]() -> bool {
+                const unsigned long long S2 = S;
+                unsigned long long lost = 0ull;
+                S = 0ull; dirty = false;
+                for (int j = 0; j < kGenN; ++j) L.H[lane][j] = 0.0;
+                gen_sync();
+                for (int v = 0; v < n; ++v) {
+                    if (!((S2 >> v) & 1ull)) continue;
+                    bool sm;
+                    if (gen_insert(L, n, scale, S, v, lane, sm, 0.0)) dirty = dirty || sm;
+                    else lost |= 1ull << v;
+                }
+                if (lost == 0ull) return true;
+                alpha = ((lost >> lane) & 1ull) ? 0.0 : alpha;
+                const double s1 = wave_sum64(alpha);
+                if (S != 0ull && s1 > 0.0) { alpha /= s1; return true; }
+                S = 0ull;
+                for (int j = 0; j < kGenN; ++j) L.H[lane][j] = 0.0;
+                gen_sync();
+                (void)gen_insert(L, n, scale, S, i0, lane);
+                alpha = lane == i0 ? 1.0 : 0.0;
+                return false;
+            };
             const double tol = 1.4210854715202004e-14 * scale;  // 64 eps * scale
             for (int it = 0; it < 3 * kGenN + 8; ++it) {
                 L.va[lane] = alpha;
@@ -1901,14 +1989,21 @@ __global__ __launch_bounds__(64) void hull_generic_kernel(QpArgs a, int nprob, c
                 int jb;
                 wave_argmin64((mine && !(((S | banned) >> lane) & 1ull)) ? gi : kInf, lane, gmin, jb);
                 if (jb < 0 || !(gmin < val - tol)) break;
-                if (!gen_insert(L, n, scale, S, jb, lane)) {
-                    banned |= 1ull << jb;
-                    continue;
+                {
+                    bool sm;
+                    if (!gen_insert(L, n, scale, S, jb, lane, sm)) {
+                        banned |= 1ull << jb;
+                        continue;
+                    }
+                    dirty = dirty || sm;
                 }
                 for (int mi = 0; mi <= n; ++mi) {
                     double beta;
                     if (!gen_beta(L, n, S, lane, beta)) {   // (degenerate weights: give the vertex up)
-                        if ((S >> jb) & 1ull) gen_remove(L, n, S, jb, lane);
+                        if ((S >> jb) & 1ull) {
+                            gen_remove(L, n, S, jb, lane);
+                            if (dirty) (void)rebuild();
+                        }
                         banned |= 1ull << jb;
                         break;
                     }
@@ -1926,6 +2021,7 @@ __global__ __launch_bounds__(64) void hull_generic_kernel(QpArgs a, int nprob, c
                     alpha = (in && lane != kr) ? vnew : 0.0;
                     gen_remove(L, n, S, kr, lane);
                     if (kr == jb) banned |= 1ull << jb;
+                    if (dirty && !rebuild()) break;
                 }
             }
             L.va[lane] = alpha;
