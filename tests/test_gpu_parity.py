@@ -345,7 +345,7 @@ CASES = [
     # wide rows (round 5: shadow rows of two to four 144-column slices): k = 5 width on the fused kernel with overlapping
     # bins (update-mode shortlist, repeated rounds), the default neighbour count on the list-based kernels
     (900, 528, 8, 5, 5, 3e-3, 0.6, 8, 257),
-    (800, 300, 6, 15, 3, 3e-3, 0.6, 20, 300),
+    (600, 300, 6, 15, 3, 3e-3, 0.6, 20, 300),
     (1500, 200, 5, 5, 6, 5e-3, 0.9, 4, 2048),
 ]
 
@@ -964,11 +964,11 @@ F16_CASES = [
     (1000, 64, 4, 15, 20, 0, True),        # duplicated members: exact ties at the selection boundary -> exact path
     # rows wider than the 288-column tile that stages the query row (round 5): the WIDEROW instantiation's windows --
     # two windows with a short second one, k = 5 width (two windows), the widest rows (576 = exactly two), many batch entries
-    (900, 300, 4, 15, 20, 0, False),
-    (900, 528, 4, 15, 20, 0, False),
+    (600, 300, 4, 15, 20, 0, False),
+    (600, 528, 4, 15, 20, 0, False),
     (700, 573, 3, 16, 20, 0, False),
     (900, 300, 4, 12, 3, 600, False),
-    (800, 528, 4, 15, 20, 0, True),
+    (500, 528, 4, 15, 20, 0, True),
 ]
 
 
@@ -1312,7 +1312,7 @@ def test_persistent_pack_equals_rebuild(O, N, D, B, m, iters, sigma, mix, n_seed
     (24000, 136, 24, 5, 4, 4.5e-3, 0.3, None, 2048, "any"),        # overlapping bins: labels change in later sweeps (holes, departures)
     (20000, 146, 20, 5, 3, 2e-3, 0.2, None, 4096, "any"),          # ten coverage columns: the tile-skipping pool build
     (5000, 136, 8, 8, 3, 2e-3, 0.2, None, 512, "any"),             # m = 8 builds
-    (4000, 140, 8, 15, 3, 2e-3, 0.2, None, 512, "any"),            # m = 15 builds (16-entry lists), five coverage columns
+    (2400, 140, 8, 15, 3, 2e-3, 0.2, None, 512, "any"),            # m = 15 builds (16-entry lists), five coverage columns
     (6000, 136, 8, 5, 4, 6e-3, 0.6, 12, 512, "any"),               # heavy overlap: long shortlists, the fit drops the pools
 ])
 def test_threshold_pools_equal_two_sweeps(O, N, D, B, m, iters, sigma, mix, n_seed, batch, expect):
