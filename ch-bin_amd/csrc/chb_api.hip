@@ -1564,7 +1564,10 @@ int chb_fit_cluster_ex(chb_ctx *h, int64_t B, const int64_t *initial_bins, const
     // batch rebuilds the CSR and the padded pack of ALL labelled contigs (cost ~ N per batch, ~ N^2 / K per sweep), while a
     // batch is a smaller share of the sweep and collides with itself no more often (measured: 115 against 124 ms per sweep
     // at 500k x 140 x 128, 517 against 538 at 1M x 146 x 200; 100k contigs are best served by 8192)
-    int Kmax = batch > 0 ? batch : 8192 * std::max(1, (int)std::lround(std::sqrt((double)h->world))) * (n_move >= 300000 ? 2 : 1);
+    // (round 5, with the pools' cheaper shortlist launches: four times from 750k contigs -- 1M x 146 x 200: 342 against 361 ms per
+    //  sweep; 500k x 140 x 128 stays best at twice: 105.5 against 108.5)
+    int Kmax = batch > 0 ? batch : 8192 * std::max(1, (int)std::lround(std::sqrt((double)h->world))) *
+                                       ((n_move >= 750000 && h->world == 1) ? 4 : (n_move >= 300000 ? 2 : 1));   // (sharded: as before)
     if (m > kMaxM && batch <= 0) Kmax = std::min(Kmax, 512);   // the plain kernels: one wavefront per (contig, bin)
     if (Kmax > n_move) Kmax = (int)std::max<int64_t>(n_move, 1);
     h->last_batch = Kmax;
