@@ -1,7 +1,7 @@
 """Developer soak: random small configurations, HIP fit_cluster vs the CPU oracle (labels, sweep
 counts, per-sweep change counts must be identical).  usage: python tools/fuzz_fit.py [n_cases] [seed] [big|m16]   (big: bins of > 512 members, few bins; m16: the fused
 16-lane kernel, 6 <= m <= 16; manybins: 65 .. 400 bins of a handful of members -- more than one 64-bin tile of the
-per-fit query-norm table)"""
+per-fit query-norm table; wide: rows of 158 .. 573 columns -- the wide shortlist builds of round 5 and the fused kernels on them)"""
 import os
 import sys
 
@@ -16,6 +16,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 m16 = len(sys.argv) > 3 and sys.argv[3] == "m16"
 manybins = len(sys.argv) > 3 and sys.argv[3] == "manybins"
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ctx = _lib.default_context()
 bad = 0
@@ -44,6 +45,9 @@ for t in range(n_cases):
         N = int(rng.integers(2000, 5000)); B = int(rng.integers(65, 400)); m = int(rng.choice([1, 3, 5, 5]))
         D = int(rng.choice([100, 136, 140, 146])); S = 1 if D < 140 else (5 if D < 146 else 10)
         iters = int(rng.integers(1, 3)); batch = int(rng.choice([0, 300, 1000])); n_seed = int(rng.integers(1, 4))
+    if wide:
+        N = int(rng.integers(200, 1300)); D = int(rng.choice([158, 200, 285, 286, 300, 429, 430, 528, 573, 574]))
+        S = int(rng.choice([1, 1, 5, 10])); iters = int(rng.integers(1, 4))
     metric = str(rng.choice(["convex", "convex", "convex", "affine"]))
     if m > D or D < 24 or (D < 40 and m > 8):   # (round 4, case `120 91 m16` #101: 14 vertices in D = 24 straddle orth's cutoff too)
         # m > D: the affine hull of > D generic points is the whole space, every distance is rounding
