@@ -40,6 +40,7 @@ CASES = [
     (700, 40, 6, 15, 3, 9e-3, 0.5, 20, 150),       # m = 15: fused 16-lane kernel (hull_select_qp16_kernel)
     (10000, 136, 32, 5, 4, 1.5e-3, 0.0, None, 0),  # BASELINE configs[1] at its stated size (seed 0 as in test_gpu_configs)
     (6000, 140, 12, 5, 3, 2e-3, 0.2, 60, 0),       # five coverage columns: the tile-skipping shortlist build on a rank's slice
+    (1200, 300, 6, 5, 3, 3e-3, 0.5, 10, 300),      # wide rows (round 5: three 144-column slices) on position slices that do not start at 0
 ]
 res = {}
 for case, (N, D, B, m, iters, sigma, mix, n_seed, batch) in enumerate(CASES):
