@@ -421,6 +421,9 @@ def main():
             cfg_idx = next((i for i, shp in BASELINE_CONFIGS.items() if shp == (N, D, B)), None)
             if cfg_idx in (3, 4) and m <= 5:
                 default_tf = TRAFFIC_FILE.replace("_traffic", f"_cfg{cfg_idx}_traffic")
+            wide528 = (N, D, B) == (100_000, 528, 64) and m == 5   # the wide-row run of the profile set (KmerK = 5 width)
+            if wide528:
+                default_tf = TRAFFIC_FILE.replace("_traffic", "_wide528_traffic")
             tj = json.load(open(args.traffic_file or os.path.join(ROOT, "profiles", default_tf)))
             tf_label = (f"{args.traffic_file} (this run's own rocprofv3 --pmc passes; committed as profiles/{default_tf})"
                         if args.traffic_file else f"profiles/{default_tf}")
@@ -431,11 +434,14 @@ def main():
             #  the ordinary base builds -- tile skipping and threshold pools are chosen per fit)
             base_sl = sorted((k for k in tr if k.startswith(f"shortlist_kernel<{ml}, false, ") and ", 0, " in k and not k.endswith("true>")),
                              key=lambda k: -tr[k].get("launches", 0))
+            if Dz > 160:   # the wide builds: shortlist_wide_kernel<ML, UPD, slices>
+                base_sl = [f"shortlist_wide_kernel<{ml}, false, {Dz // 144}>"]
             tmap = {"prefilter": base_sl + [f"shortlist_kernel<{ml}, false, 9, 0, false>", f"shortlist_kernel<{ml}, false, 9, 0>",
                                             f"shortlist_kernel<{ml}, false, 9>"],
                     "hull_qp": ["hull_select_qp_kernel<5, 7, 4, true>"] if m <= 5 else
                                ["hull_select_qp16_kernel<4, false>", "hull_select_qp16_kernel<4>"],
-                    "prefilter_update": [f"shortlist_kernel<{1 if m <= 8 else 2}, true, {9 if D <= 141 else 10}, 0, false, false, false>",
+                    "prefilter_update": ([f"shortlist_wide_kernel<{1 if m <= 8 else 2}, true, {Dz // 144}>"] if Dz > 160 else []) +
+                                        [f"shortlist_kernel<{1 if m <= 8 else 2}, true, {9 if D <= 141 else 10}, 0, false, false, false>",
                                          f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false, false>",
                                          f"shortlist_kernel<{1 if m <= 8 else 2}, true, 9, 0, false>",
                                          "shortlist_kernel<1, true, 9, 0>", "shortlist_kernel<1, true, 9>"]}
@@ -443,7 +449,7 @@ def main():
             if tj.get("kernel_source_stamp") != stamp:
                 traffic_note = (f"{tf_label} was measured on kernel sources {tj.get('kernel_source_stamp')}, "
                                 f"this build is {stamp}: not quoted")
-            elif (((N, D, B) == (100_000, 136, 64) and m in (5, 15)) or (cfg_idx in (3, 4) and m == 5)) and not args.batch and not use_dist and fused:
+            elif (((N, D, B) == (100_000, 136, 64) and m in (5, 15)) or (cfg_idx in (3, 4) and m == 5) or wide528) and not args.batch and not use_dist and fused:
                 for name, names in tmap.items():
                     src = next((k for k in names if k in tr), None)
                     if src is not None:

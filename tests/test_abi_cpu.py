@@ -132,7 +132,7 @@ def test_committed_traffic_tables_match_the_sources():
     import json
     import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for name in ("r05_traffic.json", "r05_m15_traffic.json", "r05_cfg3_traffic.json", "r05_cfg4_traffic.json"):
+    for name in ("r05_traffic.json", "r05_m15_traffic.json", "r05_cfg3_traffic.json", "r05_cfg4_traffic.json", "r05_wide528_traffic.json"):
         if not os.path.exists(os.path.join(root, "profiles", name)):
             pytest.skip(f"profiles/{name} not collected yet")
         t = json.load(open(os.path.join(root, "profiles", name)))

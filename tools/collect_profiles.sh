@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's profile set on the GPU box into gpurun_out/<tag>/ (copy what is to be judged into profiles/).
-# usage (through gpurun): bash tools/collect_profiles.sh r05prof [quick | a | b]
+# usage (through gpurun): bash tools/collect_profiles.sh r05prof [quick | a | b | w]
 #   (the whole set no longer fits one 20-minute gpurun call: `a` = configs[2] and m = 15, `b` = configs[1] / [3] / [4] with
 #    their counter tables and the wide-feature run; both write into the same gpurun_out/<tag>/)
 #   kernel stats (rocprofv3 --kernel-trace --stats) + the bench line of the same run, HBM-side counters (separate --pmc
@@ -13,7 +13,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
 PB="--steps 1 --warmup 0 --cpu-sample 0 --no-e2e --no-extra"
-if [ "$quick" != "b" ]; then
+if [ "$quick" != "b" ] && [ "$quick" != "w" ]; then
 echo "[1] kernel stats, config 2"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg2 -o t -- $B --steps 3 --warmup 1 --cpu-sample 0 --no-e2e --no-extra > $O/bench_under_rocprof.json 2> $O/err_stats_cfg2.txt || exit 1
 echo "[2] pmc fetch"; rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o t -- $B --steps 1 --warmup 0 --cpu-sample 0 --no-e2e --no-extra > $O/bench_pmc_fetch.json 2> $O/err_pmc_fetch.txt || exit 1
 echo "[3] pmc write"; rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o t -- $B --steps 1 --warmup 0 --cpu-sample 0 --no-e2e --no-extra > $O/bench_pmc_write.json 2> $O/err_pmc_write.txt || exit 1
@@ -36,6 +36,7 @@ echo "[5] m = 15"; $B --neighbors 15 --steps 3 --warmup 1 --no-extra --traffic-f
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_m15 -o t -- $B --neighbors 15 --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-extra > $O/m15_bench_under_rocprof.json 2> $O/err_stats_m15.txt || exit 1
 [ "$quick" = "a" ] && exit 0
 fi
+if [ "$quick" != "w" ]; then
 echo "[6] configs[1]"; $B --contigs 10000 --bins 32 --steps 5 --warmup 2 --cpu-sample 200 --no-extra > $O/cfg1_bench.json 2> $O/err_cfg1.txt || exit 1
 echo "[7] configs[3]"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg3 -o t -- $B --contigs 500000 --dim 140 --bins 128 --steps 2 --warmup 1 --cpu-sample 0 --no-extra > $O/cfg3_bench_under_rocprof.json 2> $O/err_cfg3.txt || exit 1
 echo "[8] configs[4]"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -o t -- $B --contigs 1000000 --dim 146 --bins 200 --steps 2 --warmup 1 --cpu-sample 0 --no-extra > $O/cfg4_bench_under_rocprof.json 2> $O/err_cfg4.txt || exit 1
@@ -51,7 +52,15 @@ for c in cfg3:"--contigs 500000 --dim 140 --bins 128" cfg4:"--contigs 1000000 --
   python3 $R/tools/traffic_from_pmc.py $O/$name $O/this_$name > $O/traffic_${name}_log.txt 2>&1 || exit 1
   $B $cargs --steps 2 --warmup 1 --cpu-sample 0 --no-extra --traffic-file $O/this_${name}_traffic.json > $O/${name}_bench.json 2> $O/err_${name}_bench.txt || exit 1
 done
+fi   # (w: the wide-feature part only)
 # VERDICT r4 item 8, "first, the numbers": a feature width beyond the shortlist stage's 157 columns (k = 5: 512 k-mer columns)
-echo "[10] wide features"; $B --dim 528 --steps 2 --warmup 1 --cpu-sample 0 --no-extra --no-e2e > $O/wide528_bench.json 2> $O/err_wide528.txt || exit 1
+echo "[10] wide features"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_wide528 -o t -- $B --dim 528 --steps 2 --warmup 1 --cpu-sample 0 --no-extra --no-e2e > $O/wide528_bench_under_rocprof.json 2> $O/err_stats_wide528.txt || exit 1
+for p in tcp:"TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" tcc:"TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" sq:"SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES" fetch:FETCH_SIZE write:WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc ${p#*:} --output-format csv -d $O/wide528/pmc_${p%%:*} -o t -- $B --dim 528 $PB > $O/wide528_bench_pmc_${p%%:*}.json 2> $O/wide528_err_pmc_${p%%:*}.txt || exit 1
+  find $O/wide528 -name "*kernel_trace.csv" -delete
+done
+python3 $R/tools/traffic_from_pmc.py $O/wide528 $O/this_wide528 > $O/traffic_wide528_log.txt 2>&1 || exit 1
+$B --dim 528 --steps 3 --warmup 1 --cpu-sample 0 --no-extra --no-e2e --traffic-file $O/this_wide528_traffic.json > $O/wide528_bench.json 2> $O/err_wide528.txt || exit 1
 find $O -name "*kernel_trace.csv" -size +8M -delete
 echo done

@@ -17,3 +17,5 @@ for c in cfg3 cfg4; do
   [ -f $P/${c}_bench.json ] && cp $P/${c}_bench.json ${R}_${c}_bench.json
 done
 [ -f $P/wide528_bench.json ] && cp $P/wide528_bench.json ${R}_wide528_bench.json
+[ -f $P/this_wide528_traffic.json ] && cp $P/this_wide528_traffic.json ${R}_wide528_traffic.json && cp $P/this_wide528_pmc_hbm_counters.csv ${R}_wide528_pmc_hbm_counters.csv
+[ -f $P/stats_wide528/t_kernel_stats.csv ] && cp $P/stats_wide528/t_kernel_stats.csv ${R}_wide528_kernel_stats_bench_steps2.csv && cp $P/wide528_bench_under_rocprof.json ${R}_wide528_bench_under_rocprof.json
